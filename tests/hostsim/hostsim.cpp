@@ -1,0 +1,63 @@
+// hostsim.cpp - TEST INFRASTRUCTURE ONLY.
+// Compiles the engine headers with -DTHOR_HOSTSIM (1-lane teams, plain loops) into a CPU
+// executable so that the bit-exactness of the algorithm can be checked against the reference
+// encoder (oracle/_ref/Thorenc) in a container without a GPU.  The product library
+// (thor_amd/csrc/thor_hip.cpp) never links or calls this; it has no CPU path.
+#include "../../thor_amd/csrc/tk_block.h"
+#include "../../thor_amd/csrc/tk_filters.h"
+#include "../../thor_amd/csrc/tk_cli.h"
+
+namespace tk {
+Tables g_tab;
+namespace backend {
+void* dev_alloc(size_t n) { return calloc(1, n); }
+void dev_free(void* p) { free(p); }
+void h2d(void* d, const void* h, size_t n) { memcpy(d, h, n); }
+void d2h(void* h, const void* d, size_t n) { memcpy(h, d, n); }
+void dev_memset(void* d, int v, size_t n) { memset(d, v, n); }
+void dev_sync() {}
+size_t team_ws_bytes(int pix_bytes) { return pix_bytes == 1 ? sizeof(TeamWs<uint8_t>) : sizeof(TeamWs<uint16_t>); }
+
+template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>*, int S) {
+  Team t{0, 1};
+  for (int s = 0; s < S; s++) {
+    const FrameJob<PIX>& J = jobs[s];
+    for (int k = 0; k < J.sb_rows; k++)
+      for (int l = 0; l < J.sb_cols; l++) {
+        const int sbi = k * J.sb_cols + l;
+        TeamWs<PIX>* ws = (TeamWs<PIX>*)J.scratch;
+        BitSink out;
+        out.buf = J.sb_bits + (size_t)sbi * J.sb_words; out.pos = 0; out.cap = J.sb_words * 32; out.emit = 1; out.ovf = 0;
+        process_sb(t, J, ws, k * kMaxSb, l * kMaxSb, out);
+        J.sb_nbits[sbi] = out.pos;
+        J.sb_status[sbi] = out.ovf;
+      }
+  }
+}
+template <typename PIX> void run_deblock(const FrameJob<PIX>* jobs, const FrameJob<PIX>*, int S) {
+  for (int s = 0; s < S; s++) {
+    const FrameJob<PIX>& J = jobs[s];
+    DbParams P;
+    P.width = J.cfg.width; P.height = J.cfg.height; P.bitdepth = J.cfg.bitdepth;
+    const int qpc = g_tab.chroma_qp[J.qp];
+    P.beta = g_tab.beta[J.qp] << (P.bitdepth - 8);
+    P.tc_y = g_tab.tc[J.qp] >> (12 - P.bitdepth);
+    P.tc_c = g_tab.tc[qpc] >> (12 - P.bitdepth);
+    P.cells = J.cells; P.cs = J.cell_stride;
+    for (int pass = 0; pass < 4; pass++) deblock_pass(J.rec, P, pass, 0, 1);
+  }
+}
+template <typename PIX> void run_make_ref(const FrameJob<PIX>* hjobs, const Plane3<PIX>* dst, int S) {
+  for (int s = 0; s < S; s++) make_ref_rows(hjobs[s].rec, dst[s], hjobs[s].cfg.width, hjobs[s].cfg.height, 0, 1);
+}
+template void run_superblocks<uint8_t>(const FrameJob<uint8_t>*, const FrameJob<uint8_t>*, int);
+template void run_deblock<uint8_t>(const FrameJob<uint8_t>*, const FrameJob<uint8_t>*, int);
+template void run_make_ref<uint8_t>(const FrameJob<uint8_t>*, const Plane3<uint8_t>*, int);
+}  // namespace backend
+}  // namespace tk
+
+int main(int argc, char** argv) {
+  tk::init_tables(&tk::g_tab);
+  tk::CliArgs a = tk::cli_parse(argc, argv);
+  return tk::cli_run<uint8_t>(a);
+}

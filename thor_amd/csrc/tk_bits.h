@@ -1,0 +1,304 @@
+// tk_bits.h - bit sink (count or emit) and the block-level syntax of the Thor bitstream.
+// Restates, for RDO bit counting on the device AND for the final emission, the syntax of
+// enc/putvlc.c:73-160 (put_vlc), enc/write_bits.c:123-143 (write_mv), :145-241 (write_coeff),
+// :257-358 (write_super_mode) and :360-600 (write_block).  4:2:0 only, no delta-QP syntax
+// (max_delta_qp = bitrate = 0 in every BASELINE config).
+#pragma once
+#include "tk_common.h"
+
+namespace tk {
+
+struct BitSink {
+  uint32_t* buf;  // word w holds stream bits [32w, 32w+32), first bit in the MSB
+  int pos;        // bit position
+  int cap;        // capacity in bits
+  int emit;       // 0: count only
+  int ovf;
+};
+
+TK_DEV void bs_put(BitSink& b, int n, uint32_t val) {
+  if (b.emit && n > 0) {
+    if (b.pos + n > b.cap) {
+      b.ovf = 1;
+    } else {
+      uint32_t msk = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+      val &= msk;
+      int w = b.pos >> 5, off = b.pos & 31, room = 32 - off;
+      if (n <= room) {
+        int sh = room - n;
+        b.buf[w] = (b.buf[w] & ~(msk << sh)) | (val << sh);
+      } else {
+        int lo = n - room;  // bits that spill into the next word
+        uint32_t mroom = room >= 32 ? 0xffffffffu : ((1u << room) - 1u);
+        b.buf[w] = (b.buf[w] & ~mroom) | (val >> lo);
+        uint32_t mlo = (1u << lo) - 1u;
+        b.buf[w + 1] = (b.buf[w + 1] & ~(mlo << (32 - lo))) | ((val & mlo) << (32 - lo));
+      }
+    }
+  }
+  b.pos += n;
+}
+
+// (len, code) of VLC table n for symbol cn (enc/putvlc.c:73-160).
+TK_DEV void vlc_code(int n, uint32_t cn, int& len, uint32_t& code) {
+  if (n == 6 || n == 7) {
+    if (cn == 0) { len = 2; code = 2; return; }
+    if (n == 6) { cn++; n = 2; }
+    else {
+      if (cn == 1) { len = 3; code = 6; return; }
+      if (cn < 4) { len = 4; code = (7u << 1) | (cn & 1u); return; }
+      cn += 4; n = 3;
+    }
+  }
+  if (n <= 5) {
+    uint32_t t = 1u << n;
+    if ((int)cn < (int)(5u * t)) {
+      code = t + (cn & (t - 1u));
+      len = 1 + n + (int)(cn >> n);
+    } else {
+      code = cn - 5u * t + t;
+      len = (5 - n) + 1 + 2 * ilog2(code);
+    }
+    return;
+  }
+  if (n == 8) {
+    if (cn < 6) { len = 2 + (int)(cn >> 1); code = 2u + (cn & 1u); }
+    else { len = 5; code = cn - 6u; }
+    return;
+  }
+  if (n == 10) { code = cn + 1u; len = 1 + 2 * ilog2(code); return; }
+  // 11..18: truncated unary with m = n-10 symbols+1
+  uint32_t m = (uint32_t)(n - 10);
+  len = (cn == m) ? (int)m : (int)cn + 1;
+  code = (cn != m) ? 1u : 0u;
+}
+
+TK_DEV int bs_vlc(BitSink& b, int n, uint32_t cn) {
+  int len; uint32_t code;
+  vlc_code(n, cn, len, code);
+  if (len > 32) { bs_put(b, len - 32, 0); bs_put(b, 32, code); }
+  else bs_put(b, len, code);
+  return len;
+}
+TK_DEV int vlc_len(int n, uint32_t cn) {
+  int len; uint32_t code;
+  vlc_code(n, cn, len, code);
+  return len;
+}
+
+// write_mv (enc/write_bits.c:123-143): mvd via VLC 7 + sign bit per component, x first.
+TK_DEV void bs_mv(BitSink& b, mv_t mv, mv_t mvp) {
+  int dx = (int16_t)(mv.x - mvp.x), dy = (int16_t)(mv.y - mvp.y);
+  uint32_t ax = (uint16_t)iabs(dx), ay = (uint16_t)iabs(dy);
+  bs_vlc(b, 7, ax);
+  if (ax > 0) bs_put(b, 1, dx < 0);
+  bs_vlc(b, 7, ay);
+  if (ay > 0) bs_put(b, 1, dy < 0);
+}
+
+// write_coeff (enc/write_bits.c:145-241). coeff: qsize x qsize row-major (qsize=min(size,16)),
+// type bit0 = chroma, bit1 = intra block.
+TK_DEV void bs_coeff(BitSink& b, const int16_t* coeff, int size, int type) {
+  const int qsize = size < kMaxQuant ? size : kMaxQuant;
+  const int N = qsize * qsize;
+  const int16_t* izz = qsize == 4 ? TK_TAB.izz4 : (qsize == 8 ? TK_TAB.izz8 : TK_TAB.izz16);
+  const int chroma = type & 1, intra = (type >> 1) & 1;
+  int vlc_adaptive = intra && !chroma;
+  const uint32_t eob_pos = chroma ? 0u : 2u;
+  const int runtab = (chroma && size <= 8) ? 10 : 6;
+
+  int last_pos = N - 1;
+  while (last_pos > 0 && coeff[izz[last_pos]] == 0) last_pos--;
+
+  int pos = 0;
+  if (chroma) {
+    int c0 = coeff[izz[0]];
+    if (last_pos == 0 && iabs(c0) == 1) { bs_put(b, 2, 2u + (c0 < 0)); pos = N; }
+    else bs_put(b, 1, 0);
+  }
+  int level_mode = 1, level = 1;
+  while (pos <= last_pos) {
+    int c;
+    if (level_mode) {
+      while (pos <= last_pos && level > 0) {
+        c = coeff[izz[pos++]];
+        level = iabs(c);
+        bs_vlc(b, vlc_adaptive, (uint32_t)level);
+        if (level > 0) bs_put(b, 1, c < 0);
+        if (!chroma) vlc_adaptive = level > 3;
+      }
+    }
+    int run = 0;
+    c = 0;
+    while (c == 0 && pos <= last_pos) {
+      c = coeff[izz[pos++]];
+      run += !c;
+      if (c) {
+        level = iabs(c);
+        int sign = c < 0;
+        uint32_t cn = (level == 1) ? (uint32_t)((run * 5) / 4) : (uint32_t)(run * 5 + 4);
+        bs_vlc(b, runtab, cn + (cn >= eob_pos));
+        level_mode = level > 1;
+        if (level > 1) bs_vlc(b, 0, (uint32_t)((level - 2) * 2 + sign));
+        else bs_put(b, 1, sign);
+        run = 0;
+      }
+    }
+  }
+  if (pos < N && level_mode) { bs_vlc(b, vlc_adaptive, 0); pos++; }
+  if (pos < N) bs_vlc(b, runtab, eob_pos);
+}
+
+// Everything write_block / write_super_mode read besides the block parameters.
+struct SynCtx {
+  int frame_type, num_ref, enable_bipred, interp_ref;
+  int max_pb_part, max_tb_part, num_intra_modes;
+  int size, encode_this_size;
+  int ctx_index, ctx_cbp;       // block_context_t index / cbp (common_block.c:283-309)
+  int num_skip, num_merge;
+  mv_t mvp;
+};
+
+struct BlkParam {  // block_param_t without the coefficient arrays (common/types.h:205-222)
+  int8_t mode, intra_mode, skip_idx, pb_part, ref0, ref1, dir, tb_param, tb_split;
+  uint8_t cbp_y, cbp_u, cbp_v;  // bit masks (4 TUs, MSB = TU0) when tb_split, else 0/1
+  mv_t mv0[4], mv1[4];
+};
+
+// write_super_mode (enc/write_bits.c:257-358).
+TK_DEV void bs_super_mode(BitSink& b, const SynCtx& s, int mode, int ref0, int split_flag) {
+  if (s.frame_type != F_I) {
+    if (!s.encode_this_size) { bs_put(b, 1, !split_flag); return; }
+    int bipred_possible = s.num_ref > 1 && s.enable_bipred;
+    int split_possible = s.size > kMinBlk;
+    int maxbit = 2 + s.num_ref + split_possible + bipred_possible;
+    if (s.interp_ref > 2) maxbit -= 1;
+    int moved = (s.ctx_index == 2 || s.ctx_index > 3);
+    if (split_flag == 1) {
+      if (s.size > 128) { bs_put(b, 1, 0); return; }
+      int code = 1;
+      if (moved) code = (code + 3) % 4;
+      bs_vlc(b, 10 + maxbit, (uint32_t)code);
+      return;
+    }
+    int code = 0;
+    if (s.interp_ref) {
+      if (mode == M_SKIP) code = 0;
+      else if (mode == M_MERGE) code = 2;
+      else if (mode == M_BIPRED) code = 3;
+      else if (mode == M_INTRA) code = 4;
+      else if (mode == M_INTER && ref0 > 0) code = 4 + ref0;
+      else code = 4 + s.num_ref;
+      if (!bipred_possible && code > 3) code--;
+      if (!split_possible && code > 1) code--;
+      if (moved && s.size > kMinBlk && code < 3) code = (code + 2) % 3;
+    } else {
+      if (mode == M_SKIP) code = 0;
+      else if (mode == M_INTER && ref0 == 0) code = 2;
+      else if (mode == M_MERGE) code = 3;
+      else if (mode == M_BIPRED) code = 4;
+      else if (mode == M_INTRA) code = 5;
+      else if (mode == M_INTER && ref0 > 0) code = 5 + ref0;
+      if (!bipred_possible && code > 4) code--;
+      if (!split_possible && code > 1) code--;
+      if (moved && s.size > kMinBlk && code < 4) code = (code + 3) % 4;
+    }
+    bs_vlc(b, 10 + maxbit, (uint32_t)code);
+  } else {
+    if (s.encode_this_size && (s.size > kMinBlk || split_flag == 1)) bs_put(b, 1, (uint32_t)split_flag);
+  }
+}
+
+TK_DEV int cbp_code(int cbp) {  // cbp_table (enc/write_bits.c:382)
+  return cbp == 0 ? 1 : cbp == 1 ? 0 : cbp == 2 ? 5 : cbp == 3 ? 2 : cbp == 4 ? 6 : cbp == 5 ? 3 : cbp == 6 ? 7 : 4;
+}
+
+// write_block (enc/write_bits.c:360-600).  cy/cu/cv: quantised coefficients, TU t of a
+// tb-split block at offset t*256 (MAX_QUANT_SIZE^2) like the reference.
+TK_DEV int bs_block(BitSink& b, const SynCtx& s, const BlkParam& p, const int16_t* cy, const int16_t* cu,
+                    const int16_t* cv) {
+  const int start = b.pos;
+  const int size = s.size, size_uv = size >> 1;
+  const int mode = p.mode;
+  const int coeff_type = (mode == M_INTRA) << 1;
+  bs_super_mode(b, s, mode, p.ref0, 0);
+
+  if (mode == M_INTRA) {
+    if (s.num_intra_modes <= 4) bs_put(b, 2, (uint32_t)p.intra_mode);
+    else bs_vlc(b, 8, (uint32_t)p.intra_mode);
+  } else if (mode == M_INTER) {
+    if (s.max_pb_part > 1) bs_vlc(b, 13, (uint32_t)p.pb_part);
+    mv_t mvp2 = s.mvp;
+    bs_mv(b, p.mv0[0], mvp2);
+    mvp2 = p.mv0[0];
+    if (p.pb_part == P_HOR) bs_mv(b, p.mv0[2], mvp2);
+    else if (p.pb_part == P_VER) bs_mv(b, p.mv0[1], mvp2);
+    else if (p.pb_part == P_QUAD) { bs_mv(b, p.mv0[1], mvp2); bs_mv(b, p.mv0[2], mvp2); bs_mv(b, p.mv0[3], mvp2); }
+  } else if (mode == M_BIPRED) {
+    mv_t mvp2 = s.mvp;
+    if (p.pb_part == P_NONE) bs_mv(b, p.mv0[0], mvp2);
+    if (s.frame_type == F_B) mvp2 = p.mv0[0];
+    bs_mv(b, p.mv1[0], mvp2);
+    if (p.pb_part != P_NONE) {
+      mvp2 = p.mv1[0];
+      if (p.pb_part == P_HOR) bs_mv(b, p.mv1[2], mvp2);
+      else if (p.pb_part == P_VER) bs_mv(b, p.mv1[1], mvp2);
+      else { bs_mv(b, p.mv1[1], mvp2); bs_mv(b, p.mv1[2], mvp2); bs_mv(b, p.mv1[3], mvp2); }
+    }
+    if (s.frame_type == F_P) {
+      if (s.num_ref == 2) bs_vlc(b, 13, (uint32_t)(2 * p.ref0 + p.ref1));
+      else bs_vlc(b, 10, (uint32_t)(4 * p.ref0 + p.ref1));
+    }
+  } else if (mode == M_SKIP || mode == M_MERGE) {
+    int nvec = mode == M_SKIP ? s.num_skip : s.num_merge;
+    if (nvec == 4) bs_put(b, 2, (uint32_t)p.skip_idx);
+    else if (nvec == 3) bs_vlc(b, 12, (uint32_t)p.skip_idx);
+    else if (nvec == 2) bs_put(b, 1, (uint32_t)p.skip_idx);
+  }
+
+  if (mode != M_SKIP) {
+    const int tb_split = p.tb_split;
+    int code;
+    const int off = mode == M_MERGE ? 1 : 2;
+    if (s.max_tb_part > 1 && tb_split) {
+      code = off;
+    } else {
+      int cbp = p.cbp_y + (p.cbp_u << 1) + (p.cbp_v << 2);
+      code = cbp_code(cbp);
+      if (mode == M_MERGE) {
+        if (code == 1) code = 7;
+        else if (code > 1) code--;
+      } else if (s.ctx_cbp == 0 && code < 2) code = 1 - code;
+      if (s.max_tb_part > 1 && code >= off) code++;
+    }
+    bs_vlc(b, 0, (uint32_t)code);
+
+    if (tb_split == 0) {
+      if (p.cbp_y) bs_coeff(b, cy, size, coeff_type | 0);
+      if (p.cbp_u) bs_coeff(b, cu, size_uv, coeff_type | 1);
+      if (p.cbp_v) bs_coeff(b, cv, size_uv, coeff_type | 1);
+    } else if (size_uv > 4) {
+      for (int t = 0; t < 4; t++) {
+        int ty = (p.cbp_y >> (3 - t)) & 1, tu = (p.cbp_u >> (3 - t)) & 1, tv = (p.cbp_v >> (3 - t)) & 1;
+        int c = cbp_code(ty + (tu << 1) + (tv << 2));
+        if (s.ctx_cbp == 0 && c < 2) c = 1 - c;
+        bs_vlc(b, 0, (uint32_t)c);
+        if (ty) bs_coeff(b, cy + t * 256, size / 2, coeff_type | 0);
+        if (tu) bs_coeff(b, cu + t * 256, size_uv / 2, coeff_type | 1);
+        if (tv) bs_coeff(b, cv + t * 256, size_uv / 2, coeff_type | 1);
+      }
+    } else {
+      for (int t = 0; t < 4; t++) {
+        int ty = (p.cbp_y >> (3 - t)) & 1;
+        bs_put(b, 1, (uint32_t)ty);
+        if (ty) bs_coeff(b, cy + t * 256, size / 2, coeff_type | 0);
+      }
+      bs_vlc(b, 13, (uint32_t)(p.cbp_u + 2 * p.cbp_v));
+      if (p.cbp_u) bs_coeff(b, cu, size_uv, coeff_type | 1);
+      if (p.cbp_v) bs_coeff(b, cv, size_uv, coeff_type | 1);
+    }
+  }
+  return b.pos - start;
+}
+
+}  // namespace tk

@@ -1,0 +1,918 @@
+// tk_block.h - the per-superblock decision engine: quadtree recursion, early skip, RDO trials,
+// final encode (recon + cell state + bit emission).
+// Specification followed: enc/encode_block.c:2401-2566 (process_block), :1835-2121
+// (mode_decision_rdo), :1340-1514 (encode_block), :1100-1338 (encode_and_reconstruct_*),
+// :1679-1833 (search_bipred_prediction_params), :1033-1098 (search_inter_prediction_params),
+// :2123-2392 (early skip), :916-926 (cost_calc), :1568-1613 (copy_deblock_data);
+// common/inter_prediction.c:413-834 (get_mv_pred / get_mv_merge / get_mv_skip);
+// common/common_block.c:283-309 (find_block_contexts), :347-428 (improve_uv_prediction);
+// common/common_block.h:52-95 (availability).
+#pragma once
+#include "tk_common.h"
+#include "tk_bits.h"
+#include "tk_pred.h"
+#include "tk_xform.h"
+#include "tk_me.h"
+
+namespace tk {
+
+struct Node {
+  int size, ypos, xpos, bw, bh;
+  int stage, child;
+  unsigned cost_small;
+  int bitpos0;
+  int encode_this_size, encode_rect;
+  SynCtx syn;
+  InterPred skip[2], merge[2];
+  BlkParam best;
+};
+
+template <typename PIX> struct TeamWs {
+  XformWs xf;
+  MeWs me;
+  IntraEdge<PIX> edge;
+  PIX pred_y[kMaxSb * kMaxSb], pred_u[kMaxSb * kMaxSb / 4], pred_v[kMaxSb * kMaxSb / 4];
+  PIX p0_y[kMaxSb * kMaxSb], p0_u[kMaxSb * kMaxSb / 4], p0_v[kMaxSb * kMaxSb / 4];
+  PIX p1_y[kMaxSb * kMaxSb], p1_u[kMaxSb * kMaxSb / 4], p1_v[kMaxSb * kMaxSb / 4];
+  PIX rec_y[kMaxSb * kMaxSb], rec_u[kMaxSb * kMaxSb / 4], rec_v[kMaxSb * kMaxSb / 4];
+  PIX org8[kMaxSb * kMaxSb];
+  int16_t coef_y[4 * 256], coef_u[4 * 256], coef_v[4 * 256];
+  unsigned long long acc[12];
+  Node stack[5];
+};
+
+// ---------------------------------------------------------------------------------
+// availability (common_block.h:52-95)
+// ---------------------------------------------------------------------------------
+TK_DEV int upright_avail(int ypos, int xpos, int bw, int bh, int fw, int sb) {
+  int a = (ypos > 0) && (xpos + bw < fw);
+  int size = bw > bh ? bw : bh;
+  for (int s2 = size; s2 < sb; s2 *= 2)
+    if ((ypos % (s2 << 1)) == s2 && (xpos % s2) == (s2 - size)) a = 0;
+  return a;
+}
+TK_DEV int downleft_avail(int ypos, int xpos, int bw, int bh, int fh, int sb) {
+  int a = (xpos > 0) && (ypos + bh < fh);
+  int size = bw > bh ? bw : bh;
+  if ((ypos % sb) == (sb - size) && (xpos % sb) == 0) a = 0;
+  for (int s2 = 2 * size; s2 <= sb; s2 *= 2)
+    if ((ypos % s2) == (s2 - size) && (xpos % s2) > 0) a = 0;
+  return a;
+}
+
+TK_DEV InterPred zero_pred() {
+  InterPred z;
+  z.mv0 = mk_mv(0, 0);
+  z.mv1 = mk_mv(0, 0);
+  z.ref0 = z.ref1 = 0;
+  z.dir = 0;
+  z.pad = 0;
+  return z;
+}
+TK_DEV InterPred cell_pred(const DbCell& c) {
+  InterPred p;
+  p.mv0 = c.mv0;
+  p.mv1 = c.mv1;
+  p.ref0 = c.ref0;
+  p.ref1 = c.ref1;
+  p.dir = c.dir;
+  p.pad = 0;
+  return p;
+}
+
+// get_mv_pred (inter_prediction.c:413-526): median of three neighbours' mv0.
+TK_DEV mv_t get_mv_pred(const DbCell* cells, int cs, int ypos, int xpos, int fw, int fh, int size, int sb) {
+  const int bsz = size / kMinPb;
+  const int bi = (ypos / kMinPb) * cs + xpos / kMinPb;
+  const int up0 = bi - cs, up1 = bi - cs + (bsz - 1) / 2, up2 = bi - cs + bsz - 1;
+  const int l0 = bi - 1, l1 = bi + cs * ((bsz - 1) / 2) - 1, l2 = bi + cs * (bsz - 1) - 1;
+  const int dl = bi + cs * bsz - 1, ur = bi - cs + bsz, ul = bi - cs - 1;
+  const int U = ypos > 0, L = xpos > 0;
+  const int UR = upright_avail(ypos, xpos, size, size, fw, sb);
+  const int DL = downleft_avail(ypos, xpos, size, size, fh, sb);
+  mv_t a = mk_mv(0, 0), b = a, c = a;
+  if (U == 0 && UR == 0 && L == 0 && DL == 0) {
+  } else if (U == 1 && UR == 0 && L == 0 && DL == 0) { a = cells[up0].mv0; b = cells[up1].mv0; c = cells[up2].mv0; }
+  else if (U == 1 && UR == 1 && L == 0 && DL == 0) { a = cells[up0].mv0; b = cells[up2].mv0; c = cells[ur].mv0; }
+  else if (U == 0 && UR == 0 && L == 1 && DL == 0) { a = cells[l0].mv0; b = cells[l1].mv0; c = cells[l2].mv0; }
+  else if (U == 1 && UR == 0 && L == 1 && DL == 0) { a = cells[ul].mv0; b = cells[up2].mv0; c = cells[l2].mv0; }
+  else if (U == 1 && UR == 1 && L == 1 && DL == 0) { a = cells[up0].mv0; b = cells[ur].mv0; c = cells[l2].mv0; }
+  else if (U == 0 && UR == 0 && L == 1 && DL == 1) { a = cells[l0].mv0; b = cells[l2].mv0; c = cells[dl].mv0; }
+  else if (U == 1 && UR == 0 && L == 1 && DL == 1) { a = cells[up2].mv0; b = cells[l0].mv0; c = cells[dl].mv0; }
+  else if (U == 1 && UR == 1 && L == 1 && DL == 1) { a = cells[up0].mv0; b = cells[ur].mv0; c = cells[l0].mv0; }
+  mv_t p;
+  p.x = a.x < b.x ? tmin(b.x, tmax(a.x, c.x)) : tmin(a.x, tmax(b.x, c.x));
+  p.y = a.y < b.y ? tmin(b.y, tmax(a.y, c.y)) : tmin(a.y, tmax(b.y, c.y));
+  return p;
+}
+
+// get_mv_skip / get_mv_merge (LIMITED_SKIP variant; inter_prediction.c:528-834): identical rules.
+TK_DEV int get_mv_cands(const DbCell* cells, int cs, int ypos, int xpos, int fw, int fh, int size, int sb,
+                        InterPred* out) {
+  const int bsz = size / kMinPb;
+  const int bi = (ypos / kMinPb) * cs + xpos / kMinPb;
+  int up0 = bi - cs, up2 = bi - cs + bsz - 1;
+  int l0 = bi - 1, l2 = bi + cs * (bsz - 1) - 1;
+  const int ur = bi - cs + bsz;
+  const int U = ypos > 0, L = xpos > 0;
+  const int UR = upright_avail(ypos, xpos, size, size, fw, sb);
+  if (ypos + size > fh) l2 = l0;
+  if (xpos + size > fw) up2 = up0;
+  InterPred tmp[2];
+  tmp[0] = L ? cell_pred(cells[l2]) : zero_pred();
+  tmp[1] = UR ? cell_pred(cells[ur]) : (U ? cell_pred(cells[up2]) : zero_pred());
+  out[0] = tmp[0];
+  int n = 1;
+  // duplicate test (inter_prediction.c:816-826); dir == -1 plays the reference's (uint32)-1
+  const InterPred& q = tmp[1];
+  const InterPred& o = out[0];
+  int dup = q.mv0.x == o.mv0.x && q.mv0.y == o.mv0.y && q.ref0 == o.ref0 && q.mv1.x == o.mv1.x &&
+            q.mv1.y == o.mv1.y && q.ref1 == o.ref1 && (q.dir == o.dir || q.dir == -1);
+  if (!dup) out[n++] = tmp[1];
+  return n;
+}
+
+// find_block_contexts (common_block.c:283-309)
+TK_DEV void find_contexts(const DbCell* cells, int cs, int ypos, int xpos, int fh, int fw, int size, int enable,
+                          SynCtx* s) {
+  if (ypos >= kMinBlk && xpos >= kMinBlk && ypos + size < fh && xpos + size < fw && enable && size <= 128) {
+    const int bi = (ypos / kMinPb) * cs + xpos / kMinPb;
+    const DbCell& up = cells[bi - cs];
+    const DbCell& le = cells[bi - 1];
+    int split = (up.size < size) + (le.size < size);
+    s->ctx_cbp = ((up.cbp & 1) != 0) + ((le.cbp & 1) != 0);
+    int cbp2 = (up.cbp != 0) + (le.cbp != 0);
+    s->ctx_index = 3 * split + cbp2;
+  } else {
+    s->ctx_cbp = -1;
+    s->ctx_index = -1;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// SSD / cost
+// ---------------------------------------------------------------------------------
+template <typename PIX>
+TK_DEV void ssd_acc(const Team& t, unsigned long long* acc, const PIX* a, int as, const PIX* b, int bs, int w, int h) {
+  unsigned long long local = 0;
+  for (int k = t.rank; k < w * h; k += t.size) {
+    int i = k / w, j = k - i * w;
+    int d = (int)a[i * as + j] - (int)b[i * bs + j];
+    local += (unsigned long long)(d * d);
+  }
+  team_add64(acc, local);
+}
+
+// cost_calc (encode_block.c:916-926) on the trial recon in ws->rec_* vs. the original frame.
+template <typename PIX>
+TK_DEV unsigned rd_cost(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int nbits, double lambda) {
+  if (t.rank == 0) ws->acc[0] = 0;
+  t.sync();
+  const int yc = nd.ypos >> 1, xc = nd.xpos >> 1, sc = nd.size >> 1;
+  ssd_acc(t, &ws->acc[0], J.orig.y + nd.ypos * J.orig.sy + nd.xpos, J.orig.sy, ws->rec_y, nd.size, nd.bw, nd.bh);
+  ssd_acc(t, &ws->acc[0], J.orig.u + yc * J.orig.sc + xc, J.orig.sc, ws->rec_u, sc, nd.bw >> 1, nd.bh >> 1);
+  ssd_acc(t, &ws->acc[0], J.orig.v + yc * J.orig.sc + xc, J.orig.sc, ws->rec_v, sc, nd.bw >> 1, nd.bh >> 1);
+  t.sync();
+  unsigned long long ssd = ws->acc[0];
+  t.sync();
+  unsigned long long cost = (ssd >> (J.cfg.bitdepth * 2 - 16)) + (unsigned long long)(long long)mul_add_nofma(lambda, (double)nbits, 0.5);
+  if (cost > (1ull << 30)) cost = 1ull << 30;
+  return (unsigned)cost;
+}
+
+// ---------------------------------------------------------------------------------
+// Chroma-from-luma (common_block.c:347-428).  y: luma prediction (stride n), u/v: chroma
+// prediction (stride cstride>>1), ry: reconstructed luma (stride `stride`), n = luma size.
+// ---------------------------------------------------------------------------------
+template <typename PIX>
+TK_DEV void improve_uv(const Team& t, TeamWs<PIX>* ws, const PIX* y, PIX* u, PIX* v, const PIX* ry, int n, int cstride,
+                       int stride, int bitdepth) {
+  const int nc = n >> 1, lognc = ilog2(nc), cs = cstride >> 1;
+  for (int k = t.rank; k < 9; k += t.size) ws->acc[k] = 0;
+  t.sync();
+  {
+    unsigned long long local = 0;
+    for (int k = t.rank; k < n * n; k += t.size) {
+      int i = k / n, j = k - i * n;
+      int d = (int)ry[i * stride + j] - (int)y[i * n + j];
+      local += (unsigned long long)(d * d);
+    }
+    team_add64(&ws->acc[0], local);
+  }
+  t.sync();
+  long long sq = (long long)ws->acc[0];
+  if ((sq >> (2 * ilog2(n))) <= (64ll << (2 * (bitdepth - 8)))) { t.sync(); return; }
+  {
+    unsigned long long ls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = t.rank; k < nc * nc; k += t.size) {
+      int i = k / nc, j = k - i * nc;
+      int us = u[i * cs + j], vs = v[i * cs + j];
+      int ys = (y[(i * 2) * n + j * 2] + y[(i * 2) * n + j * 2 + 1] + y[(i * 2 + 1) * n + j * 2] + y[(i * 2 + 1) * n + j * 2 + 1] + 2) >> 2;
+      ls[0] += ys; ls[1] += us; ls[2] += vs;
+      ls[3] += (unsigned)(ys * ys); ls[4] += (unsigned)(ys * us); ls[5] += (unsigned)(ys * vs);
+      ls[6] += (unsigned)(us * us); ls[7] += (unsigned)(vs * vs);
+    }
+    for (int q = 0; q < 8; q++) team_add64(&ws->acc[1 + q], ls[q]);
+  }
+  t.sync();
+  const long long ysum = ws->acc[1], usum = ws->acc[2], vsum = ws->acc[3], yysum = ws->acc[4], yusum = ws->acc[5],
+                  yvsum = ws->acc[6], uusum = ws->acc[7], vvsum = ws->acc[8];
+  t.sync();
+  const long long ssyy = yysum - ((ysum * ysum) >> (lognc * 2));
+  const long long ssuu = uusum - ((usum * usum) >> (lognc * 2));
+  const long long ssvv = vvsum - ((vsum * vsum) >> (lognc * 2));
+  const long long ssyu = yusum - ((ysum * usum) >> (lognc * 2));
+  const long long ssyv = yvsum - ((ysum * vsum) >> (lognc * 2));
+  if (!ssyy) return;
+  for (int pl = 0; pl < 2; pl++) {
+    const long long ssyc = pl ? ssyv : ssyu, sscc = pl ? ssvv : ssuu, csum = pl ? vsum : usum;
+    PIX* c = pl ? v : u;
+    if (ssyc * ssyc * 2 > ssyy * sscc) {
+      long long a64 = (ssyc << 16) / ssyy;
+      long long b64 = ((csum << 16) - a64 * ysum) >> (lognc * 2);
+      const long long alim = 1ll << (31 - bitdepth);
+      int a = (int)(a64 < -alim ? -alim : (a64 > alim ? alim : a64));
+      long long bb = b64 + (1 << 15);
+      int b = (int)(bb < -(1ll << 31) ? -(1ll << 31) : (bb > ((1ll << 31) - 1) ? ((1ll << 31) - 1) : bb));
+      for (int k = t.rank; k < nc * nc; k += t.size) {
+        int i = k / nc, j = k - i * nc;
+        int s = 2;
+        for (int q = 0; q < 4; q++) {
+          int r = ry[(i * 2 + (q >> 1)) * stride + j * 2 + (q & 1)];
+          int m = (int)((unsigned)a * (unsigned)r + (unsigned)b);  // wraps like the reference's int arithmetic
+          s += sat_pix(m >> 16, bitdepth);
+        }
+        c[i * cs + j] = (PIX)(s >> 2);
+      }
+    }
+  }
+  t.sync();
+}
+
+// ---------------------------------------------------------------------------------
+// encode_block (encode_block.c:1340-1514): prediction + residual coding of one CB into the trial
+// buffers ws->rec_* / ws->coef_*; returns the number of bits of write_block.  `bs` counts or emits.
+// ---------------------------------------------------------------------------------
+template <typename PIX>
+TK_DEV void predict_inter(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, const BlkParam& p,
+                          int split) {
+  const EncCfg& c = J.cfg;
+  const int bi = (p.mode == M_BIPRED) || ((p.mode == M_SKIP || p.mode == M_MERGE) && p.dir == 2);
+  if (bi) {
+    pred_inter_yuv(t, J.ref[p.ref0], ws->p0_y, ws->p0_u, ws->p0_v, nd.ypos, nd.xpos, nd.size, nd.bw, nd.bh, p.mv0,
+                   J.sign[p.ref0], c.width, c.height, c.enable_bipred, split, c.bitdepth);
+    pred_inter_yuv(t, J.ref[p.ref1], ws->p1_y, ws->p1_u, ws->p1_v, nd.ypos, nd.xpos, nd.size, nd.bw, nd.bh, p.mv1,
+                   J.sign[p.ref1], c.width, c.height, c.enable_bipred, split, c.bitdepth);
+    t.sync();
+    average_yuv(t, ws->pred_y, ws->pred_u, ws->pred_v, ws->p0_y, ws->p0_u, ws->p0_v, ws->p1_y, ws->p1_u, ws->p1_v,
+                nd.size, nd.bw, nd.bh);
+  } else {
+    pred_inter_yuv(t, J.ref[p.ref0], ws->pred_y, ws->pred_u, ws->pred_v, nd.ypos, nd.xpos, nd.size, nd.bw, nd.bh,
+                   p.mv0, J.sign[p.ref0], c.width, c.height, c.enable_bipred, split, c.bitdepth);
+  }
+  t.sync();
+}
+
+// residual coding of one plane of an inter block (encode_and_reconstruct_block_inter :1275-1338)
+template <typename PIX>
+TK_DEV int code_inter_plane(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const PIX* org, int ostride,
+                            const PIX* pred, PIX* rec, int size, int qp, int coeff_type, int tb_split, int16_t* coef) {
+  const int bd = J.cfg.bitdepth;
+  if (!tb_split) {
+    int fast = (size == 64 && J.cfg.encoder_speed > 0) || J.cfg.encoder_speed > 1;
+    return code_tu(t, &ws->xf, org, ostride, pred, size, rec, size, size, qp, coeff_type, fast, coef, bd);
+  }
+  const int s2 = size / 2;
+  int cbp = 0, index = 0;
+  for (int i = 0; i < size; i += s2)
+    for (int j = 0; j < size; j += s2) {
+      int fast = size == 64 || J.cfg.encoder_speed > 1;
+      int bit = code_tu(t, &ws->xf, org + i * ostride + j, ostride, pred + i * size + j, size, rec + i * size + j, size,
+                        s2, qp, coeff_type, fast, coef + index, bd);
+      cbp = (cbp << 1) + bit;
+      index += 256;
+    }
+  return cbp;
+}
+
+template <typename PIX>
+TK_DEV int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BlkParam& p, BitSink& bs) {
+  const EncCfg& c = J.cfg;
+  const int size = nd.size, sizeC = size >> 1;
+  const int yc = nd.ypos >> 1, xc = nd.xpos >> 1;
+  const int qpY = J.qp, qpC = TK_TAB.chroma_qp[qpY];
+  const int tb_split = p.tb_param > 0 ? p.tb_param : 0;
+  const int zero_block = p.tb_param == -1;
+  const int ftI = (J.frame_type == F_I) << 1;
+  const int bd = c.bitdepth;
+  p.tb_split = (int8_t)tb_split;
+  const PIX* oy = J.orig.y + nd.ypos * J.orig.sy + nd.xpos;
+  const PIX* ou = J.orig.u + yc * J.orig.sc + xc;
+  const PIX* ov = J.orig.v + yc * J.orig.sc + xc;
+  int cbp_y = 0, cbp_u = 0, cbp_v = 0;
+
+  if (p.mode == M_INTRA) {
+    const int ur = upright_avail(nd.ypos, nd.xpos, size, size, c.width, kMaxSb);
+    const int dl = downleft_avail(nd.ypos, nd.xpos, size, size, c.height, kMaxSb);
+    const PIX* fy = J.rec.y + nd.ypos * J.rec.sy + nd.xpos;
+    const PIX* fu = J.rec.u + yc * J.rec.sc + xc;
+    const PIX* fv = J.rec.v + yc * J.rec.sc + xc;
+    // luma (encode_and_reconstruct_block_intra :1100-1168)
+    if (tb_split) {
+      const int s2 = size / 2;
+      int index = 0;
+      for (int i = 0; i < size; i += s2)
+        for (int j = 0; j < size; j += s2) {
+          make_edges(t, &ws->edge, fy, J.rec.sy, ws->rec_y + i * size + j, size, i, j, nd.ypos, nd.xpos, s2, ur, dl, 1, bd);
+          pred_intra(t, &ws->edge, nd.ypos + i, nd.xpos + j, s2, ws->pred_y + i * size + j, size, p.intra_mode, bd);
+          t.sync();
+          int bit = code_tu(t, &ws->xf, oy + i * J.orig.sy + j, J.orig.sy, ws->pred_y + i * size + j, size,
+                            ws->rec_y + i * size + j, size, s2, qpY, ftI | 0, c.encoder_speed > 1, ws->coef_y + index, bd);
+          cbp_y = (cbp_y << 1) + bit;
+          index += 256;
+        }
+    } else {
+      make_edges(t, &ws->edge, fy, J.rec.sy, (const PIX*)nullptr, 0, 0, 0, nd.ypos, nd.xpos, size, ur, dl, 0, bd);
+      pred_intra(t, &ws->edge, nd.ypos, nd.xpos, size, ws->pred_y, size, p.intra_mode, bd);
+      t.sync();
+      cbp_y = code_tu(t, &ws->xf, oy, J.orig.sy, ws->pred_y, size, ws->rec_y, size, size, qpY, ftI | 0,
+                      c.encoder_speed > 1, ws->coef_y, bd);
+    }
+    // chroma (encode_and_reconstruct_block_intra_uv :1170-1273)
+    const int csplit = tb_split && sizeC > 4;
+    if (csplit) {
+      const int s2 = sizeC / 2;
+      int index = 0;
+      for (int i = 0; i < sizeC; i += s2)
+        for (int j = 0; j < sizeC; j += s2) {
+          make_edges(t, &ws->edge, fu, J.rec.sc, ws->rec_u + i * sizeC + j, sizeC, i, j, yc, xc, s2, ur, dl, 1, bd);
+          pred_intra(t, &ws->edge, yc + i, xc + j, s2, ws->pred_u + i * sizeC + j, sizeC, p.intra_mode, bd);
+          t.sync();
+          make_edges(t, &ws->edge, fv, J.rec.sc, ws->rec_v + i * sizeC + j, sizeC, i, j, yc, xc, s2, ur, dl, 1, bd);
+          pred_intra(t, &ws->edge, yc + i, xc + j, s2, ws->pred_v + i * sizeC + j, sizeC, p.intra_mode, bd);
+          t.sync();
+          if (c.cfl_intra)  // sic: luma pointers offset in CHROMA units (encode_block.c:1199)
+            improve_uv(t, ws, ws->pred_y + i * sizeC + j, ws->pred_u + i * sizeC + j, ws->pred_v + i * sizeC + j,
+                       ws->rec_y + (i << 1) * size + (j << 1), s2 << 1, sizeC << 1, size, bd);
+          int bu = code_tu(t, &ws->xf, ou + i * J.orig.sc + j, J.orig.sc, ws->pred_u + i * sizeC + j, sizeC,
+                           ws->rec_u + i * sizeC + j, sizeC, s2, qpC, ftI | 1, c.encoder_speed > 1, ws->coef_u + index, bd);
+          cbp_u = (cbp_u << 1) + bu;
+          int bv = code_tu(t, &ws->xf, ov + i * J.orig.sc + j, J.orig.sc, ws->pred_v + i * sizeC + j, sizeC,
+                           ws->rec_v + i * sizeC + j, sizeC, s2, qpC, ftI | 1, c.encoder_speed > 1, ws->coef_v + index, bd);
+          cbp_v = (cbp_v << 1) + bv;
+          index += 256;
+        }
+    } else {
+      make_edges(t, &ws->edge, fu, J.rec.sc, (const PIX*)nullptr, 0, 0, 0, yc, xc, sizeC, ur, dl, 0, bd);
+      pred_intra(t, &ws->edge, yc, xc, sizeC, ws->pred_u, sizeC, p.intra_mode, bd);
+      t.sync();
+      make_edges(t, &ws->edge, fv, J.rec.sc, (const PIX*)nullptr, 0, 0, 0, yc, xc, sizeC, ur, dl, 0, bd);
+      pred_intra(t, &ws->edge, yc, xc, sizeC, ws->pred_v, sizeC, p.intra_mode, bd);
+      t.sync();
+      if (c.cfl_intra) improve_uv(t, ws, ws->pred_y, ws->pred_u, ws->pred_v, ws->rec_y, size, size, size, bd);
+      cbp_u = code_tu(t, &ws->xf, ou, J.orig.sc, ws->pred_u, sizeC, ws->rec_u, sizeC, sizeC, qpC, ftI | 1,
+                      c.encoder_speed > 1, ws->coef_u, bd);
+      cbp_v = code_tu(t, &ws->xf, ov, J.orig.sc, ws->pred_v, sizeC, ws->rec_v, sizeC, sizeC, qpC, ftI | 1,
+                      c.encoder_speed > 1, ws->coef_v, bd);
+    }
+  } else {
+    const int split = (p.mode == M_INTER || p.mode == M_BIPRED) ? c.enable_pb_split : 0;
+    predict_inter(t, J, ws, nd, p, split);
+    if (p.mode == M_SKIP || zero_block) {
+      copy_block(t, ws->rec_y, size, ws->pred_y, size, nd.bw, nd.bh);
+      copy_block(t, ws->rec_u, sizeC, ws->pred_u, sizeC, nd.bw >> 1, nd.bh >> 1);
+      copy_block(t, ws->rec_v, sizeC, ws->pred_v, sizeC, nd.bw >> 1, nd.bh >> 1);
+      t.sync();
+    } else {
+      cbp_y = code_inter_plane(t, J, ws, oy, J.orig.sy, ws->pred_y, ws->rec_y, size, qpY, ftI | 0, tb_split, ws->coef_y);
+      if (c.cfl_inter) improve_uv(t, ws, ws->pred_y, ws->pred_u, ws->pred_v, ws->rec_y, size, size, size, bd);
+      const int csplit = tb_split && sizeC > 4;
+      cbp_u = code_inter_plane(t, J, ws, ou, J.orig.sc, ws->pred_u, ws->rec_u, sizeC, qpC, ftI | 1, csplit, ws->coef_u);
+      cbp_v = code_inter_plane(t, J, ws, ov, J.orig.sc, ws->pred_v, ws->rec_v, sizeC, qpC, ftI | 1, csplit, ws->coef_v);
+    }
+  }
+  p.cbp_y = (uint8_t)cbp_y;
+  p.cbp_u = (uint8_t)cbp_u;
+  p.cbp_v = (uint8_t)cbp_v;
+  return bs_block(bs, nd.syn, p, ws->coef_y, ws->coef_u, ws->coef_v);
+}
+
+// One RDO trial: count bits, evaluate cost, keep `best` (copy_best_parameters, :1615-1677).
+template <typename PIX>
+TK_DEV unsigned rdo_trial(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BlkParam& p, double lambda) {
+  BitSink cnt;
+  cnt.buf = nullptr; cnt.pos = 0; cnt.cap = 0; cnt.emit = 0; cnt.ovf = 0;
+  int nbits = encode_block(t, J, ws, nd, p, cnt);
+  return rd_cost(t, J, ws, nd, nbits, lambda);
+}
+
+TK_DEV void keep_best(Node& nd, const BlkParam& p) {
+  BlkParam b = p;
+  if (p.mode == M_SKIP || p.mode == M_MERGE) {
+    const InterPred& c = (p.mode == M_SKIP) ? nd.skip[p.skip_idx] : nd.merge[p.skip_idx];
+    b.ref0 = c.ref0; b.ref1 = c.ref1; b.dir = c.dir;
+    for (int i = 0; i < 4; i++) { b.mv0[i] = c.mv0; b.mv1[i] = c.mv1; }
+  } else if (p.mode == M_INTRA) {
+    b.ref0 = b.ref1 = 0; b.dir = -1;
+    for (int i = 0; i < 4; i++) { b.mv0[i] = mk_mv(0, 0); b.mv1[i] = mk_mv(0, 0); }
+  } else if (p.mode == M_INTER) b.dir = 0;
+  else b.dir = 2;
+  nd.best = b;
+}
+
+TK_DEV void set_cand(BlkParam& p, const InterPred& c, int idx, int mode) {
+  p.mode = (int8_t)mode;
+  p.skip_idx = (int8_t)idx;
+  p.ref0 = c.ref0; p.ref1 = c.ref1; p.dir = c.dir;
+  for (int i = 0; i < 4; i++) { p.mv0[i] = c.mv0; p.mv1[i] = c.mv1; }
+}
+
+// search_inter_prediction_params (encode_block.c:1033-1098)
+template <typename PIX>
+TK_DEV unsigned search_inter(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, int ypos, int xpos, int size,
+                             const PIX* org, int ostride, int ref_idx, mv_t mvc, mv_t mvp, mv_t* mv_arr, int part,
+                             int sign) {
+  const Plane3<PIX>& ref = J.ref[ref_idx];
+  const PIX* ref_y = ref.y + ypos * ref.sy + xpos;
+  MeArgs a;
+  a.cb_size = size; a.rstride = ref.sy; a.sign = sign; a.fwidth = J.cfg.width; a.fheight = J.cfg.height;
+  a.xpos = xpos; a.ypos = ypos; a.enable_bipred = J.cfg.enable_bipred; a.bitdepth = J.cfg.bitdepth;
+  a.lam = J.sqrt_lambda; a.ostride = ostride;
+  unsigned sad = 0;
+  mv_t mv, mvp2 = mvp;
+  if (part == P_NONE) {
+    a.width = size; a.height = size;
+    sad += motion_estimate(t, &ws->me, org, ref_y, a, mvc, mvp2, ref_idx, &mv);
+    mv_arr[0] = mv_arr[1] = mv_arr[2] = mv_arr[3] = mv;
+  } else if (part == P_HOR) {
+    a.width = size; a.height = size / 2;
+    for (int index = 0; index < 4; index += 2) {
+      int py = index >> 1;
+      sad += motion_estimate(t, &ws->me, org + py * (size / 2) * ostride, ref_y + py * (size / 2) * ref.sy, a, mvc, mvp2, ref_idx, &mv);
+      mv_arr[index] = mv; mv_arr[index + 1] = mv;
+      mvp2 = mv_arr[0];
+    }
+  } else if (part == P_VER) {
+    a.width = size / 2; a.height = size;
+    for (int index = 0; index < 2; index++) {
+      sad += motion_estimate(t, &ws->me, org + index * (size / 2), ref_y + index * (size / 2), a, mvc, mvp2, ref_idx, &mv);
+      mv_arr[index] = mv; mv_arr[index + 2] = mv;
+      mvp2 = mv_arr[0];
+    }
+  } else {
+    a.width = size / 2; a.height = size / 2;
+    for (int index = 0; index < 4; index++) {
+      int px = index & 1, py = index >> 1;
+      sad += motion_estimate(t, &ws->me, org + py * (size / 2) * ostride + px * (size / 2),
+                             ref_y + py * (size / 2) * ref.sy + px * (size / 2), a, mvc, mvp2, ref_idx, &mv);
+      mv_arr[index] = mv;
+      mvp2 = mv_arr[0];
+    }
+  }
+  return sad;
+}
+
+template <typename PIX> TK_DEV void add_cands4(const Team& t, TeamWs<PIX>* ws, int ref_idx, const mv_t* mv4) {
+  if (t.rank == 0)
+    for (int i = 0; i < 4; i++) add_mvcand(&ws->me, ref_idx, mv4[i]);
+  t.sync();
+}
+
+// search_bipred_prediction_params, me_mode 0 (encode_block.c:1739-1832) - P and B frames.
+template <typename PIX>
+TK_DEV void search_bipred(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int part,
+                          const mv_t* mv_center, mv_t mvp, int* ref_idx0, int* ref_idx1, mv_t* mv_arr0, mv_t* mv_arr1) {
+  const EncCfg& c = J.cfg;
+  const int size = nd.size;
+  const int num_iter = c.encoder_speed == 0 ? 2 : 1;
+  int min_ref0 = (J.frame_type == F_B && J.interp_ref > 0) ? 1 : 0, min_ref1 = 0;
+  mv_t min0[4], min1[4];
+  for (int i = 0; i < 4; i++) { min0[i] = mvp; min1[i] = mvp; }
+  unsigned min_sad = 1u << 30;
+  const PIX* oy = J.orig.y + nd.ypos * J.orig.sy + nd.xpos;
+  for (int n = 0; n < num_iter; n++) {
+    const int stop = part == 0 ? 0 : 1;
+    for (int list = 1; list >= stop; list--) {
+      mv_t mvo = list ? min0[0] : min1[0];
+      int ref_o = list ? min_ref0 : min_ref1;
+      pred_inter_yuv(t, J.ref[ref_o], ws->pred_y, ws->pred_u, ws->pred_v, nd.ypos, nd.xpos, size, nd.bw, nd.bh,
+                     list ? min0 : min1, J.sign[ref_o], c.width, c.height, c.enable_bipred, part > 0, c.bitdepth);
+      t.sync();
+      for (int k = t.rank; k < size * size; k += t.size) {
+        int i = k / size, j = k - i * size;
+        ws->org8[k] = (PIX)sat_pix(2 * (int)oy[i * J.orig.sy + j] - (int)ws->pred_y[k], c.bitdepth);
+      }
+      t.sync();
+      int ref_start, ref_end;
+      if (J.frame_type == F_P) { ref_start = 0; ref_end = J.num_ref - 1; }
+      else {
+        ref_start = ref_end = list ? 1 : 0;
+        if (J.interp_ref) { ref_start++; ref_end++; }
+      }
+      for (int r = ref_start; r <= ref_end; r++) {
+        mv_t mvp2 = (J.frame_type == F_B && list == 1) ? mvo : mvp;
+        mv_t mv_all[4];
+        unsigned sad = search_inter(t, J, ws, nd.ypos, nd.xpos, size, ws->org8, size, r, mv_center[r], mvp2, mv_all, part, J.sign[r]);
+        add_cands4(t, ws, r, mv_all);
+        if (sad < min_sad) {
+          min_sad = sad;
+          if (list) { min_ref1 = r; for (int i = 0; i < 4; i++) min1[i] = mv_all[i]; }
+          else { min_ref0 = r; for (int i = 0; i < 4; i++) min0[i] = mv_all[i]; }
+        }
+      }
+    }
+  }
+  *ref_idx0 = min_ref0;
+  *ref_idx1 = min_ref1;
+  for (int i = 0; i < 4; i++) { mv_arr0[i] = min0[i]; mv_arr1[i] = min1[i]; }
+}
+
+// ---------------------------------------------------------------------------------
+// mode_decision_rdo (encode_block.c:1835-2121).  Result in nd.best; returns min cost.
+// ---------------------------------------------------------------------------------
+template <typename PIX>
+TK_DEV unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd) {
+  const EncCfg& c = J.cfg;
+  const int size = nd.size;
+  const double lambda = J.lambda;
+  const int rect = nd.bw != size || nd.bh != size;
+  const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
+  const int max_pb = c.enable_pb_split ? 4 : 1;
+  unsigned min_cost = kCostInit;
+  BlkParam p;
+  // deterministic stand-in for the reference's uninitialised tmp_block_param
+  p.mode = M_SKIP; p.intra_mode = 0; p.skip_idx = 0; p.pb_part = P_NONE; p.ref0 = p.ref1 = 0; p.dir = 0;
+  p.tb_param = 0; p.tb_split = 0; p.cbp_y = p.cbp_u = p.cbp_v = 0;
+  for (int i = 0; i < 4; i++) { p.mv0[i] = mk_mv(0, 0); p.mv1[i] = mk_mv(0, 0); }
+
+  if (J.frame_type != F_I) {
+    p.tb_param = 0;
+    p.pb_part = P_NONE;
+    for (int k = 0; k < nd.syn.num_skip; k++) {
+      set_cand(p, nd.skip[k], k, M_SKIP);
+      unsigned cost = rdo_trial(t, J, ws, nd, p, lambda);
+      if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
+    }
+  }
+  if ((size < 128 || c.encoder_speed == 0) && !rect) {
+    if (J.frame_type != F_I) {
+      for (int k = 0; k < nd.syn.num_merge; k++) {
+        set_cand(p, nd.merge[k], k, M_MERGE);
+        for (int tb = 0; tb <= max_tb - 1; tb++) {
+          p.tb_param = (int8_t)tb;
+          unsigned cost = rdo_trial(t, J, ws, nd, p, lambda);
+          if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
+        }
+      }
+      // uni-prediction per reference
+      mv_t mv_center[kMaxRefs];
+      mv_t mv_all[4][4];
+      mv_t mvp = mk_mv(0, 0);
+      const PIX* oy = J.orig.y + nd.ypos * J.orig.sy + nd.xpos;
+      const int min_idx = (J.frame_type == F_B && J.interp_ref > 2) ? 1 : 0;
+      for (int r = min_idx; r < J.num_ref; r++) {
+        mvp = get_mv_pred(J.cells, J.cell_stride, nd.ypos, nd.xpos, c.width, c.height, size, kMaxSb);
+        if (t.rank == 0) add_mvcand(&ws->me, r, mvp);
+        t.sync();
+        nd.syn.mvp = mvp;
+        mv_center[r] = mvp;
+        for (int part = 0; part < max_pb; part++) {
+          search_inter(t, J, ws, nd.ypos, nd.xpos, size, oy, J.orig.sy, r, mv_center[r], mvp, mv_all[part], part, J.sign[r]);
+          add_cands4(t, ws, r, mv_all[part]);
+          mv_center[r] = mv_all[0][0];
+        }
+        p.mode = M_INTER;
+        p.ref0 = p.ref1 = (int8_t)r;
+        for (int part = 0; part < max_pb; part++) {
+          p.pb_part = (int8_t)part;
+          for (int i = 0; i < 4; i++) { p.mv0[i] = mv_all[part][i]; p.mv1[i] = mv_all[part][i]; }
+          const int min_tb = c.encoder_speed < 1 ? -1 : 0;
+          for (int tb = min_tb; tb <= max_tb - 1; tb++) {
+            p.tb_param = (int8_t)tb;
+            unsigned cost = rdo_trial(t, J, ws, nd, p, lambda);
+            if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
+          }
+        }
+      }
+      // bi-prediction
+      if (J.num_ref > 1 && c.enable_bipred) {
+        int r0, r1;
+        mv_t a0[4], a1[4];
+        search_bipred(t, J, ws, nd, 0, mv_center, mvp, &r0, &r1, a0, a1);
+        p.mode = M_BIPRED;
+        p.pb_part = P_NONE;
+        p.ref0 = (int8_t)r0; p.ref1 = (int8_t)r1;
+        for (int i = 0; i < 4; i++) { p.mv0[i] = a0[i]; p.mv1[i] = a1[i]; }
+        for (int tb = 0; tb <= max_tb - 1; tb++) {
+          p.tb_param = (int8_t)tb;
+          unsigned cost = rdo_trial(t, J, ws, nd, p, lambda);
+          if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
+        }
+        // TODO(B frames): motion_estimate_bi joint search (encode_block.c:2052-2068)
+      }
+    }
+    // intra
+    p.mode = M_INTRA;
+    int intra_mode = 0;
+    if (c.intra_rdo) {
+      unsigned min_intra = kCostInit;
+      for (int m = 0; m < J.num_intra_modes; m++) {
+        p.intra_mode = (int8_t)m;
+        for (int tb = 0; tb <= max_tb - 1; tb++) {
+          p.tb_param = (int8_t)tb;
+          unsigned cost = rdo_trial(t, J, ws, nd, p, lambda);
+          if (cost < min_intra) { min_intra = cost; intra_mode = m; }
+        }
+      }
+    }
+    p.intra_mode = (int8_t)intra_mode;
+    for (int tb = 0; tb <= max_tb - 1; tb++) {
+      p.tb_param = (int8_t)tb;
+      unsigned cost = rdo_trial(t, J, ws, nd, p, lambda);
+      if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
+    }
+  }
+  return min_cost;
+}
+
+// ---------------------------------------------------------------------------------
+// Early skip (encode_block.c:2123-2392)
+// ---------------------------------------------------------------------------------
+template <typename PIX>
+TK_DEV int early_skip_sub(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const PIX* org, int ostride,
+                          const PIX* pred, int pstride, int size, int qp, float thr) {
+  // luma: 2x2 average + (N/2) transform (size > 4 always here), threshold 0.5*thr
+  const int bd = J.cfg.bitdepth;
+  const int s2 = size / 2;
+  for (int k = t.rank; k < s2 * s2; k += t.size) {
+    int i = k / s2, j = k - i * s2;
+    int a = (int16_t)((int)org[(2 * i) * ostride + 2 * j] - (int)pred[(2 * i) * pstride + 2 * j]);
+    int b = (int16_t)((int)org[(2 * i) * ostride + 2 * j + 1] - (int)pred[(2 * i) * pstride + 2 * j + 1]);
+    int cc = (int16_t)((int)org[(2 * i + 1) * ostride + 2 * j] - (int)pred[(2 * i + 1) * pstride + 2 * j]);
+    int d = (int16_t)((int)org[(2 * i + 1) * ostride + 2 * j + 1] - (int)pred[(2 * i + 1) * pstride + 2 * j + 1]);
+    ws->xf.in[k] = (int16_t)((a + b + cc + d + 2) >> 2);
+  }
+  t.sync();
+  fwd_transform_block(t, &ws->xf, s2, bd);
+  const int shift2 = 21 - ilog2(s2) + qp / 6;
+  const double fql = (double)(1 << shift2) / (double)quant_scale(qp % 6);
+  const double rel = 0.5 * thr;  // float -> double promotion as in the reference
+  const int threshold = (int)(rel * fql);
+  if (t.rank == 0) ws->xf.flag = 0;
+  t.sync();
+  int f = 0;
+  for (int k = t.rank; k < s2 * s2; k += t.size)
+    if (iabs((int)ws->xf.coef[k]) > threshold) f = 1;
+  if (f) team_or((unsigned*)&ws->xf.flag, 1u);
+  t.sync();
+  int r = ws->xf.flag;
+  t.sync();
+  return r != 0;
+}
+
+template <typename PIX>
+TK_DEV int early_skip_subC(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const PIX* org, int ostride,
+                           const PIX* pred, int pstride, int size, int qp, float thr) {
+  const int shift2 = 21 - 5 + qp / 6;
+  const double fql = (double)(1 << shift2) / (double)quant_scale(qp % 6);
+  const int threshold = ((int)(thr * fql)) << (J.cfg.bitdepth - 8);
+  if (t.rank == 0) ws->xf.flag = 0;
+  t.sync();
+  // calc_cbp (encode_block.c:2182-2212): column sums (pairs of columns for 4x4)
+  const int ncol = size == 4 ? 2 : size;
+  int f = 0;
+  for (int col = t.rank; col < ncol; col += t.size) {
+    int sum = 0;
+    for (int i = 0; i < size; i++) {
+      if (size == 4)
+        sum += (int16_t)((int)org[i * ostride + 2 * col] - (int)pred[i * pstride + 2 * col]) +
+               (int16_t)((int)org[i * ostride + 2 * col + 1] - (int)pred[i * pstride + 2 * col + 1]);
+      else sum += (int16_t)((int)org[i * ostride + col] - (int)pred[i * pstride + col]);
+    }
+    if (iabs(sum) > threshold) f = 1;
+  }
+  if (f) team_or((unsigned*)&ws->xf.flag, 1u);
+  t.sync();
+  int r = ws->xf.flag;
+  t.sync();
+  return r != 0;
+}
+
+template <typename PIX>
+TK_DEV int check_early_skip(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, const BlkParam& p) {
+  const EncCfg& c = J.cfg;
+  const int size = nd.size, size0 = size < 32 ? size : 32;
+  const int qpY = J.qp, qpC = TK_TAB.chroma_qp[qpY];
+  const float thr = c.early_skip_thr;
+  const int size0c = size0 >> 1;
+  int significant = 0;
+  for (int i = 0; i < size && !significant; i += size0)
+    for (int j = 0; j < size && !significant; j += size0) {
+      struct { int ypos, xpos; } sub = {nd.ypos + i, nd.xpos + j};
+      const int yc = sub.ypos >> 1, xc = sub.xpos >> 1;
+      if (p.dir == 2) {
+        pred_inter_yuv(t, J.ref[p.ref0], ws->p0_y, ws->p0_u, ws->p0_v, sub.ypos, sub.xpos, size0, size0, size0, p.mv0,
+                       J.sign_ge[p.ref0], c.width, c.height, c.enable_bipred, 0, c.bitdepth);
+        pred_inter_yuv(t, J.ref[p.ref1], ws->p1_y, ws->p1_u, ws->p1_v, sub.ypos, sub.xpos, size0, size0, size0, p.mv1,
+                       J.sign_ge[p.ref1], c.width, c.height, c.enable_bipred, 0, c.bitdepth);
+        t.sync();
+        average_yuv(t, ws->pred_y, ws->pred_u, ws->pred_v, ws->p0_y, ws->p0_u, ws->p0_v, ws->p1_y, ws->p1_u, ws->p1_v,
+                    size0, size0, size0);
+      } else {
+        pred_inter_yuv(t, J.ref[p.ref0], ws->pred_y, ws->pred_u, ws->pred_v, sub.ypos, sub.xpos, size0, size0, size0,
+                       p.mv0, J.sign[p.ref0], c.width, c.height, c.enable_bipred, 0, c.bitdepth);
+      }
+      t.sync();
+      significant = early_skip_sub(t, J, ws, J.orig.y + sub.ypos * J.orig.sy + sub.xpos, J.orig.sy, ws->pred_y, size0,
+                                   size0, qpY, thr);
+      if (!significant)
+        significant = early_skip_subC(t, J, ws, J.orig.u + yc * J.orig.sc + xc, J.orig.sc, ws->pred_u, size0c, size0c, qpC, thr);
+      if (!significant)
+        significant = early_skip_subC(t, J, ws, J.orig.v + yc * J.orig.sc + xc, J.orig.sc, ws->pred_v, size0c, size0c, qpC, thr);
+    }
+  return !significant;
+}
+
+// ---------------------------------------------------------------------------------
+// Final encode of a CB: recompute (encode_block final), write recon + cell state, emit bits.
+// ---------------------------------------------------------------------------------
+template <typename PIX>
+TK_DEV int final_encode(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BitSink& out) {
+  BlkParam p = nd.best;
+  BitSink cnt;
+  cnt.buf = nullptr; cnt.pos = 0; cnt.cap = 0; cnt.emit = 0; cnt.ovf = 0;
+  int nbits = encode_block(t, J, ws, nd, p, cnt);
+  // bits (one lane), then recon copy and cells (all lanes)
+  if (t.rank == 0) {
+    BitSink w = out;
+    bs_block(w, nd.syn, p, ws->coef_y, ws->coef_u, ws->coef_v);
+    out.ovf |= w.ovf;
+  }
+  out.pos += nbits;
+  const int size = nd.size, sc = size >> 1;
+  const int yc = nd.ypos >> 1, xc = nd.xpos >> 1;
+  copy_block(t, J.rec.y + nd.ypos * J.rec.sy + nd.xpos, J.rec.sy, ws->rec_y, size, nd.bw, nd.bh);
+  copy_block(t, J.rec.u + yc * J.rec.sc + xc, J.rec.sc, ws->rec_u, sc, nd.bw >> 1, nd.bh >> 1);
+  copy_block(t, J.rec.v + yc * J.rec.sc + xc, J.rec.sc, ws->rec_v, sc, nd.bw >> 1, nd.bh >> 1);
+  // copy_deblock_data (encode_block.c:1568-1613)
+  const int tbs = p.tb_param > 0 ? 1 : 0;
+  const int pb = p.mode == M_INTER ? p.pb_part : P_NONE;
+  const int div = size / (2 * kMinPb);
+  const int cw = nd.bw / kMinPb, ch = nd.bh / kMinPb;
+  const int cbpbits = tbs ? 7 : ((p.cbp_y ? 1 : 0) | (p.cbp_u ? 2 : 0) | (p.cbp_v ? 4 : 0));
+  for (int k = t.rank; k < cw * ch; k += t.size) {
+    int m = k / cw, n = k - m * cw;
+    int m0 = div > 0 ? m / div : 0, n0 = div > 0 ? n / div : 0;
+    int index = 2 * m0 + n0;
+    DbCell& cell = J.cells[(nd.ypos / kMinPb + m) * J.cell_stride + nd.xpos / kMinPb + n];
+    cell.mv0 = p.mv0[index];
+    cell.mv1 = p.mv1[index];
+    cell.mode = (uint8_t)p.mode;
+    cell.size = (uint8_t)size;
+    cell.tbpb = (uint8_t)(tbs | (pb << 1));
+    cell.cbp = (uint8_t)cbpbits;
+    cell.ref0 = p.ref0;
+    cell.ref1 = p.ref1;
+    cell.dir = p.dir;
+    cell.pad = 0;
+  }
+  t.sync();
+  return nbits;
+}
+
+// ---------------------------------------------------------------------------------
+// process_block (encode_block.c:2401-2566) as an explicit-stack traversal of one superblock.
+// ---------------------------------------------------------------------------------
+template <typename PIX>
+TK_DEV void process_sb(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, int sb_y, int sb_x, BitSink& out) {
+  const EncCfg& c = J.cfg;
+  const int fw = c.width, fh = c.height;
+  if (t.rank == 0)
+    for (int r = 0; r < kMaxRefs; r++) { ws->me.mvcand_num[r] = 0; ws->me.mvcand_mask[r] = 0; }
+  t.sync();
+  int sp = 0;
+  unsigned ret = 0;  // value "returned" by the node that was just popped
+  int have_ret = 0;
+  {
+    Node& n = ws->stack[0];
+    if (t.rank == 0) { n.size = kMaxSb; n.ypos = sb_y; n.xpos = sb_x; n.stage = 0; }
+    t.sync();
+  }
+  while (sp >= 0) {
+    Node& nd = ws->stack[sp];
+    if (nd.stage == 0) {
+      // ---- entry
+      const int size = nd.size, ypos = nd.ypos, xpos = nd.xpos;
+      if (ypos + kMinBlk > fh || xpos + kMinBlk > fw) { ret = 0; have_ret = 1; sp--; continue; }
+      t.sync();
+      if (t.rank == 0) {
+        nd.bw = tmin(size, fw - xpos);
+        nd.bh = tmin(size, fh - ypos);
+        nd.encode_this_size = ypos + size <= fh && xpos + size <= fw;
+        nd.encode_rect = !nd.encode_this_size && J.frame_type != F_I;
+        nd.cost_small = 1u << 28;
+        nd.bitpos0 = out.pos;
+        nd.child = 0;
+        SynCtx& s = nd.syn;
+        s.frame_type = J.frame_type; s.num_ref = J.num_ref; s.enable_bipred = c.enable_bipred; s.interp_ref = J.interp_ref;
+        s.max_pb_part = c.enable_pb_split ? 4 : 1; s.max_tb_part = c.enable_tb_split == 1 ? 2 : 1;
+        s.num_intra_modes = J.num_intra_modes; s.size = size; s.encode_this_size = nd.encode_this_size;
+        s.num_skip = 0; s.num_merge = 0; s.mvp = mk_mv(0, 0);
+        find_contexts(J.cells, J.cell_stride, ypos, xpos, fh, fw, size, c.use_block_contexts, &s);
+        if (J.frame_type != F_I && (nd.encode_this_size || nd.encode_rect)) {
+          s.num_skip = get_mv_cands(J.cells, J.cell_stride, ypos, xpos, fw, fh, size, kMaxSb, nd.skip);
+          s.num_merge = get_mv_cands(J.cells, J.cell_stride, ypos, xpos, fw, fh, size, kMaxSb, nd.merge);
+        }
+      }
+      t.sync();
+      // ---- early skip
+      if (nd.encode_this_size && J.frame_type != F_I && c.early_skip_thr > 0.0f) {
+        unsigned min_cost = kCostInit;
+        int any = 0;
+        BlkParam p;
+        p.intra_mode = 0; p.pb_part = P_NONE; p.tb_param = 0; p.tb_split = 0; p.cbp_y = p.cbp_u = p.cbp_v = 0;
+        for (int k = 0; k < nd.syn.num_skip; k++) {
+          set_cand(p, nd.skip[k], k, M_SKIP);
+          if (check_early_skip(t, J, ws, nd, p)) {
+            any = 1;
+            unsigned cost = rdo_trial(t, J, ws, nd, p, J.lambda);
+            if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); t.sync(); }
+          }
+        }
+        if (any) {
+          int nbits = final_encode(t, J, ws, nd, out);
+          // reference recomputes cost_calc on the final recon: identical to min_cost of that candidate
+          ret = rd_cost(t, J, ws, nd, nbits, J.lambda);
+          have_ret = 1;
+          sp--;
+          continue;
+        }
+      }
+      // ---- split signalling + children
+      if (size > kMinBlk) {
+        if (t.rank == 0) {
+          BitSink w = out;
+          bs_super_mode(w, nd.syn, 0, 0, 1);
+          out.ovf |= w.ovf;
+          nd.cost_small = 0;
+        }
+        {
+          BitSink cnt = out;
+          cnt.emit = 0;
+          bs_super_mode(cnt, nd.syn, 0, 0, 1);
+          out.pos = cnt.pos;
+        }
+        t.sync();
+        if (t.rank == 0) nd.stage = 1;
+        t.sync();
+      } else {
+        if (t.rank == 0) nd.stage = 2;
+        t.sync();
+      }
+      have_ret = 0;
+      continue;
+    }
+    if (nd.stage == 1) {
+      // ---- children TL, BL, TR, BR (encode_block.c:2513-2516)
+      if (have_ret) {
+        if (t.rank == 0) nd.cost_small += ret;
+        have_ret = 0;
+        t.sync();
+      }
+      if (nd.child < 4) {
+        const int ch = nd.child, hs = nd.size / 2;
+        Node& cn = ws->stack[sp + 1];
+        t.sync();
+        if (t.rank == 0) {
+          cn.size = hs;
+          cn.ypos = nd.ypos + ((ch & 1) ? hs : 0);   // order: (0,0) (1,0) (0,1) (1,1) in (y,x)
+          cn.xpos = nd.xpos + ((ch & 2) ? hs : 0);
+          cn.stage = 0;
+          nd.child = ch + 1;
+        }
+        t.sync();
+        sp++;
+        continue;
+      }
+      if (t.rank == 0) nd.stage = 2;
+      t.sync();
+    }
+    // ---- stage 2: decide this size
+    {
+      unsigned cost = 1u << 28;
+      if (nd.encode_this_size || nd.encode_rect) {
+        cost = mode_decision(t, J, ws, nd);
+        t.sync();
+        if (cost <= nd.cost_small) {
+          out.pos = nd.bitpos0;
+          final_encode(t, J, ws, nd, out);
+        }
+      }
+      ret = cost < nd.cost_small ? cost : nd.cost_small;
+      have_ret = 1;
+      sp--;
+    }
+  }
+}
+
+}  // namespace tk

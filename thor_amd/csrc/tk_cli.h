@@ -1,0 +1,139 @@
+// tk_cli.h - minimal Thorenc-compatible option/config-file reader for the test drivers.
+// Same surface as enc/strings.c:287-356 for the options this path honours: "-name value" tokens,
+// ';' starts a comment, "-cf file" includes a config file (command line wins over later files,
+// like the reference, because explicit arguments are applied after the config contents).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+#include <fstream>
+#include <sstream>
+#include <cstdlib>
+#include "tk_encoder.h"
+
+namespace tk {
+
+struct CliArgs {
+  SeqParams sp;
+  std::string infile, outfile, recfile;
+  int num_frames = 600, skip = 0, streams = 1;
+};
+
+static inline void cli_tokens_from_file(const std::string& path, std::vector<std::string>& out) {
+  std::ifstream f(path);
+  if (!f) { fprintf(stderr, "cannot open config %s\n", path.c_str()); exit(2); }
+  std::string line;
+  while (std::getline(f, line)) {
+    size_t sc = line.find(';');
+    if (sc != std::string::npos) line.resize(sc);
+    std::istringstream is(line);
+    std::string tok;
+    while (is >> tok) out.push_back(tok);
+  }
+}
+
+static inline void cli_apply(CliArgs& a, const std::vector<std::string>& t) {
+  for (size_t i = 0; i + 1 < t.size(); i += 2) {
+    const std::string& k = t[i];
+    const std::string& v = t[i + 1];
+    SeqParams& p = a.sp;
+    auto I = [&]() { return atoi(v.c_str()); };
+    auto F = [&]() { return (float)atof(v.c_str()); };
+    if (k == "-cf") { std::vector<std::string> sub; cli_tokens_from_file(v, sub); cli_apply(a, sub); }
+    else if (k == "-if") a.infile = v;
+    else if (k == "-of") a.outfile = v;
+    else if (k == "-rf") a.recfile = v;
+    else if (k == "-n") a.num_frames = I();
+    else if (k == "-skip") a.skip = I();
+    else if (k == "-streams") a.streams = I();
+    else if (k == "-width") p.width = I();
+    else if (k == "-height") p.height = I();
+    else if (k == "-qp") p.qp = I();
+    else if (k == "-f") p.frame_rate = F();
+    else if (k == "-lambda_coeffI") p.lambda_coeffI = F();
+    else if (k == "-lambda_coeffP") p.lambda_coeffP = F();
+    else if (k == "-early_skip_thr") p.early_skip_thr = F();
+    else if (k == "-enable_tb_split") p.enable_tb_split = I();
+    else if (k == "-enable_pb_split") p.enable_pb_split = I();
+    else if (k == "-max_num_ref") p.max_num_ref = I();
+    else if (k == "-HQperiod") p.HQperiod = I();
+    else if (k == "-num_reorder_pics") p.num_reorder_pics = I();
+    else if (k == "-interp_ref") p.interp_ref = I();
+    else if (k == "-dqpP") p.dqpP = I();
+    else if (k == "-dqpI") p.dqpI = I();
+    else if (k == "-mqpP") p.mqpP = F();
+    else if (k == "-intra_period") p.intra_period = I();
+    else if (k == "-intra_rdo") p.intra_rdo = I();
+    else if (k == "-encoder_speed") p.encoder_speed = I();
+    else if (k == "-deblocking") p.deblocking = I();
+    else if (k == "-cdef") p.cdef = I();
+    else if (k == "-clpf") p.clpf = I();
+    else if (k == "-use_block_contexts") p.use_block_contexts = I();
+    else if (k == "-enable_bipred") p.enable_bipred = I();
+    else if (k == "-enable_cfl_intra") p.cfl_intra = I();
+    else if (k == "-enable_cfl_inter") p.cfl_inter = I();
+    else if (k == "-bitdepth") p.bitdepth = I();
+    else if (k == "-input_bitdepth") p.input_bitdepth = I();
+    // anything else (B-frame QP tables etc.) is accepted and ignored by this path
+  }
+}
+
+static inline CliArgs cli_parse(int argc, char** argv) {
+  CliArgs a;
+  std::vector<std::string> t;
+  for (int i = 1; i < argc; i++) t.push_back(argv[i]);
+  // config files first, explicit arguments afterwards (enc/strings.c:196-265 applies argv last)
+  std::vector<std::string> files, rest;
+  for (size_t i = 0; i + 1 < t.size(); i += 2) {
+    if (t[i] == "-cf") { files.push_back(t[i]); files.push_back(t[i + 1]); }
+    else { rest.push_back(t[i]); rest.push_back(t[i + 1]); }
+  }
+  cli_apply(a, files);
+  cli_apply(a, rest);
+  return a;
+}
+
+// Encode `num_frames` frames of a raw 4:2:0 file with S identical-geometry streams: stream s
+// codes frames [skip + s*num_frames, skip + (s+1)*num_frames) as its own closed stream (what the
+// reference produces with -skip/-n).  Outputs "<of>" for S==1, "<of>.<s>" otherwise.
+template <typename PIX> int cli_run(const CliArgs& a) {
+  const SeqParams& p = a.sp;
+  FILE* fi = fopen(a.infile.c_str(), "rb");
+  if (!fi) { fprintf(stderr, "cannot open %s\n", a.infile.c_str()); return 2; }
+  const size_t fsz = (size_t)p.width * p.height * 3 / 2;
+  Engine<PIX> eng;
+  eng.open(p, a.streams);
+  std::vector<PIX> frame(fsz), rec(fsz);
+  std::vector<FILE*> fr(a.streams, nullptr);
+  auto name = [&](const std::string& base, int s) { return a.streams == 1 ? base : base + "." + std::to_string(s); };
+  for (int s = 0; s < a.streams; s++)
+    if (!a.recfile.empty()) fr[s] = fopen(name(a.recfile, s).c_str(), "wb");
+  for (int n = 0; n < a.num_frames; n++) {
+    std::vector<FrameParams> fp(a.streams);
+    for (int s = 0; s < a.streams; s++) {
+      size_t idx = (size_t)a.skip + (size_t)s * a.num_frames + n;
+      if (fseek(fi, (long)(idx * fsz * sizeof(PIX)), SEEK_SET) || fread(frame.data(), sizeof(PIX), fsz, fi) != fsz) {
+        fprintf(stderr, "short read at frame %zu\n", idx);
+        return 3;
+      }
+      eng.upload_orig(s, frame.data());
+      fp[s] = eng.next_frame_params(s);
+    }
+    eng.encode_frames(fp);
+    for (int s = 0; s < a.streams; s++)
+      if (fr[s]) { eng.download_rec(s, rec.data()); fwrite(rec.data(), sizeof(PIX), fsz, fr[s]); }
+  }
+  for (int s = 0; s < a.streams; s++) {
+    if (fr[s]) fclose(fr[s]);
+    if (!a.outfile.empty()) {
+      FILE* fo = fopen(name(a.outfile, s).c_str(), "wb");
+      fwrite(eng.st[s].out.data(), 1, eng.st[s].out.size(), fo);
+      fclose(fo);
+    }
+  }
+  eng.close();
+  fclose(fi);
+  return 0;
+}
+
+}  // namespace tk

@@ -1,0 +1,199 @@
+// thor_amd: MI355X-native per-block encode path for the Thor codec.
+// tk_common.h - build modes, team abstraction, basic codec types and constant tables.
+//
+// The engine sources (tk_*.h) are written once as "team-cooperative" code: every
+// function is executed by all lanes of a team in lock step (uniform control
+// flow), data-parallel loops are strided over team.rank/team.size and phases are
+// separated by team.sync().  On the GPU a team is one 64-lane wavefront
+// (gfx950, wave64) working on one superblock.  With -DTHOR_HOSTSIM the very same
+// source compiles with g++ as a 1-lane team; that build exists ONLY so that the
+// bit-exactness of the algorithm can be developed and regression-tested against
+// the reference encoder in a container without a GPU (tests/ only - the product
+// library contains no CPU path).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(THOR_HOSTSIM)
+#include <string.h>
+#include <stdlib.h>
+#define TK_DEV static inline
+#define TK_CONST static const
+#define TK_HOST 1
+#else
+#include <hip/hip_runtime.h>
+#define TK_DEV __device__ __forceinline__
+#define TK_DEVNI __device__ __noinline__
+#define TK_CONST __device__ const
+#define TK_HOST 0
+#endif
+#if TK_HOST
+#define TK_DEVNI static
+#endif
+
+namespace tk {
+
+// ---------------------------------------------------------------------------------
+// Team: the cooperating lane group.
+// ---------------------------------------------------------------------------------
+struct Team {
+  int rank;
+  int size;
+#if TK_HOST
+  inline void sync() const {}
+#else
+  __device__ __forceinline__ void sync() const { __syncthreads(); }  // one wave per workgroup
+#endif
+};
+
+TK_DEV void team_add(int* p, int v) {
+#if TK_HOST
+  *p += v;
+#else
+  atomicAdd(p, v);
+#endif
+}
+TK_DEV void team_add64(unsigned long long* p, unsigned long long v) {
+#if TK_HOST
+  *p += v;
+#else
+  atomicAdd(p, v);
+#endif
+}
+TK_DEV void team_or(unsigned* p, unsigned v) {
+#if TK_HOST
+  *p |= v;
+#else
+  atomicOr(p, v);
+#endif
+}
+
+// IEEE double multiply-add WITHOUT contraction: the reference is built -std=c99
+// (=> -ffp-contract=off), so lambda*bits+0.5 is a rounded product followed by a
+// rounded sum.
+TK_DEV double mul_add_nofma(double a, double b, double c) {
+#if TK_HOST
+  volatile double p = a * b;
+  return p + c;
+#else
+  return __dadd_rn(__dmul_rn(a, b), c);
+#endif
+}
+
+template <typename T> TK_DEV T tmin(T a, T b) { return a < b ? a : b; }
+template <typename T> TK_DEV T tmax(T a, T b) { return a > b ? a : b; }
+TK_DEV int iabs(int a) { return a < 0 ? -a : a; }
+TK_DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+TK_DEV int ilog2(unsigned x) {
+#if TK_HOST
+  return 31 - __builtin_clz(x);
+#else
+  return 31 - __clz((int)x);
+#endif
+}
+TK_DEV int sat_pix(int v, int bitdepth) { return clampi(v, 0, (1 << bitdepth) - 1); }
+
+// ---------------------------------------------------------------------------------
+// Codec constants (reference: common/global.h:54-93).
+// ---------------------------------------------------------------------------------
+enum { kMaxSb = 128, kMinBlk = 8, kMinPb = 4, kMaxQuant = 16, kPadY = 160, kMaxRefs = 4 };
+enum { F_I = 0, F_P = 1, F_B = 2 };
+enum { M_SKIP = 0, M_INTRA = 1, M_INTER = 2, M_BIPRED = 3, M_MERGE = 4 };
+enum { P_NONE = 0, P_HOR = 1, P_VER = 2, P_QUAD = 3 };
+enum { kNumIntraModes = 10 };
+enum { kCostInit = 1u << 31 };  // reference MAX_UINT32 is 1<<31 (common/global.h:63)
+
+struct mv_t {
+  int16_t x, y;
+};
+TK_DEV mv_t mk_mv(int x, int y) {
+  mv_t m;
+  m.x = (int16_t)x;
+  m.y = (int16_t)y;
+  return m;
+}
+
+// Candidate / neighbour motion record (reference inter_pred_t, common/types.h:138-145).
+// dir: 0 uni, 2 bi, -1 "came from an intra block" (reference stores (uint32_t)-1).
+struct InterPred {
+  mv_t mv0, mv1;
+  int8_t ref0, ref1, dir, pad;
+};
+
+// Per 4x4-pel cell state (compact device form of deblock_data_t, common/types.h:178-187).
+struct DbCell {
+  mv_t mv0, mv1;
+  uint8_t mode;
+  uint8_t size;
+  uint8_t tbpb;  // bit0 tb_split, bits1-2 pb_part
+  uint8_t cbp;   // bit0 y>0, bit1 u>0, bit2 v>0
+  int8_t ref0, ref1, dir;
+  uint8_t pad;
+};
+
+// Constant tables: filled once by the host (tk_tables.h:init_tables) and uploaded
+// (device) or used in place (hostsim).
+struct Tables {
+  int16_t zz4[16], zz8[64], zz16[256];       // position -> scan index (common_tables.c:29-66)
+  int16_t izz4[16], izz8[64], izz16[256];    // scan index -> position
+  int16_t dct4[16], dct8[64], dct16[256], dct32[1024];  // HEVC integer DCT (transform.c:37-241)
+  uint8_t chroma_qp[52];
+  uint8_t beta[52];
+  uint8_t tc[56];
+};
+
+#if TK_HOST
+extern Tables g_tab;
+#define TK_TAB (tk::g_tab)
+#else
+extern __device__ Tables g_tab;
+#define TK_TAB (tk::g_tab)
+#endif
+
+// quant / dequant scales (common_tables.c:74-75)
+TK_DEV int quant_scale(int r) {
+  return r == 0 ? 26214 : r == 1 ? 23302 : r == 2 ? 20560 : r == 3 ? 18396 : r == 4 ? 16384 : 14564;
+}
+TK_DEV int dequant_scale(int r) { return r == 0 ? 40 : r == 1 ? 45 : r == 2 ? 51 : r == 3 ? 57 : r == 4 ? 64 : 72; }
+
+// ---------------------------------------------------------------------------------
+// Frame / stream description shared by host and device.
+// ---------------------------------------------------------------------------------
+template <typename PIX> struct Plane3 {
+  PIX* y;
+  PIX* u;
+  PIX* v;    // pointers to pixel (0,0) (inside the padding for padded planes)
+  int sy, sc;  // strides in samples
+};
+
+struct EncCfg {  // the subset of enc_params the block path reads (enc/mainenc.h:35-112)
+  int width, height;
+  int bitdepth;
+  int enable_tb_split, enable_pb_split, enable_bipred;
+  int encoder_speed, intra_rdo, use_block_contexts;
+  int cfl_intra, cfl_inter;
+  int max_num_ref, interp_ref_cfg;
+  float early_skip_thr;
+};
+
+template <typename PIX> struct FrameJob {
+  EncCfg cfg;
+  int frame_type, qp, num_ref, frame_num, interp_ref, num_intra_modes;
+  int sign[kMaxRefs];     // ref->frame_num >  cur frame_num  (uni-pred / RDO paths)
+  int sign_ge[kMaxRefs];  // ref->frame_num >= cur frame_num  (bi-pred early skip, Appendix B.19)
+  double lambda;          // lambda_coeff * squared_lambda_QP[qp]
+  double sqrt_lambda;     // sqrt(lambda), computed on the host with libm
+  Plane3<PIX> orig, rec;
+  Plane3<PIX> ref[kMaxRefs];  // by ref_idx (already resolved through ref_array[])
+  DbCell* cells;              // (height/4) x (width/4)
+  int cell_stride;
+  int sb_cols, sb_rows;
+  uint32_t* sb_bits;       // per SB bit buffer, sb_words words each
+  int sb_words;
+  int* sb_nbits;           // per SB number of bits written
+  int* sb_status;          // 0 ok, !=0 overflow/internal error
+  uint8_t* scratch;        // per-team scratch arena, scratch_bytes each
+  size_t scratch_bytes;
+};
+
+}  // namespace tk

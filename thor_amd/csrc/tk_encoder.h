@@ -1,0 +1,349 @@
+// tk_encoder.h - host side of the engine: stream state in device memory, per-frame job set-up,
+// superblock wavefront scheduling, bitstream assembly.  Shared by the HIP library (kernels in
+// thor_hip.cpp) and by the 1-lane host simulation used in CPU tests (hostsim.cpp); the two
+// differ only in the `backend` functions declared below.
+// Specification followed: enc/encode_frame.c:637-850 (encode_frame: lambda, header, SB raster
+// order, deblock, CDEF, reference rotation), enc/write_bits.c:49-121 (sequence / frame header),
+// enc/putbits.c:45-83 (frame framing), enc/mainenc.c:246-523 (low-delay GOP: frame types, QPs and
+// reference lists).
+#pragma once
+#include <vector>
+#include <string>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include "tk_common.h"
+#include "tk_tables.h"
+
+namespace tk {
+
+// ---- backend (device memory + launches) ------------------------------------------------
+namespace backend {
+void* dev_alloc(size_t n);
+void dev_free(void* p);
+void h2d(void* d, const void* h, size_t n);
+void d2h(void* h, const void* d, size_t n);
+void dev_memset(void* d, int v, size_t n);
+void dev_sync();
+size_t team_ws_bytes(int pix_bytes);
+// jobs: device array of S FrameJob; hjobs: the same on the host.
+template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S);
+template <typename PIX> void run_deblock(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S);
+template <typename PIX> void run_make_ref(const FrameJob<PIX>* hjobs, const Plane3<PIX>* dst, int S);
+}  // namespace backend
+
+// ---- parameters -------------------------------------------------------------------------
+struct SeqParams {  // the enc_params fields this path honours (enc/mainenc.h:35-112)
+  int width = 0, height = 0, qp = 32;
+  int bitdepth = 8, input_bitdepth = 8;
+  float frame_rate = 30.f;
+  float lambda_coeffI = 1.f, lambda_coeffP = 1.f;
+  float early_skip_thr = 0.f;
+  int enable_tb_split = 0, enable_pb_split = 0, max_num_ref = 1, HQperiod = 1;
+  int num_reorder_pics = 0, dyadic_coding = 1, interp_ref = 0;
+  int dqpP = 0, dqpI = 0;
+  float mqpP = 1.f;
+  int intra_period = 0, intra_rdo = 0, encoder_speed = 0;
+  int deblocking = 1, cdef = 2, clpf = 0, use_block_contexts = 0, enable_bipred = 0;
+  int cfl_intra = 1, cfl_inter = 0;
+  int log2_sb_size = 7;
+};
+
+struct FrameParams {
+  int frame_type = F_I, qp = 32, num_ref = 0, frame_num = 0, interp_ref = 0, num_intra_modes = 10;
+  int ref_array[kMaxRefs] = {0, 0, 0, 0};  // indices into the sliding window (0 = most recent)
+  double lambda_coeff = 1.0;
+};
+
+// ---- host bit writer (MSB first) ---------------------------------------------------------
+struct HostBits {
+  std::vector<uint8_t> bytes;
+  int nbits = 0;
+  void put(int n, uint32_t v) {
+    for (int i = n - 1; i >= 0; i--) {
+      if ((nbits & 7) == 0) bytes.push_back(0);
+      if ((v >> i) & 1u) bytes.back() |= (uint8_t)(0x80u >> (nbits & 7));
+      nbits++;
+    }
+  }
+  // append nb bits taken MSB-first from 32-bit words (device BitSink layout)
+  void append_words(const uint32_t* w, int nb) {
+    int i = 0;
+    for (; i + 32 <= nb; i += 32) put(32, w[i >> 5]);
+    if (i < nb) put(nb - i, w[i >> 5] >> (32 - (nb - i)));
+  }
+  void overwrite(int pos, int n, uint32_t v) {  // header back-patching
+    for (int i = n - 1; i >= 0; i--, pos++) {
+      uint8_t m = (uint8_t)(0x80u >> (pos & 7));
+      if ((v >> i) & 1u) bytes[pos >> 3] |= m; else bytes[pos >> 3] &= (uint8_t)~m;
+    }
+  }
+};
+
+inline void write_sequence_header(HostBits& b, const SeqParams& p) {  // write_bits.c:49-81 (4:2:0, no qmtx)
+  b.put(16, p.width); b.put(16, p.height); b.put(3, p.log2_sb_size);
+  b.put(1, p.enable_pb_split); b.put(1, p.enable_tb_split); b.put(2, p.max_num_ref - 1);
+  b.put(2, p.interp_ref); b.put(1, 0 /*delta qp*/); b.put(1, p.deblocking); b.put(1, p.clpf ? 1 : 0);
+  b.put(1, p.use_block_contexts); b.put(2, p.enable_bipred); b.put(1, 0 /*qmtx*/);
+  b.put(2, 1 /*420*/); b.put(4, p.num_reorder_pics); b.put(1, p.cfl_intra); b.put(1, p.cfl_inter);
+  b.put(1, p.bitdepth != 8);
+  if (p.bitdepth != 8) b.put(1, p.bitdepth == 12);
+  b.put(1, p.input_bitdepth != 8);
+  if (p.input_bitdepth != 8) b.put(1, p.input_bitdepth == 12);
+}
+
+struct CdefHeader {
+  int damping = 5, bits = 0;
+  int strengths[8] = {0}, uv_strengths[8] = {0};
+};
+inline void write_cdef_params(HostBits& b, int pos_or_minus1, int cdef_on, const CdefHeader& h) {  // write_bits.c:83-97
+  HostBits tmp;
+  if (cdef_on) {
+    tmp.put(2, h.damping - 3); tmp.put(2, h.bits);
+    for (int i = 0; i < (1 << h.bits); i++) { tmp.put(7, h.strengths[i]); tmp.put(7, h.uv_strengths[i]); }
+  } else tmp.put(18, 0);
+  if (pos_or_minus1 < 0) {
+    for (int i = 0; i < tmp.nbits; i++) b.put(1, (tmp.bytes[i >> 3] >> (7 - (i & 7))) & 1u);
+  } else {
+    for (int i = 0; i < tmp.nbits; i++) b.overwrite(pos_or_minus1 + i, 1, (tmp.bytes[i >> 3] >> (7 - (i & 7))) & 1u);
+  }
+}
+
+// ---- per-stream device state ---------------------------------------------------------------
+template <typename PIX> struct DevFrame {
+  PIX* base_y = nullptr;
+  PIX* base_c = nullptr;
+  Plane3<PIX> p;
+  int frame_num = -1;
+  void alloc(int w, int h, int pad) {
+    int sy = (w + 2 * pad + 15) & ~15, sc = (w / 2 + 2 * (pad / 2) + 15) & ~15;
+    size_t ay = (size_t)(h + 2 * pad) * sy + 64, ac = (size_t)(h / 2 + 2 * (pad / 2)) * sc + 64;
+    base_y = (PIX*)backend::dev_alloc(ay * sizeof(PIX));
+    base_c = (PIX*)backend::dev_alloc(2 * ac * sizeof(PIX));
+    p.sy = sy; p.sc = sc;
+    p.y = base_y + (size_t)pad * sy + pad;
+    p.u = base_c + (size_t)(pad / 2) * sc + pad / 2;
+    p.v = p.u + ac;
+  }
+  void release() { backend::dev_free(base_y); backend::dev_free(base_c); base_y = base_c = nullptr; }
+};
+
+template <typename PIX> struct Stream {
+  DevFrame<PIX> orig, rec;
+  std::vector<DevFrame<PIX>> ring;  // sliding window, ring[0] = most recent reconstruction
+  DbCell* cells = nullptr;
+  uint32_t* sb_bits = nullptr;
+  int* sb_nbits = nullptr;
+  int* sb_status = nullptr;
+  uint8_t* scratch = nullptr;
+  int num_encoded = 0;
+  HostBits bits;             // bits of the frame being assembled (sequence header rides on frame 0)
+  std::vector<uint8_t> out;  // finished stream bytes (4-byte big-endian length + payload per frame)
+};
+
+template <typename PIX> class Engine {
+ public:
+  SeqParams sp;
+  int S = 0, sb_cols = 0, sb_rows = 0, nsb = 0, max_diag = 0, ring_size = 0;
+  static const int kSbWords = 16384;
+  std::vector<Stream<PIX>> st;
+  FrameJob<PIX>* d_jobs = nullptr;
+  std::vector<FrameJob<PIX>> h_jobs;
+  size_t ws_bytes = 0;
+
+  void open(const SeqParams& p, int num_streams) {
+    sp = p; S = num_streams;
+    sb_cols = (p.width + kMaxSb - 1) / kMaxSb; sb_rows = (p.height + kMaxSb - 1) / kMaxSb; nsb = sb_cols * sb_rows;
+    max_diag = 0;
+    for (int t = 0; t <= (sb_cols - 1) + 2 * (sb_rows - 1); t++) {
+      int n = 0;
+      for (int k = 0; k < sb_rows; k++) { int l = t - 2 * k; if (l >= 0 && l < sb_cols) n++; }
+      if (n > max_diag) max_diag = n;
+    }
+    ring_size = (p.HQperiod > p.max_num_ref ? p.HQperiod : p.max_num_ref) + 1;
+    ws_bytes = (backend::team_ws_bytes((int)sizeof(PIX)) + 255) & ~(size_t)255;
+    st.resize(S);
+    const int cw = p.width / 4, chh = p.height / 4;
+    for (auto& s : st) {
+      s.orig.alloc(p.width, p.height, 0);
+      s.rec.alloc(p.width, p.height, 0);
+      s.ring.resize(ring_size);
+      for (auto& r : s.ring) r.alloc(p.width, p.height, kPadY);
+      s.cells = (DbCell*)backend::dev_alloc((size_t)cw * chh * sizeof(DbCell));
+      backend::dev_memset(s.cells, 0, (size_t)cw * chh * sizeof(DbCell));
+      s.sb_bits = (uint32_t*)backend::dev_alloc((size_t)nsb * kSbWords * 4);
+      s.sb_nbits = (int*)backend::dev_alloc(nsb * sizeof(int));
+      s.sb_status = (int*)backend::dev_alloc(nsb * sizeof(int));
+      s.scratch = (uint8_t*)backend::dev_alloc(ws_bytes * max_diag);
+      write_sequence_header(s.bits, sp);
+    }
+    d_jobs = (FrameJob<PIX>*)backend::dev_alloc(sizeof(FrameJob<PIX>) * S);
+    h_jobs.resize(S);
+  }
+  void close() {
+    for (auto& s : st) {
+      s.orig.release(); s.rec.release();
+      for (auto& r : s.ring) r.release();
+      backend::dev_free(s.cells); backend::dev_free(s.sb_bits); backend::dev_free(s.sb_nbits);
+      backend::dev_free(s.sb_status); backend::dev_free(s.scratch);
+    }
+    st.clear();
+    backend::dev_free(d_jobs); d_jobs = nullptr;
+  }
+
+  // planar 4:2:0 frame in host memory -> device `orig` of stream s
+  void upload_orig(int s, const PIX* yuv) {
+    const int w = sp.width, h = sp.height;
+    std::vector<PIX> tmp;
+    DevFrame<PIX>& f = st[s].orig;
+    if (f.p.sy == w) backend::h2d(f.p.y, yuv, (size_t)w * h * sizeof(PIX));
+    else { tmp.assign((size_t)f.p.sy * h, 0); for (int i = 0; i < h; i++) memcpy(&tmp[(size_t)i * f.p.sy], yuv + (size_t)i * w, w * sizeof(PIX)); backend::h2d(f.p.y, tmp.data(), tmp.size() * sizeof(PIX)); }
+    const PIX* cu = yuv + (size_t)w * h; const PIX* cv = cu + (size_t)(w / 2) * (h / 2);
+    if (f.p.sc == w / 2) { backend::h2d(f.p.u, cu, (size_t)(w / 2) * (h / 2) * sizeof(PIX)); backend::h2d(f.p.v, cv, (size_t)(w / 2) * (h / 2) * sizeof(PIX)); }
+    else {
+      tmp.assign((size_t)f.p.sc * (h / 2), 0);
+      for (int i = 0; i < h / 2; i++) memcpy(&tmp[(size_t)i * f.p.sc], cu + (size_t)i * (w / 2), (w / 2) * sizeof(PIX));
+      backend::h2d(f.p.u, tmp.data(), tmp.size() * sizeof(PIX));
+      for (int i = 0; i < h / 2; i++) memcpy(&tmp[(size_t)i * f.p.sc], cv + (size_t)i * (w / 2), (w / 2) * sizeof(PIX));
+      backend::h2d(f.p.v, tmp.data(), tmp.size() * sizeof(PIX));
+    }
+  }
+  void download_rec(int s, PIX* yuv) {
+    const int w = sp.width, h = sp.height;
+    DevFrame<PIX>& f = st[s].rec;
+    std::vector<PIX> tmp((size_t)f.p.sy * h);
+    backend::d2h(tmp.data(), f.p.y, tmp.size() * sizeof(PIX));
+    for (int i = 0; i < h; i++) memcpy(yuv + (size_t)i * w, &tmp[(size_t)i * f.p.sy], w * sizeof(PIX));
+    PIX* cu = yuv + (size_t)w * h; PIX* cv = cu + (size_t)(w / 2) * (h / 2);
+    tmp.resize((size_t)f.p.sc * (h / 2));
+    backend::d2h(tmp.data(), f.p.u, tmp.size() * sizeof(PIX));
+    for (int i = 0; i < h / 2; i++) memcpy(cu + (size_t)i * (w / 2), &tmp[(size_t)i * f.p.sc], (w / 2) * sizeof(PIX));
+    backend::d2h(tmp.data(), f.p.v, tmp.size() * sizeof(PIX));
+    for (int i = 0; i < h / 2; i++) memcpy(cv + (size_t)i * (w / 2), &tmp[(size_t)i * f.p.sc], (w / 2) * sizeof(PIX));
+  }
+
+  // Low-delay GOP decisions for the next frame of stream s (enc/mainenc.c:261-523, num_reorder_pics == 0).
+  FrameParams next_frame_params(int s) const {
+    const Stream<PIX>& q = st[s];
+    const int n = q.num_encoded;
+    FrameParams f;
+    f.frame_num = n;
+    if (sp.intra_period > 0) f.frame_type = (n % sp.intra_period) == 0 ? F_I : F_P;
+    else f.frame_type = n == 0 ? F_I : F_P;
+    if (f.frame_type == F_I) f.qp = sp.qp + sp.dqpI;
+    else if (n % sp.HQperiod) f.qp = (int)(sp.mqpP * (float)sp.qp) + sp.dqpP;
+    else f.qp = sp.qp;
+    f.qp = f.qp < 0 ? 0 : (f.qp > 51 ? 51 : f.qp);
+    f.num_ref = f.frame_type == F_I ? 0 : (n < sp.max_num_ref ? n : sp.max_num_ref);
+    if (f.num_ref >= 1) f.ref_array[0] = 0;
+    if (f.num_ref >= 2) {
+      int r1 = ((n + sp.HQperiod - 2) % sp.HQperiod) + 1;
+      f.ref_array[1] = r1;
+      if (f.num_ref >= 3) {
+        int r2 = r1 == 1 ? 2 : 1;
+        f.ref_array[2] = r2;
+        if (f.num_ref == 4) { int r3 = r2 + 1; if (r3 == r1) r3 += 1; f.ref_array[3] = r3; }
+      }
+    }
+    for (int r = f.num_ref - 1; r > 0; --r)
+      for (int k = r - 1; k >= 0; --k)
+        if (f.ref_array[k] == f.ref_array[r]) {
+          for (int t = r; t < f.num_ref - 1; ++t) f.ref_array[t] = f.ref_array[t + 1];
+          f.num_ref--;
+          break;
+        }
+    // references older than the last intra frame are dropped (mainenc.c:506-518)
+    if (sp.intra_period > 0) {
+      int last_intra = (n / sp.intra_period) * sp.intra_period;
+      if (n > last_intra)
+        for (int r = f.num_ref - 1; r >= 0; --r)
+          if (q.ring[f.ref_array[r]].frame_num < last_intra) {
+            for (int t = r; t < f.num_ref - 1; ++t) f.ref_array[t] = f.ref_array[t + 1];
+            f.num_ref--;
+          }
+    }
+    f.num_intra_modes = (sp.intra_rdo == 0 || (f.frame_type != F_I && sp.encoder_speed > 0)) ? 4 : 10;
+    f.lambda_coeff = f.frame_type == F_I ? sp.lambda_coeffI : sp.lambda_coeffP;
+    return f;
+  }
+
+  // Encode one frame per stream (origs already uploaded). Appends to st[s].out.
+  void encode_frames(const std::vector<FrameParams>& fp) {
+    for (int s = 0; s < S; s++) {
+      Stream<PIX>& q = st[s];
+      const FrameParams& f = fp[s];
+      FrameJob<PIX>& J = h_jobs[s];
+      memset(&J, 0, sizeof(J));
+      EncCfg& c = J.cfg;
+      c.width = sp.width; c.height = sp.height; c.bitdepth = sp.bitdepth;
+      c.enable_tb_split = sp.enable_tb_split; c.enable_pb_split = sp.enable_pb_split; c.enable_bipred = sp.enable_bipred;
+      c.encoder_speed = sp.encoder_speed; c.intra_rdo = sp.intra_rdo; c.use_block_contexts = sp.use_block_contexts;
+      c.cfl_intra = sp.cfl_intra; c.cfl_inter = sp.cfl_inter; c.max_num_ref = sp.max_num_ref; c.interp_ref_cfg = sp.interp_ref;
+      c.early_skip_thr = sp.early_skip_thr;
+      J.frame_type = f.frame_type; J.qp = f.qp; J.num_ref = f.num_ref; J.frame_num = f.frame_num;
+      J.interp_ref = f.interp_ref; J.num_intra_modes = f.num_intra_modes;
+      J.lambda = f.lambda_coeff * kSquaredLambdaQP[f.qp];
+      J.sqrt_lambda = sqrt(J.lambda);
+      J.orig = q.orig.p; J.rec = q.rec.p;
+      for (int r = 0; r < f.num_ref; r++) {
+        const DevFrame<PIX>& rf = q.ring[f.ref_array[r]];
+        J.ref[r] = rf.p;
+        J.sign[r] = rf.frame_num > f.frame_num;
+        J.sign_ge[r] = rf.frame_num >= f.frame_num;
+      }
+      J.cells = q.cells; J.cell_stride = sp.width / 4;
+      J.sb_cols = sb_cols; J.sb_rows = sb_rows;
+      J.sb_bits = q.sb_bits; J.sb_words = kSbWords; J.sb_nbits = q.sb_nbits; J.sb_status = q.sb_status;
+      J.scratch = q.scratch; J.scratch_bytes = ws_bytes;
+      if (f.frame_type == F_I) backend::dev_memset(q.cells, 0, (size_t)(sp.width / 4) * (sp.height / 4) * sizeof(DbCell));
+    }
+    backend::h2d(d_jobs, h_jobs.data(), sizeof(FrameJob<PIX>) * S);
+    backend::run_superblocks<PIX>(d_jobs, h_jobs.data(), S);
+    if (sp.deblocking) backend::run_deblock<PIX>(d_jobs, h_jobs.data(), S);
+    // TODO CDEF (encode_frame.c:768-783)
+    // sliding window: the slot shifted out becomes ref[0] (encode_frame.c:826-835)
+    std::vector<Plane3<PIX>> dst(S);
+    for (int s = 0; s < S; s++) {
+      Stream<PIX>& q = st[s];
+      DevFrame<PIX> last = q.ring.back();
+      for (int r = ring_size - 1; r > 0; r--) q.ring[r] = q.ring[r - 1];
+      q.ring[0] = last;
+      q.ring[0].frame_num = fp[s].frame_num;
+      dst[s] = q.ring[0].p;
+    }
+    backend::run_make_ref<PIX>(h_jobs.data(), dst.data(), S);
+    backend::dev_sync();
+    // bitstream assembly
+    std::vector<int> nb(nsb), stt(nsb);
+    std::vector<uint32_t> words;
+    for (int s = 0; s < S; s++) {
+      Stream<PIX>& q = st[s];
+      const FrameParams& f = fp[s];
+      HostBits& b = q.bits;
+      // write_frame_header (write_bits.c:98-121)
+      b.put(1, f.frame_type != F_I); b.put(8, f.qp); b.put(4, f.num_intra_modes);
+      if (f.frame_type != F_I) b.put(2, f.num_ref - 1);
+      for (int r = 0; r < f.num_ref; r++) b.put(6, f.ref_array[r] + 1);
+      b.put(16, f.frame_num);
+      CdefHeader ch;
+      write_cdef_params(b, -1, 0, ch);
+      backend::d2h(nb.data(), q.sb_nbits, nsb * sizeof(int));
+      backend::d2h(stt.data(), q.sb_status, nsb * sizeof(int));
+      for (int i = 0; i < nsb; i++) {
+        if (stt[i]) { fprintf(stderr, "thor_hip: superblock %d bit buffer overflow\n", i); abort(); }
+        size_t nw = ((size_t)nb[i] + 31) / 32;
+        words.resize(nw);
+        backend::d2h(words.data(), q.sb_bits + (size_t)i * kSbWords, nw * 4);
+        b.append_words(words.data(), nb[i]);
+      }
+      // flush_all_bits framing (putbits.c:45-83)
+      uint32_t nbytes = (uint32_t)b.bytes.size();
+      for (int i = 0; i < 4; i++) q.out.push_back((uint8_t)(nbytes >> (24 - 8 * i)));
+      q.out.insert(q.out.end(), b.bytes.begin(), b.bytes.end());
+      b.bytes.clear(); b.nbits = 0;
+      q.num_encoded++;
+    }
+  }
+};
+
+}  // namespace tk

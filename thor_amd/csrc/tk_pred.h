@@ -1,0 +1,305 @@
+// tk_pred.h - inter (sub-pel) and intra prediction, team-cooperative.
+// Scalar specifications followed: common/inter_prediction.c:51-63 (clip_mv), :65-115
+// (chroma 1/8-pel 4-tap), :117-181 (luma 1/4-pel 6-tap + centre filter), :185-226
+// (get_inter_prediction_yuv), :228-247 (average_blocks_all); common/intra_prediction.c:57-183
+// (make_top_and_left) and :185-428 (the ten predictors); filter taps common_kernels.c:1905-1928.
+#pragma once
+#include "tk_common.h"
+
+namespace tk {
+
+// luma taps, [bipred set][frac][6]  (common_kernels.c:1905-1917)
+TK_DEV int luma_tap(int bipred, int frac, int m) {
+  // standard: {0,0,64,0,0,0},{1,-7,55,19,-5,1},{1,-7,38,38,-7,1},{1,-5,19,55,-7,1}
+  // bipred  : {0,0,64,0,0,0},{2,-10,59,17,-5,1},{1,-8,39,39,-8,1},{1,-5,17,59,-10,2}
+  const int8_t s[4][6] = {{0, 0, 64, 0, 0, 0}, {1, -7, 55, 19, -5, 1}, {1, -7, 38, 38, -7, 1}, {1, -5, 19, 55, -7, 1}};
+  const int8_t b[4][6] = {{0, 0, 64, 0, 0, 0}, {2, -10, 59, 17, -5, 1}, {1, -8, 39, 39, -8, 1}, {1, -5, 17, 59, -10, 2}};
+  return bipred ? b[frac][m] : s[frac][m];
+}
+// chroma taps [frac][4] (common_kernels.c:1919-1928)
+TK_DEV int chroma_tap(int frac, int m) {
+  const int8_t c[8][4] = {{0, 64, 0, 0},   {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-4, 44, 28, -4},
+                          {-4, 36, 36, -4}, {-4, 28, 44, -4}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
+  return c[frac][m];
+}
+
+// clip_mv (inter_prediction.c:51-63)
+TK_DEV mv_t clip_mv(mv_t mv, int ypos, int xpos, int fwidth, int fheight, int bwidth, int bheight, int sign) {
+  const int ext = kPadY - 16;
+  int mvy = sign ? -mv.y : mv.y;
+  int mvx = sign ? -mv.x : mv.x;
+  if (ypos + mvy / 4 < -ext) mvy = 4 * (-ext - ypos);
+  if (ypos + mvy / 4 + bheight > fheight + ext) mvy = 4 * (fheight + ext - ypos - bheight);
+  if (xpos + mvx / 4 < -ext) mvx = 4 * (-ext - xpos);
+  if (xpos + mvx / 4 + bwidth > fwidth + ext) mvx = 4 * (fwidth + ext - xpos - bwidth);
+  return mk_mv(sign ? -mvx : mvx, sign ? -mvy : mvy);
+}
+
+// One luma prediction sample at (i=row, j=col) of a PU whose reference pointer (at integer
+// displacement 0) is `ref`.  hor_int/ver_int/frac as derived by luma_setup().
+struct SubPel {
+  int hor_int, ver_int, hor_frac, ver_frac;
+};
+TK_DEV SubPel luma_setup(mv_t mv, int sign, int width, int height, int pic_w, int pic_h, int xpos, int ypos) {
+  int mx = sign ? -mv.x : mv.x, my = sign ? -mv.y : mv.y;
+  SubPel s;
+  s.ver_frac = my & 3;
+  s.hor_frac = mx & 3;
+  int vi = my >> 2, hi = mx >> 2;
+  vi = tmin(vi, pic_h - ypos);
+  vi = tmax(vi, -xpos - height);  // sic: xpos (inter_prediction.c:129), kept for parity
+  hi = tmin(hi, pic_w - xpos);
+  hi = tmax(hi, -xpos - width);
+  s.ver_int = vi;
+  s.hor_int = hi;
+  return s;
+}
+
+template <typename PIX>
+TK_DEV int luma_sample(const PIX* ref, int stride, int i, int j, const SubPel& s, int bipred, int bitdepth) {
+  const PIX* p = ref + (i + s.ver_int) * stride + (j + s.hor_int);
+  if (s.ver_frac == 0 && s.hor_frac == 0) return p[0];
+  if (s.ver_frac == 2 && s.hor_frac == 2 && bipred < 2) {
+    int sum = p[-stride] + p[-stride + 1] + p[-1] + 2 * p[0] + 2 * p[1] + p[2] + p[stride - 1] + 2 * p[stride] +
+              2 * p[stride + 1] + p[stride + 2] + p[2 * stride] + p[2 * stride + 1];
+    return sat_pix((sum + 8) >> 4, bitdepth);
+  }
+  if (s.hor_frac == 0) {
+    int sum = 0;
+    for (int m = 0; m < 6; m++) sum += luma_tap(bipred, s.ver_frac, m) * p[(m - 2) * stride];
+    return sat_pix((sum * 64 + 2048) >> 12, bitdepth);
+  }
+  if (s.ver_frac == 0) {
+    int sum = 0;
+    for (int m = 0; m < 6; m++) sum += luma_tap(bipred, s.hor_frac, m) * p[m - 2];
+    return sat_pix((sum * 64 + 2048) >> 12, bitdepth);
+  }
+  int sum = 0;
+  for (int n = 0; n < 6; n++) {
+    int col = 0;
+    for (int m = 0; m < 6; m++) col += luma_tap(bipred, s.ver_frac, m) * p[(m - 2) * stride + (n - 2)];
+    sum += luma_tap(bipred, s.hor_frac, n) * col;
+  }
+  return sat_pix((sum + 2048) >> 12, bitdepth);
+}
+
+// get_inter_prediction_luma for a whole PU (team-parallel over samples).
+template <typename PIX>
+TK_DEV void pred_luma(const Team& t, PIX* dst, int dstride, const PIX* ref, int rstride, int width, int height, mv_t mv,
+                      int sign, int bipred, int pic_w, int pic_h, int xpos, int ypos, int bitdepth) {
+  SubPel s = luma_setup(mv, sign, width, height, pic_w, pic_h, xpos, ypos);
+  for (int k = t.rank; k < width * height; k += t.size) {
+    int i = k / width, j = k - i * width;
+    dst[i * dstride + j] = (PIX)luma_sample(ref, rstride, i, j, s, bipred, bitdepth);
+  }
+}
+
+template <typename PIX>
+TK_DEV void pred_chroma(const Team& t, PIX* dst, int dstride, const PIX* ref, int rstride, int width, int height,
+                        mv_t mv, int sign, int pic_w2, int pic_h2, int xpos, int ypos, int bitdepth) {
+  int mx = sign ? -mv.x : mv.x, my = sign ? -mv.y : mv.y;
+  int vf = my & 7, hf = mx & 7;
+  int vi = my >> 3, hi = mx >> 3;
+  vi = tmin(vi, pic_h2 - ypos);
+  vi = tmax(vi, -xpos - height);  // sic (inter_prediction.c:78)
+  hi = tmin(hi, pic_w2 - xpos);
+  hi = tmax(hi, -xpos - width);
+  for (int k = t.rank; k < width * height; k += t.size) {
+    int i = k / width, j = k - i * width;
+    const PIX* p = ref + (i + vi) * rstride + (j + hi);
+    int v;
+    if (vf == 0 && hf == 0) {
+      v = p[0];
+    } else {
+      int sum = 0;
+      for (int n = 0; n < 4; n++) {
+        const PIX* q = p + (n - 1) * rstride;
+        int row = chroma_tap(hf, 0) * q[-1] + chroma_tap(hf, 1) * q[0] + chroma_tap(hf, 2) * q[1] + chroma_tap(hf, 3) * q[2];
+        sum += chroma_tap(vf, n) * row;
+      }
+      v = sat_pix((sum + 2048) >> 12, bitdepth);
+    }
+    dst[i * dstride + j] = (PIX)v;
+  }
+}
+
+// get_inter_prediction_yuv (inter_prediction.c:185-226), 4:2:0.  dst planes are compact blocks
+// of stride `size` (luma) / size/2 (chroma).  `split`: 1 => four quadrant PUs with mv_arr[0..3].
+template <typename PIX>
+TK_DEV void pred_inter_yuv(const Team& t, const Plane3<PIX>& ref, PIX* py, PIX* pu, PIX* pv, int ypos, int xpos,
+                           int size, int bw, int bh, const mv_t* mv_arr, int sign, int pic_w, int pic_h,
+                           int enable_bipred, int split, int bitdepth) {
+  const int div = split + 1;
+  const int bwidth = bw / div, bheight = bh / div;
+  const int pstride = size;
+  const int yc = ypos >> 1, xc = xpos >> 1;
+  const PIX* ry = ref.y + ypos * ref.sy + xpos;
+  const PIX* ru = ref.u + yc * ref.sc + xc;
+  const PIX* rv = ref.v + yc * ref.sc + xc;
+  for (int index = 0; index < div * div; index++) {
+    int idx = index & 1, idy = (index >> 1) & 1;
+    int offpY = idy * bheight * pstride + idx * bwidth;
+    int offpC = ((idy * bheight * pstride) >> 2) + ((idx * bwidth) >> 1);
+    int offrY = idy * bheight * ref.sy + idx * bwidth;
+    int offrC = ((idy * bheight * ref.sc) >> 1) + ((idx * bwidth) >> 1);
+    mv_t mv = clip_mv(mv_arr[index], ypos, xpos, pic_w, pic_h, bwidth, bheight, sign);
+    pred_luma(t, py + offpY, pstride, ry + offrY, ref.sy, bwidth, bheight, mv, sign, enable_bipred, pic_w, pic_h,
+              xpos, ypos, bitdepth);
+    pred_chroma(t, pu + offpC, pstride >> 1, ru + offrC, ref.sc, bwidth >> 1, bheight >> 1, mv, sign, pic_w >> 1,
+                pic_h >> 1, xc, yc, bitdepth);
+    pred_chroma(t, pv + offpC, pstride >> 1, rv + offrC, ref.sc, bwidth >> 1, bheight >> 1, mv, sign, pic_w >> 1,
+                pic_h >> 1, xc, yc, bitdepth);
+  }
+}
+
+// average_blocks_all: truncating (a+b)>>1 (inter_prediction.c:228-247).
+template <typename PIX>
+TK_DEV void average_yuv(const Team& t, PIX* dy, PIX* du, PIX* dv, const PIX* ay, const PIX* au, const PIX* av,
+                        const PIX* by, const PIX* bu, const PIX* bv, int size, int bw, int bh) {
+  for (int k = t.rank; k < bw * bh; k += t.size) {
+    int i = k / bw, j = k - i * bw, o = i * size + j;
+    dy[o] = (PIX)(((int)ay[o] + (int)by[o]) >> 1);
+  }
+  int cw = bw >> 1, ch = bh >> 1, cs = size >> 1;
+  for (int k = t.rank; k < cw * ch; k += t.size) {
+    int i = k / cw, j = k - i * cw, o = i * cs + j;
+    du[o] = (PIX)(((int)au[o] + (int)bu[o]) >> 1);
+    dv[o] = (PIX)(((int)av[o] + (int)bv[o]) >> 1);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Intra
+// ---------------------------------------------------------------------------------
+template <typename PIX> struct IntraEdge {
+  PIX left[2 * kMaxSb];
+  PIX top[2 * kMaxSb];
+  PIX top_left;
+};
+
+// make_top_and_left (intra_prediction.c:57-183).  rec_frame points at the CB's top-left sample in
+// the reconstructed frame; rblock at the TU's top-left in the CB-local recon block (tb_split only);
+// (i, j) = TU offset inside the CB; (ypos, xpos) = CB position in this plane.
+template <typename PIX>
+TK_DEV void make_edges(const Team& t, IntraEdge<PIX>* e, const PIX* rec_frame, int fstride, const PIX* rblock,
+                       int rbstride, int i, int j, int ypos, int xpos, int size, int cb_upright, int cb_downleft,
+                       int tb_split, int bitdepth) {
+  const int len = 2 * size;
+  const PIX dflt = (PIX)(128 << (bitdepth - 8));
+  int downleft, upright;
+  if (!tb_split) {
+    downleft = cb_downleft;
+    upright = cb_upright;
+  } else {
+    downleft = (j == 0 && (i == 0 || cb_downleft)) ? 1 : 0;
+    upright = (j == 0 || (i == 0 && cb_upright)) ? 1 : 0;
+  }
+  const int leftlen = downleft ? size + 1 : size;
+  const int toplen = upright ? size + 1 : size;
+  const int top_from_block = tb_split && i != 0;
+  const int left_from_block = tb_split && j != 0;
+  const PIX* trow = top_from_block ? (rblock - rbstride) : (rec_frame - fstride + j);
+  // tb_split==0 => i==j==0 so (rec_frame - fstride + j) is the reference's &rec_frame[-fstride+j].
+  const int top_dflt = (ypos + i == 0);
+  const int left_dflt = (xpos + j == 0);
+  for (int k = t.rank; k < len; k += t.size) {
+    PIX tv, lv;
+    if (top_dflt) tv = dflt;
+    else tv = trow[k < toplen ? k : toplen - 1];
+    if (left_dflt) lv = dflt;
+    else {
+      int kk = k < leftlen ? k : leftlen - 1;
+      lv = left_from_block ? rblock[kk * rbstride - 1] : rec_frame[(i + kk) * fstride - 1];
+    }
+    e->top[k] = tv;
+    e->left[k] = lv;
+  }
+  if (t.rank == 0) {
+    PIX tl;
+    if (top_dflt) {
+      tl = left_dflt ? dflt : (left_from_block ? rblock[-1] : rec_frame[i * fstride - 1]);  // = left[0]
+    } else if (!top_from_block) {
+      tl = xpos > 0 ? rec_frame[-fstride + j - 1] : trow[0];
+    } else {
+      tl = xpos > 0 ? (j > 0 ? rblock[-rbstride - 1] : rec_frame[(i - 1) * fstride - 1]) : trow[0];
+    }
+    e->top_left = tl;
+  }
+  t.sync();
+}
+
+template <typename PIX> TK_DEV int f121(const PIX* a, int k, int len) {
+  int km = k > 0 ? k - 1 : 0, kp = k < len - 1 ? k + 1 : len - 1;
+  return (a[km] + 2 * a[k] + a[kp] + 2) >> 2;
+}
+template <typename PIX> TK_DEV int f5(const PIX* a, int k, int size) {
+  int k0 = clampi(k - 2, 0, size - 1), k1 = clampi(k - 1, 0, size - 1), k3 = clampi(k + 1, 0, size - 1),
+      k4 = clampi(k + 2, 0, size - 1);
+  return (int16_t)(a[k0] + 2 * a[k1] + 2 * a[k] + 2 * a[k3] + a[k4]);
+}
+
+// get_intra_prediction (intra_prediction.c:403-428) - writes size x size at dst (stride dstride).
+// (ypos, xpos) = TU position in this plane (only the ==0 tests matter, for DC).
+template <typename PIX>
+TK_DEV void pred_intra(const Team& t, const IntraEdge<PIX>* e, int ypos, int xpos, int size, PIX* dst, int dstride,
+                       int mode, int bitdepth) {
+  const PIX* left = e->left;
+  const PIX* top = e->top;
+  const int tl = e->top_left;
+  int dc = 0, tlF = 0, tlP = 0;
+  if (mode == 0 || mode > 9) {
+    const PIX* a = xpos != 0 ? left : top;
+    const PIX* b = ypos != 0 ? top : left;
+    unsigned sum = 0;
+    for (int k = 0; k < size; k++) sum += (unsigned)a[k] + (unsigned)b[k];
+    dc = (int)((sum + (unsigned)size) / (2u * (unsigned)size));
+  } else if (mode == 1) {
+    tlP = (int16_t)(left[1] + 2 * left[0] + 2 * tl + 2 * top[0] + top[1]);
+  } else if (mode == 4 || mode == 7 || mode == 8) {
+    tlF = (PIX)((2 * tl + left[0] + top[0] + 2) >> 2);
+  }
+  for (int k = t.rank; k < size * size; k += t.size) {
+    int i = k / size, j = k - i * size;
+    int v;
+    switch (mode) {
+      case 1:  // planar
+        v = sat_pix((f5(left, i, size) + f5(top, j, size) - tlP + 4) / 8, bitdepth);
+        break;
+      case 2: v = left[i]; break;  // hor
+      case 3: v = top[j]; break;   // ver
+      case 4: {  // upleft
+        int d = i - j;
+        v = d > 0 ? f121(left, d - 1, size) : (d == 0 ? tlF : f121(top, -d - 1, size));
+      } break;
+      case 5: v = f121(top, i + j + 1, 2 * size); break;  // upright
+      case 6: {  // upupright
+        int d = i + 2 * j;
+        v = (d & 1) ? f121(top, (d + 1) / 2, 2 * size) : ((f121(top, d / 2, 2 * size) + f121(top, d / 2 + 1, 2 * size)) >> 1);
+      } break;
+      case 7: {  // upupleft
+        int d = i - 2 * j;
+        if (d > 1) v = f121(left, d - 2, size);
+        else if (d == 1) v = tlF;
+        else if (d == 0) v = (tlF + f121(top, 0, size)) >> 1;
+        else if (d & 1) v = f121(top, (-d) / 2, size);
+        else v = (f121(top, (-d) / 2, size) + f121(top, (-d) / 2 - 1, size)) >> 1;
+      } break;
+      case 8: {  // upleftleft
+        int d = 2 * i - j;
+        if (d < -1) v = f121(top, -d - 2, size);
+        else if (d == -1) v = tlF;
+        else if (d == 0) v = (tlF + f121(left, 0, size)) >> 1;
+        else if (d & 1) v = f121(left, d / 2, size);
+        else v = (f121(left, d / 2, size) + f121(left, d / 2 - 1, size)) >> 1;
+      } break;
+      case 9: {  // downleftleft
+        int d = 2 * i + j;
+        v = (d & 1) ? f121(left, (d + 1) / 2, 2 * size) : ((f121(left, d / 2, 2 * size) + f121(left, d / 2 + 1, 2 * size)) >> 1);
+      } break;
+      default: v = dc; break;
+    }
+    dst[i * dstride + j] = (PIX)v;
+  }
+}
+
+}  // namespace tk

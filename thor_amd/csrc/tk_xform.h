@@ -1,0 +1,215 @@
+// tk_xform.h - residual, forward transform, quantise, dequantise, inverse transform, reconstruct.
+// Scalar specifications followed: common/transform.c:245-309 (transform, incl. the box-sum
+// down-scaling of 64/128 blocks and the int16 stage-1 truncation), :411-494 (inverse, 32x32 kernel
+// + replication for 64/128), enc/encode_block.c:84-160 (quantize), common/common_block.c:45-73
+// (dequantize), :75-84 (reconstruct_block).  Coefficient blocks are kept COMPACT (stride
+// qsize = min(size,16)) instead of the reference's stride-`size` layout.
+#pragma once
+#include "tk_common.h"
+
+namespace tk {
+
+struct XformWs {
+  int16_t in[32 * 32];    // (down-scaled) residual fed to the core transform
+  int16_t tmp[16 * 32];   // stage-1 output, [coef i][sample j]
+  int16_t coef[16 * 16];  // forward coefficients, compact
+  int16_t rcoef[16 * 16]; // de-quantised coefficients, compact
+  int16_t itmp[16 * 32];  // inverse stage-1, [coef col i][sample j]
+  int flag;               // team-shared scalar result
+};
+
+TK_DEV const int16_t* dct_matrix(int n) {
+  return n == 4 ? TK_TAB.dct4 : n == 8 ? TK_TAB.dct8 : n == 16 ? TK_TAB.dct16 : TK_TAB.dct32;
+}
+
+// Forward transform of (org - pred) -> ws->coef (qsize x qsize compact).
+template <typename PIX>
+TK_DEV void fwd_transform(const Team& t, XformWs* ws, const PIX* org, int ostride, const PIX* pred, int pstride,
+                          int size, int fast, int bitdepth) {
+  const int qsize = size < kMaxQuant ? size : kMaxQuant;
+  int size1 = size, scale = 1;
+  if (size > (32 >> fast)) {
+    size1 = 32 >> fast;
+    scale = size / size1;
+  }
+  // residual (+ optional saturating box sum, transform.c:262-277)
+  for (int k = t.rank; k < size1 * size1; k += t.size) {
+    int i = k / size1, j = k - i * size1;
+    int sum = 0;
+    if (scale == 1) {
+      sum = (int16_t)((int)org[i * ostride + j] - (int)pred[i * pstride + j]);
+    } else {
+      for (int m = 0; m < scale; m++)
+        for (int n = 0; n < scale; n++) {
+          int y = i * scale + m, x = j * scale + n;
+          int r = (int16_t)((int)org[y * ostride + x] - (int)pred[y * pstride + x]);
+          sum = clampi((int16_t)sum + r, -16384, 16383);
+        }
+    }
+    ws->in[k] = (int16_t)sum;
+  }
+  t.sync();
+  const int16_t* M = dct_matrix(size1);
+  const int shift_1 = ilog2(size) + ilog2(scale) + bitdepth - 8;
+  const int add_1 = 1 << (shift_1 - 1);
+  const int shift_2 = ilog2(size1) + 5;
+  const int add_2 = 1 << (shift_2 - 1);
+  for (int k = t.rank; k < qsize * size1; k += t.size) {
+    int i = k / size1, j = k - i * size1;
+    int sum = 0;
+    for (int q = 0; q < size1; q++) sum += M[i * size1 + q] * ws->in[j * size1 + q];
+    ws->tmp[i * size1 + j] = (int16_t)((sum + add_1) >> shift_1);
+  }
+  t.sync();
+  for (int k = t.rank; k < qsize * qsize; k += t.size) {
+    int i = k / qsize, j = k - i * qsize;
+    int sum = 0;
+    for (int q = 0; q < size1; q++) sum += M[i * size1 + q] * ws->tmp[j * size1 + q];
+    ws->coef[i * qsize + j] = (int16_t)((sum + add_2) >> shift_2);
+  }
+  t.sync();
+}
+
+// Same core transform but on an explicit int16 input block (early-skip path).
+TK_DEV void fwd_transform_block(const Team& t, XformWs* ws, int size, int bitdepth) {
+  // ws->in holds size x size (size <= 16) already; fast = 0, no scaling.
+  const int qsize = size;
+  const int16_t* M = dct_matrix(size);
+  const int shift_1 = ilog2(size) + bitdepth - 8;
+  const int add_1 = 1 << (shift_1 - 1);
+  const int shift_2 = ilog2(size) + 5;
+  const int add_2 = 1 << (shift_2 - 1);
+  for (int k = t.rank; k < qsize * size; k += t.size) {
+    int i = k / size, j = k - i * size;
+    int sum = 0;
+    for (int q = 0; q < size; q++) sum += M[i * size + q] * ws->in[j * size + q];
+    ws->tmp[i * size + j] = (int16_t)((sum + add_1) >> shift_1);
+  }
+  t.sync();
+  for (int k = t.rank; k < qsize * qsize; k += t.size) {
+    int i = k / qsize, j = k - i * qsize;
+    int sum = 0;
+    for (int q = 0; q < size; q++) sum += M[i * size + q] * ws->tmp[j * size + q];
+    ws->coef[i * qsize + j] = (int16_t)((sum + add_2) >> shift_2);
+  }
+  t.sync();
+}
+
+// quantize (encode_block.c:84-160), serial zigzag state machine. Returns cbp (0/1).
+TK_DEV int quantize_serial(const int16_t* coef, int16_t* coefq, int qp, int size, int intra_block) {
+  const int qsize = size < kMaxQuant ? size : kMaxQuant;
+  const int N = qsize * qsize;
+  const int16_t* izz = qsize == 4 ? TK_TAB.izz4 : (qsize == 8 ? TK_TAB.izz8 : TK_TAB.izz16);
+  const int64_t scale = quant_scale(qp % 6);
+  const int shift2 = 21 - ilog2(size) + qp / 6;
+  int64_t offset = (int64_t)(intra_block ? 38 : -26) << (shift2 - 8);
+  if (!intra_block) offset = -((int64_t)26 << (shift2 - 8));
+  int level = 0, pos = N - 1;
+  while (level == 0 && pos >= 0) {
+    int c = coef[izz[pos]];
+    int64_t l64 = (int64_t)iabs(c) * scale + offset;
+    level = (int)((l64 > 0 ? l64 : -l64) >> shift2);
+    pos--;
+  }
+  const int last_pos = level ? pos + 1 : pos;
+  const int64_t off0 = (int64_t)(intra_block ? 102 : 51) << (shift2 - 8);
+  const int64_t off1 = (int64_t)(intra_block ? 115 : 90) << (shift2 - 8);
+  int cbp = 0, level_mode = 1;
+  for (int p = 0; p < N; p++) {
+    int q = 0;
+    if (p <= last_pos) {
+      int c = coef[izz[p]];
+      int64_t ac = scale * (int64_t)iabs(c);
+      int level0 = (int)(ac >> shift2);
+      int64_t off = (level0 > (1 - level_mode)) ? off1 : off0;
+      int lev = (int)((ac + off) >> shift2);
+      q = c < 0 ? -lev : lev;
+      cbp |= (lev != 0);
+      if (level_mode) { if (lev == 0) level_mode = 0; }
+      else if (lev > 1) level_mode = 1;
+    }
+    coefq[izz[p]] = (int16_t)q;
+  }
+  return cbp;
+}
+
+TK_DEV int quantize_team(const Team& t, XformWs* ws, int16_t* coefq, int qp, int size, int intra_block) {
+  if (t.rank == 0) ws->flag = quantize_serial(ws->coef, coefq, qp, size, intra_block);
+  t.sync();
+  int r = ws->flag;
+  t.sync();
+  return r;
+}
+
+// dequantize (common_block.c:45-73): coefq -> ws->rcoef, int16 truncation as in the reference.
+TK_DEV void dequantize(const Team& t, XformWs* ws, const int16_t* coefq, int qp, int size) {
+  const int qsize = size < kMaxQuant ? size : kMaxQuant;
+  const int lshift = qp / 6, rshift = ilog2(size) - 1;
+  const int64_t scale = dequant_scale(qp % 6);
+  for (int k = t.rank; k < qsize * qsize; k += t.size) {
+    int64_t c = coefq[k];
+    int16_t r;
+    if (lshift >= rshift) r = (int16_t)((c * scale) << (lshift - rshift));
+    else r = (int16_t)((c * scale + ((int64_t)1 << (rshift - lshift - 1))) >> (rshift - lshift));
+    ws->rcoef[k] = r;
+  }
+  t.sync();
+}
+
+// inverse transform of ws->rcoef + prediction -> rec (saturated), replicating for 64/128.
+template <typename PIX>
+TK_DEV void inv_transform_recon(const Team& t, XformWs* ws, const PIX* pred, int pstride, PIX* rec, int rstride,
+                                int size, int bitdepth) {
+  const int n = size < 32 ? size : 32;
+  const int scale = size / n;
+  const int qsize = n < kMaxQuant ? n : kMaxQuant;
+  const int16_t* M = dct_matrix(n);
+  const int shift_2 = 20 - bitdepth, add_2 = 1 << (shift_2 - 1);
+  // stage 1: itmp[i*n + j] = clip((sum_k M[k][j]*rcoef[k][i] + 64) >> 7)   i < qsize, j < n
+  for (int k = t.rank; k < qsize * n; k += t.size) {
+    int i = k / n, j = k - i * n;
+    int sum = 0;
+    for (int q = 0; q < qsize; q++) sum += M[q * n + j] * ws->rcoef[q * qsize + i];
+    ws->itmp[i * n + j] = (int16_t)clampi((sum + 64) >> 7, -32768, 32767);
+  }
+  t.sync();
+  for (int k = t.rank; k < n * n; k += t.size) {
+    int i = k / n, j = k - i * n;
+    int sum = 0;
+    for (int q = 0; q < qsize; q++) sum += M[q * n + j] * ws->itmp[q * n + i];
+    int r = clampi((sum + add_2) >> shift_2, -32768, 32767);
+    for (int m = 0; m < scale; m++)
+      for (int x = 0; x < scale; x++) {
+        int yy = scale * i + m, xx = scale * j + x;
+        rec[yy * rstride + xx] = (PIX)sat_pix(r + (int)pred[yy * pstride + xx], bitdepth);
+      }
+  }
+  t.sync();
+}
+
+template <typename PIX>
+TK_DEV void copy_block(const Team& t, PIX* dst, int dstride, const PIX* src, int sstride, int w, int h) {
+  for (int k = t.rank; k < w * h; k += t.size) {
+    int i = k / w, j = k - i * w;
+    dst[i * dstride + j] = src[i * sstride + j];
+  }
+}
+
+// One transform unit: residual -> T -> Q -> (IQ -> IT -> recon | recon = pred). Returns cbp bit.
+// coeff_type: bit0 chroma, bit1 = (frame_type == I) [sic: frame type, Appendix B.6].
+template <typename PIX>
+TK_DEV int code_tu(const Team& t, XformWs* ws, const PIX* org, int ostride, const PIX* pred, int pstride, PIX* rec,
+                   int rstride, int size, int qp, int coeff_type, int fast, int16_t* coefq, int bitdepth) {
+  fwd_transform(t, ws, org, ostride, pred, pstride, size, fast, bitdepth);
+  int cbp = quantize_team(t, ws, coefq, qp, size, (coeff_type >> 1) & 1);
+  if (cbp) {
+    dequantize(t, ws, coefq, qp, size);
+    inv_transform_recon(t, ws, pred, pstride, rec, rstride, size, bitdepth);
+  } else {
+    copy_block(t, rec, rstride, pred, pstride, size, size);
+    t.sync();
+  }
+  return cbp;
+}
+
+}  // namespace tk
