@@ -5,6 +5,7 @@
 // (thor_amd/csrc/thor_hip.cpp) never links or calls this; it has no CPU path.
 #include "../../thor_amd/csrc/tk_block.h"
 #include "../../thor_amd/csrc/tk_filters.h"
+#include <math.h>
 #include "../../thor_amd/csrc/tk_cli.h"
 
 namespace tk {
@@ -50,6 +51,23 @@ template <typename PIX> void run_deblock(const FrameJob<PIX>* jobs, const FrameJ
 template <typename PIX> void run_make_ref(const FrameJob<PIX>* hjobs, const Plane3<PIX>* dst, int S) {
   for (int s = 0; s < S; s++) make_ref_rows(hjobs[s].rec, dst[s], hjobs[s].cfg.width, hjobs[s].cfg.height, 0, 1);
 }
+template <typename PIX> void run_cdef(const CdefJob<PIX>* cj, const CdefJob<PIX>*, int S) {
+  Team t{0, 1};
+  for (int s = 0; s < S; s++) {
+    const CdefJob<PIX>& C = cj[s];
+    for (int i = 0; i < C.height; i++) memcpy(C.src.y + (size_t)i * C.src.sy, C.rec.y + (size_t)i * C.rec.sy, C.width * sizeof(PIX));
+    for (int i = 0; i < C.height / 2; i++) {
+      memcpy(C.src.u + (size_t)i * C.src.sc, C.rec.u + (size_t)i * C.rec.sc, C.width / 2 * sizeof(PIX));
+      memcpy(C.src.v + (size_t)i * C.src.sc, C.rec.v + (size_t)i * C.rec.sc, C.width / 2 * sizeof(PIX));
+    }
+    cdef_pass_flags(C, 0, 1);
+    cdef_pass_dir(C, 0, 1);
+    if (C.cdef_bits) cdef_pass_mse(C, 0, 1);
+    cdef_pass_select(t, C);
+    cdef_pass_apply(C, 0, 1);
+  }
+}
+template void run_cdef<uint8_t>(const CdefJob<uint8_t>*, const CdefJob<uint8_t>*, int);
 template void run_superblocks<uint8_t>(const FrameJob<uint8_t>*, const FrameJob<uint8_t>*, int);
 template void run_deblock<uint8_t>(const FrameJob<uint8_t>*, const FrameJob<uint8_t>*, int);
 template void run_make_ref<uint8_t>(const FrameJob<uint8_t>*, const Plane3<uint8_t>*, int);

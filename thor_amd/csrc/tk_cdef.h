@@ -1,0 +1,431 @@
+// tk_cdef.h - Constrained Directional Enhancement Filter: encoder-side strength search + frame
+// filtering, work-item parallel (in-loop and ON in every *_high_efficiency
+// config, so bit-exact streams need it).
+// Specification followed: enc/encode_frame.c:47-486 (search_one_dual / joint_strength_search_dual,
+// dist_8x8, cdef_search), common/common_frame.c:766-1003 (cdef_prepare_input, cdef_allskip,
+// cdef_frame), common/common_block.c:94-279 (cdef_find_dir, direction tables, constrain,
+// cdef_filter_block), common/common_frame.h:61-72 (adjust_strength, cdef_init).
+// The reference filters in place through a write-back cache that guarantees every neighbour it
+// reads is still unfiltered; here the deblocked frame is copied to `src` and filtered out of place,
+// which is the same function.  Frame-outside taps read CDEF_VERY_LARGE exactly as
+// cdef_prepare_input produces them.  4:2:0 only.
+#pragma once
+#include "tk_common.h"
+
+namespace tk {
+
+enum { kCdefVeryLarge = 30000, kCdefMaxStr = 64 };
+
+struct CdefResult {
+  int nb_bits;                 // bits per filter block actually signalled
+  int strengths[8], uv_strengths[8];   // header values (pri*4 + sec after priconv)
+  int sb_count;                // number of non-all-skip filter blocks
+  int level_tab[2][8];         // scratch
+};
+
+template <typename PIX> struct CdefJob {
+  Plane3<PIX> rec;   // output (in-loop filtered)
+  Plane3<PIX> src;   // deblocked input copy
+  Plane3<PIX> org;
+  int width, height, bitdepth;
+  const DbCell* cells;
+  int cs;
+  int nfb_h, nfb_v;
+  int speed, damping, cdef_bits;   // speed = cdef-1; cdef_bits = header guess
+  int qp;
+  int8_t* dir;                     // per 8x8 luma block
+  int* var;
+  int* fb_compact;                 // per fb: compact index or -1 (all skip)
+  unsigned long long* mse;         // [2][nfb][64]
+  int* sel;                        // per compact index: selected preset
+  int* fb_sel;                     // per fb: selected preset (or 0)
+  CdefResult* res;
+  unsigned long long* tot;         // [64*64] scratch for the joint search
+};
+
+TK_DEV int cdef_priconv(int speed, int i) {
+  if (speed == 0) return i;
+  if (speed == 1) { const int t[8] = {0, 1, 2, 3, 5, 7, 10, 13}; return t[i & 7]; }
+  const int t[4] = {0, 1, 3, 6};
+  return t[i & 3];
+}
+TK_DEV int cdef_total_strengths(int speed) { return speed == 0 ? 64 : (speed == 1 ? 32 : 16); }
+
+TK_DEV int cdef_dx(int d, int k) {
+  const int8_t t[8][2] = {{1, 2}, {1, 2}, {1, 2}, {1, 2}, {1, 2}, {0, 1}, {0, 0}, {0, -1}};
+  return t[d][k];
+}
+TK_DEV int cdef_dy(int d, int k) {
+  const int8_t t[8][2] = {{-1, -2}, {0, -1}, {0, 0}, {0, 1}, {1, 2}, {1, 2}, {1, 2}, {1, 2}};
+  return t[d][k];
+}
+
+TK_DEV int cdef_constrain(int diff, int threshold, int damping) {
+  if (!threshold) return 0;
+  int a = iabs(diff);
+  int m = threshold - (a >> (damping - ilog2((unsigned)threshold)));
+  if (m < 0) m = 0;
+  int r = a < m ? a : m;
+  return diff < 0 ? -r : r;
+}
+
+template <typename PIX> TK_DEV int cdef_fetch(const PIX* p, int stride, int x, int y, int w, int h) {
+  if (x < 0 || y < 0 || x >= w || y >= h) return kCdefVeryLarge;
+  return p[y * stride + x];
+}
+
+// cdef_filter_block for one sample (common_block.c:224-279)
+template <typename PIX>
+TK_DEV int cdef_filter_px(const PIX* p, int stride, int x, int y, int w, int h, int pri, int sec, int dir,
+                          int pri_damp, int sec_damp, int cs) {
+  const int sel = (pri >> cs) & 1;
+  const int X = p[y * stride + x];
+  int sum = 0, mx = X, mn = X;
+  for (int k = 0; k < 2; k++) {
+    const int pt = sel ? 3 : (k == 0 ? 4 : 2);
+    const int st = k == 0 ? 2 : 1;
+    int ox = cdef_dx(dir, k), oy = cdef_dy(dir, k);
+    int p0 = cdef_fetch(p, stride, x + ox, y + oy, w, h), p1 = cdef_fetch(p, stride, x - ox, y - oy, w, h);
+    sum = (int16_t)(sum + pt * cdef_constrain(p0 - X, pri, pri_damp));
+    sum = (int16_t)(sum + pt * cdef_constrain(p1 - X, pri, pri_damp));
+    if (p0 != kCdefVeryLarge) mx = tmax(p0, mx);
+    if (p1 != kCdefVeryLarge) mx = tmax(p1, mx);
+    mn = tmin(p0, mn); mn = tmin(p1, mn);
+    int d2 = (dir + 2) & 7, d6 = (dir + 6) & 7;
+    int ax = cdef_dx(d2, k), ay = cdef_dy(d2, k), bx = cdef_dx(d6, k), by = cdef_dy(d6, k);
+    int s0 = cdef_fetch(p, stride, x + ax, y + ay, w, h), s1 = cdef_fetch(p, stride, x - ax, y - ay, w, h);
+    int s2 = cdef_fetch(p, stride, x + bx, y + by, w, h), s3 = cdef_fetch(p, stride, x - bx, y - by, w, h);
+    if (s0 != kCdefVeryLarge) mx = tmax(s0, mx);
+    if (s1 != kCdefVeryLarge) mx = tmax(s1, mx);
+    if (s2 != kCdefVeryLarge) mx = tmax(s2, mx);
+    if (s3 != kCdefVeryLarge) mx = tmax(s3, mx);
+    mn = tmin(s0, mn); mn = tmin(s1, mn); mn = tmin(s2, mn); mn = tmin(s3, mn);
+    sum = (int16_t)(sum + st * cdef_constrain(s0 - X, sec, sec_damp));
+    sum = (int16_t)(sum + st * cdef_constrain(s1 - X, sec, sec_damp));
+    sum = (int16_t)(sum + st * cdef_constrain(s2 - X, sec, sec_damp));
+    sum = (int16_t)(sum + st * cdef_constrain(s3 - X, sec, sec_damp));
+  }
+  int yv = (int16_t)(X + ((8 + sum - (sum < 0)) >> 4));
+  yv = yv < mn ? mn : yv;   // clip(n, low, high) = min(high, max(n, low))
+  yv = yv > mx ? mx : yv;
+  return yv;
+}
+
+TK_DEV int cdef_adjust_strength(int strength, int var) {
+  const int i = (var >> 6) ? tmin(ilog2((unsigned)(var >> 6)), 12) : 0;
+  return var ? (strength * (4 + i) + 8) >> 4 : 0;
+}
+
+// cdef_find_dir (common_block.c:94-162) on an 8x8 block
+template <typename PIX> TK_DEV int cdef_find_dir(const PIX* img, int stride, int* var, int cs) {
+  int cost[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int partial[8][15];
+  for (int a = 0; a < 8; a++)
+    for (int b = 0; b < 15; b++) partial[a][b] = 0;
+  const int div_table[9] = {0, 840, 420, 280, 210, 168, 140, 120, 105};
+  for (int i = 0; i < 8; i++)
+    for (int j = 0; j < 8; j++) {
+      int x = (img[i * stride + j] >> cs) - 128;
+      partial[0][i + j] += x;
+      partial[1][i + j / 2] += x;
+      partial[2][i] += x;
+      partial[3][3 + i - j / 2] += x;
+      partial[4][7 + i - j] += x;
+      partial[5][3 - i / 2 + j] += x;
+      partial[6][j] += x;
+      partial[7][i / 2 + j] += x;
+    }
+  for (int i = 0; i < 8; i++) {
+    cost[2] += partial[2][i] * partial[2][i];
+    cost[6] += partial[6][i] * partial[6][i];
+  }
+  cost[2] *= div_table[8];
+  cost[6] *= div_table[8];
+  for (int i = 0; i < 7; i++) {
+    cost[0] += (partial[0][i] * partial[0][i] + partial[0][14 - i] * partial[0][14 - i]) * div_table[i + 1];
+    cost[4] += (partial[4][i] * partial[4][i] + partial[4][14 - i] * partial[4][14 - i]) * div_table[i + 1];
+  }
+  cost[0] += partial[0][7] * partial[0][7] * div_table[8];
+  cost[4] += partial[4][7] * partial[4][7] * div_table[8];
+  for (int i = 1; i < 8; i += 2) {
+    for (int j = 0; j < 5; j++) cost[i] += partial[i][3 + j] * partial[i][3 + j];
+    cost[i] *= div_table[8];
+    for (int j = 0; j < 3; j++)
+      cost[i] += (partial[i][j] * partial[i][j] + partial[i][10 - j] * partial[i][10 - j]) * div_table[2 * j + 2];
+  }
+  int best_cost = 0, best_dir = 0;
+  for (int i = 0; i < 8; i++)
+    if (cost[i] > best_cost) { best_cost = cost[i]; best_dir = i; }
+  *var = (best_cost - cost[(best_dir + 4) & 7]) >> 10;
+  return best_dir;
+}
+
+TK_DEV int cdef_fb_allskip(const DbCell* cells, int cs, int xoff, int yoff, int width, int height) {
+  for (int m = 0; m < 8; m++)
+    for (int n = 0; n < 8; n++) {
+      int xpos = xoff + n * 8, ypos = yoff + m * 8;
+      if (xpos < width && ypos < height && cells[(ypos / 4) * cs + xpos / 4].mode != M_SKIP) return 0;
+    }
+  return 1;
+}
+
+// ---- pass 0: per filter block flags; zero mse ------------------------------------------------
+template <typename PIX> TK_DEV void cdef_pass_flags(const CdefJob<PIX>& J, int gid, int gsize) {
+  const int nfb = J.nfb_h * J.nfb_v;
+  for (int fb = gid; fb < nfb; fb += gsize) {
+    int k = fb / J.nfb_h, l = fb - k * J.nfb_h;
+    J.fb_compact[fb] = cdef_fb_allskip(J.cells, J.cs, l * 64, k * 64, J.width, J.height) ? -1 : 0;
+    J.fb_sel[fb] = 0;
+  }
+  for (int i = gid; i < 2 * nfb * kCdefMaxStr; i += gsize) J.mse[i] = 0;
+}
+
+// ---- pass 1: direction / variance per 8x8 luma block of non-skip filter blocks -------------
+template <typename PIX> TK_DEV void cdef_pass_dir(const CdefJob<PIX>& J, int gid, int gsize) {
+  const int bw = J.width / 8, bh = J.height / 8;
+  for (int b = gid; b < bw * bh; b += gsize) {
+    int by = b / bw, bx = b - by * bw;
+    int fb = (by / 8) * J.nfb_h + bx / 8;
+    if (J.fb_compact[fb] < 0) continue;
+    int v;
+    J.dir[b] = (int8_t)cdef_find_dir(J.src.y + by * 8 * J.src.sy + bx * 8, J.src.sy, &v, J.bitdepth - 8);
+    J.var[b] = v;
+  }
+}
+
+// dist_8x8 (encode_frame.c:194-221): perceptually weighted 8x8 distortion, double arithmetic.
+template <typename PIX>
+TK_DEV unsigned long long cdef_dist8(const int* dst /*64 filtered*/, const PIX* org, int ostride, int cs) {
+  unsigned long long sum_s = 0, sum_d = 0, sum_s2 = 0, sum_d2 = 0, sum_sd = 0;
+  for (int i = 0; i < 8; i++)
+    for (int j = 0; j < 8; j++) {
+      unsigned long long s = org[i * ostride + j], d = (unsigned long long)dst[i * 8 + j];
+      sum_s += s; sum_d += d; sum_s2 += s * s; sum_d2 += d * d; sum_sd += s * d;
+    }
+  unsigned long long svar = sum_s2 - ((sum_s * sum_s + 32) >> 6);
+  unsigned long long dvar = sum_d2 - ((sum_d * sum_d + 32) >> 6);
+  double num = (double)(sum_d2 + sum_s2 - 2 * sum_sd) * .5;
+  num = num * (double)(svar + dvar + (unsigned long long)(400 << (2 * cs)));
+  double den = sqrt((double)(20000 << (4 * cs)) + (double)svar * (double)dvar);
+  return (unsigned long long)floor(.5 + num / den);
+}
+
+// ---- pass 2: mse[plane group][fb][gi] (encode_frame.c:286-378) ------------------------------
+// work item = (8x8 luma-unit block, gi); each item handles Y, U and V of its block.
+template <typename PIX> TK_DEV void cdef_pass_mse(const CdefJob<PIX>& J, int gid, int gsize) {
+  const int bw = J.width / 8, bh = J.height / 8;
+  const int total = cdef_total_strengths(J.speed);
+  const int nfb = J.nfb_h * J.nfb_v;
+  const int cs = J.bitdepth - 8;
+  for (int it = gid; it < bw * bh * total; it += gsize) {
+    int b = it / total, gi = it - b * total;
+    int by = b / bw, bx = b - by * bw;
+    int fb = (by / 8) * J.nfb_h + bx / 8;
+    if (J.fb_compact[fb] < 0) continue;
+    if (J.cells[(by * 2) * J.cs + bx * 2].mode == M_SKIP) continue;
+    const int pri = cdef_priconv(J.speed, gi / 4), sec = gi % 4;
+    // luma
+    {
+      const int adj = cdef_adjust_strength(pri, J.var[b]);
+      const int pd = adj ? tmax(ilog2((unsigned)adj), J.damping) : J.damping;
+      const int dir = pri ? J.dir[b] : 0;
+      int out[64];
+      for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 8; j++)
+          out[i * 8 + j] = cdef_filter_px(J.src.y, J.src.sy, bx * 8 + j, by * 8 + i, J.width, J.height, adj << cs, sec << cs,
+                                          dir, pd + cs, J.damping + cs, cs);
+      unsigned long long d = cdef_dist8(out, J.org.y + by * 8 * J.org.sy + bx * 8, J.org.sy, cs);
+      team_add64(&J.mse[(0 * nfb + fb) * kCdefMaxStr + gi], d);
+    }
+    // chroma (encode_frame.c:295-372 with bs = 8 for every plane): the search walks CHROMA 8x8 blocks
+    // (m, n) of the filter block but takes the skip flag and the direction from the LUMA 8x8 block
+    // with the same (m, n) - i.e. from this work item's block - and covers only the first
+    // (h+7)>>4 x (w+7)>>4 of them.  Reproduced as is (cdef_frame later filters co-located 4x4s).
+    {
+      const int fbx = bx / 8, fby = by / 8, n = bx & 7, m = by & 7;
+      int h = tmin(J.height, (fby + 1) << 6) & 63, w = tmin(J.width, (fbx + 1) << 6) & 63;
+      h += (!h) << 6;
+      w += (!w) << 6;
+      if (m < ((h + 7) >> 4) && n < ((w + 7) >> 4)) {
+        const int cx = fbx * 32 + n * 8, cy = fby * 32 + m * 8;
+        const int sizex = tmin(J.width / 2 - cx, 8), sizey = tmin(J.height / 2 - cy, 8);
+        const int pd = pri ? tmax(ilog2((unsigned)pri), J.damping - 1) : J.damping - 1;
+        const int dir = pri ? J.dir[b] : 0;
+        unsigned long long sse = 0;
+        for (int pl = 0; pl < 2; pl++) {
+          const PIX* s = pl ? J.src.v : J.src.u;
+          const PIX* o = pl ? J.org.v : J.org.u;
+          for (int i = 0; i < sizey; i++)
+            for (int j = 0; j < sizex; j++) {
+              int v = cdef_filter_px(s, J.src.sc, cx + j, cy + i, J.width / 2, J.height / 2, pri << cs, sec << cs, dir,
+                                     pd + cs, J.damping - 1 + cs, cs);
+              int e = v - (int)o[(cy + i) * J.org.sc + cx + j];
+              sse += (unsigned long long)(long long)(e * e);
+            }
+        }
+        team_add64(&J.mse[(1 * nfb + fb) * kCdefMaxStr + gi], sse);
+      }
+    }
+  }
+}
+
+// ---- pass 3: joint luma+chroma strength selection (single team) ------------------------------
+// search_one_dual / joint_strength_search_dual (encode_frame.c:86-192) + the sort / dedupe /
+// per-block assignment tail of cdef_search (:380-470).
+template <typename PIX> TK_DEV void cdef_pass_select(const Team& t, const CdefJob<PIX>& J) {
+  const int nfb = J.nfb_h * J.nfb_v;
+  const int total = cdef_total_strengths(J.speed);
+  CdefResult* R = J.res;
+  // compact list of non-skip filter blocks, raster order
+  if (t.rank == 0) {
+    int n = 0;
+    for (int fb = 0; fb < nfb; fb++)
+      if (J.fb_compact[fb] >= 0) J.fb_compact[fb] = n++;
+    R->sb_count = n;
+  }
+  t.sync();
+  const int sbc = R->sb_count;
+  const unsigned long long* mse0 = J.mse;
+  const unsigned long long* mse1 = J.mse + (size_t)nfb * kCdefMaxStr;
+  if (J.cdef_bits == 0) {
+    // fixed strengths guessed from the frame QP (encode_frame.c:260-281); no per-block signalling
+    if (t.rank == 0) {
+      const int pri = tmax(0, (J.qp - 24) / 3), sec = J.qp < 32 && J.qp > 16;
+      R->strengths[0] = R->uv_strengths[0] = (pri << 2) + sec;
+      R->nb_bits = 0;
+    }
+    t.sync();
+    return;
+  }
+  const int nb_strengths = 1 << J.cdef_bits;
+  int* lev0 = R->level_tab[0];
+  int* lev1 = R->level_tab[1];
+  // greedy + refinement: sequence of search_one_dual calls
+  const int ncalls = nb_strengths + 4 * nb_strengths;
+  for (int call = 0; call < ncalls; call++) {
+    int nsel;
+    if (call < nb_strengths) nsel = call;
+    else {
+      t.sync();
+      if (t.rank == 0)
+        for (int j = 0; j < nb_strengths - 1; j++) { lev0[j] = lev0[j + 1]; lev1[j] = lev1[j + 1]; }
+      nsel = nb_strengths - 1;
+    }
+    t.sync();
+    for (int jk = t.rank; jk < total * total; jk += t.size) {
+      const int j = jk / total, k = jk - j * total;
+      unsigned long long acc = 0;
+      for (int fb = 0; fb < nfb; fb++) {
+        if (J.fb_compact[fb] < 0) continue;
+        const unsigned long long* m0 = mse0 + (size_t)fb * kCdefMaxStr;
+        const unsigned long long* m1 = mse1 + (size_t)fb * kCdefMaxStr;
+        unsigned long long best = 1ull << 63;
+        for (int g = 0; g < nsel; g++) {
+          unsigned long long c = m0[lev0[g]] + m1[lev1[g]];
+          if (c < best) best = c;
+        }
+        unsigned long long c = m0[j] + m1[k];
+        acc += c < best ? c : best;
+      }
+      J.tot[jk] = acc;
+    }
+    t.sync();
+    if (t.rank == 0) {
+      unsigned long long bt = 1ull << 63;
+      int b0 = 0, b1 = 0;
+      for (int j = 0; j < total; j++)
+        for (int k = 0; k < total; k++)
+          if (J.tot[j * total + k] < bt) { bt = J.tot[j * total + k]; b0 = j; b1 = k; }
+      lev0[nsel] = b0;
+      lev1[nsel] = b1;
+    }
+    t.sync();
+  }
+  if (t.rank == 0) {
+    int nb_bits = J.cdef_bits;
+    int strengths[8], uvs[8];
+    for (int j = 0; j < (1 << nb_bits); j++) { strengths[j] = lev0[j]; uvs[j] = lev1[j]; }
+    // sort + remove duplicates (qsort on unique keys => any correct ascending sort)
+    unsigned list[8];
+    int gi_trans[8];
+    const int n = 1 << nb_bits;
+    for (int i = 0; i < n; i++) list[i] = ((unsigned)strengths[i] << 16) + ((unsigned)uvs[i] << 8) + (unsigned)i;
+    for (int i = 1; i < n; i++) {
+      unsigned v = list[i];
+      int q = i - 1;
+      while (q >= 0 && list[q] > v) { list[q + 1] = list[q]; q--; }
+      list[q + 1] = v;
+    }
+    int j = 0;
+    for (int i = 0; i < n; i++) {
+      gi_trans[list[i] & 255] = j;
+      if (!i || (list[i] & ~255u) != (list[i - 1] & ~255u)) {
+        strengths[j] = (int)(list[i] >> 16);
+        uvs[j++] = (int)((list[i] >> 8) & 255);
+      }
+    }
+    nb_bits = ilog2((unsigned)j);
+    const int nbs = 1 << nb_bits;
+    for (int fb = 0; fb < nfb; fb++) {
+      if (J.fb_compact[fb] < 0) continue;
+      const unsigned long long* m0 = mse0 + (size_t)fb * kCdefMaxStr;
+      const unsigned long long* m1 = mse1 + (size_t)fb * kCdefMaxStr;
+      unsigned long long best = 1ull << 63;
+      int best_gi = 0;
+      for (int gi = 0; gi < nbs; gi++) {
+        unsigned long long c = m0[strengths[gi_trans[gi]]] + m1[uvs[gi_trans[gi]]];
+        if (c < best) { best_gi = tmin(nbs - 1, gi_trans[gi]); best = c; }
+      }
+      J.sel[J.fb_compact[fb]] = best_gi;
+      J.fb_sel[fb] = best_gi;
+    }
+    for (int q = 0; q < nbs; q++) {
+      R->strengths[q] = cdef_priconv(J.speed, strengths[q] / 4) * 4 + (strengths[q] % 4);
+      R->uv_strengths[q] = cdef_priconv(J.speed, uvs[q] / 4) * 4 + (uvs[q] % 4);
+    }
+    R->nb_bits = nb_bits;
+    (void)sbc;
+  }
+  t.sync();
+}
+
+// ---- pass 4: apply (cdef_frame, common_frame.c:826-1003); item = 8x8 luma-unit block --------
+template <typename PIX> TK_DEV void cdef_pass_apply(const CdefJob<PIX>& J, int gid, int gsize) {
+  const int bw = J.width / 8, bh = J.height / 8;
+  const int cs = J.bitdepth - 8;
+  const CdefResult* R = J.res;
+  for (int b = gid; b < bw * bh; b += gsize) {
+    int by = b / bw, bx = b - by * bw;
+    int fb = (by / 8) * J.nfb_h + bx / 8;
+    if (J.fb_compact[fb] < 0) continue;
+    if (J.cells[(by * 2) * J.cs + bx * 2].mode == M_SKIP) continue;
+    const int preset = J.fb_sel[fb];
+    for (int pg = 0; pg < 2; pg++) {
+      const int str = pg ? R->uv_strengths[preset] : R->strengths[preset];
+      const int pri = str >> 2;
+      int sec = str & 3;
+      sec += (sec == 3);
+      const int adj = pg ? pri : cdef_adjust_strength(pri, J.var[b]);
+      const int pd = adj ? tmax(ilog2((unsigned)adj), J.damping - pg) : J.damping - pg;
+      const int sd = J.damping - pg;
+      const int dir = pri ? J.dir[b] : 0;
+      if (pg == 0) {
+        for (int i = 0; i < 8; i++)
+          for (int j = 0; j < 8; j++)
+            J.rec.y[(by * 8 + i) * J.rec.sy + bx * 8 + j] = (PIX)cdef_filter_px(
+                J.src.y, J.src.sy, bx * 8 + j, by * 8 + i, J.width, J.height, adj << cs, sec << cs, dir, pd + cs, sd + cs, cs);
+      } else {
+        for (int pl = 0; pl < 2; pl++) {
+          const PIX* s = pl ? J.src.v : J.src.u;
+          PIX* d = pl ? J.rec.v : J.rec.u;
+          for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++)
+              d[(by * 4 + i) * J.rec.sc + bx * 4 + j] = (PIX)cdef_filter_px(
+                  s, J.src.sc, bx * 4 + j, by * 4 + i, J.width / 2, J.height / 2, adj << cs, sec << cs, dir, pd + cs, sd + cs, cs);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace tk

@@ -14,6 +14,7 @@
 #include <cmath>
 #include "tk_common.h"
 #include "tk_tables.h"
+#include "tk_cdef.h"
 
 namespace tk {
 
@@ -30,6 +31,8 @@ size_t team_ws_bytes(int pix_bytes);
 template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S);
 template <typename PIX> void run_deblock(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S);
 template <typename PIX> void run_make_ref(const FrameJob<PIX>* hjobs, const Plane3<PIX>* dst, int S);
+// copies rec -> src, then runs the five CDEF passes; cjobs/hcjobs: device/host arrays of S CdefJob
+template <typename PIX> void run_cdef(const CdefJob<PIX>* cjobs, const CdefJob<PIX>* hcjobs, int S);
 }  // namespace backend
 
 // ---- parameters -------------------------------------------------------------------------
@@ -129,13 +132,16 @@ template <typename PIX> struct DevFrame {
 };
 
 template <typename PIX> struct Stream {
-  DevFrame<PIX> orig, rec;
+  DevFrame<PIX> orig, rec, tmp;
   std::vector<DevFrame<PIX>> ring;  // sliding window, ring[0] = most recent reconstruction
   DbCell* cells = nullptr;
   uint32_t* sb_bits = nullptr;
   int* sb_nbits = nullptr;
   int* sb_status = nullptr;
   uint8_t* scratch = nullptr;
+  // CDEF state
+  int8_t* cdef_dir = nullptr; int* cdef_var = nullptr; int* cdef_fbc = nullptr; unsigned long long* cdef_mse = nullptr;
+  int* cdef_sel = nullptr; int* cdef_fbsel = nullptr; CdefResult* cdef_res = nullptr; unsigned long long* cdef_tot = nullptr;
   int num_encoded = 0;
   HostBits bits;             // bits of the frame being assembled (sequence header rides on frame 0)
   std::vector<uint8_t> out;  // finished stream bytes (4-byte big-endian length + payload per frame)
@@ -149,6 +155,9 @@ template <typename PIX> class Engine {
   std::vector<Stream<PIX>> st;
   FrameJob<PIX>* d_jobs = nullptr;
   std::vector<FrameJob<PIX>> h_jobs;
+  CdefJob<PIX>* d_cjobs = nullptr;
+  std::vector<CdefJob<PIX>> h_cjobs;
+  int nfb_h = 0, nfb_v = 0;
   size_t ws_bytes = 0;
 
   void open(const SeqParams& p, int num_streams) {
@@ -160,6 +169,7 @@ template <typename PIX> class Engine {
       for (int k = 0; k < sb_rows; k++) { int l = t - 2 * k; if (l >= 0 && l < sb_cols) n++; }
       if (n > max_diag) max_diag = n;
     }
+    nfb_h = (p.width + 63) >> 6; nfb_v = (p.height + 63) >> 6;
     ring_size = (p.HQperiod > p.max_num_ref ? p.HQperiod : p.max_num_ref) + 1;
     ws_bytes = (backend::team_ws_bytes((int)sizeof(PIX)) + 255) & ~(size_t)255;
     st.resize(S);
@@ -167,6 +177,7 @@ template <typename PIX> class Engine {
     for (auto& s : st) {
       s.orig.alloc(p.width, p.height, 0);
       s.rec.alloc(p.width, p.height, 0);
+      s.tmp.alloc(p.width, p.height, 0);
       s.ring.resize(ring_size);
       for (auto& r : s.ring) r.alloc(p.width, p.height, kPadY);
       s.cells = (DbCell*)backend::dev_alloc((size_t)cw * chh * sizeof(DbCell));
@@ -175,20 +186,34 @@ template <typename PIX> class Engine {
       s.sb_nbits = (int*)backend::dev_alloc(nsb * sizeof(int));
       s.sb_status = (int*)backend::dev_alloc(nsb * sizeof(int));
       s.scratch = (uint8_t*)backend::dev_alloc(ws_bytes * max_diag);
+      const int nfb = nfb_h * nfb_v;
+      s.cdef_dir = (int8_t*)backend::dev_alloc((size_t)(p.width / 8) * (p.height / 8));
+      s.cdef_var = (int*)backend::dev_alloc((size_t)(p.width / 8) * (p.height / 8) * sizeof(int));
+      s.cdef_fbc = (int*)backend::dev_alloc(nfb * sizeof(int));
+      s.cdef_mse = (unsigned long long*)backend::dev_alloc((size_t)2 * nfb * kCdefMaxStr * 8);
+      s.cdef_sel = (int*)backend::dev_alloc(nfb * sizeof(int));
+      s.cdef_fbsel = (int*)backend::dev_alloc(nfb * sizeof(int));
+      s.cdef_res = (CdefResult*)backend::dev_alloc(sizeof(CdefResult));
+      s.cdef_tot = (unsigned long long*)backend::dev_alloc((size_t)kCdefMaxStr * kCdefMaxStr * 8);
       write_sequence_header(s.bits, sp);
     }
     d_jobs = (FrameJob<PIX>*)backend::dev_alloc(sizeof(FrameJob<PIX>) * S);
     h_jobs.resize(S);
+    d_cjobs = (CdefJob<PIX>*)backend::dev_alloc(sizeof(CdefJob<PIX>) * S);
+    h_cjobs.resize(S);
   }
   void close() {
     for (auto& s : st) {
-      s.orig.release(); s.rec.release();
+      s.orig.release(); s.rec.release(); s.tmp.release();
+      backend::dev_free(s.cdef_dir); backend::dev_free(s.cdef_var); backend::dev_free(s.cdef_fbc); backend::dev_free(s.cdef_mse);
+      backend::dev_free(s.cdef_sel); backend::dev_free(s.cdef_fbsel); backend::dev_free(s.cdef_res); backend::dev_free(s.cdef_tot);
       for (auto& r : s.ring) r.release();
       backend::dev_free(s.cells); backend::dev_free(s.sb_bits); backend::dev_free(s.sb_nbits);
       backend::dev_free(s.sb_status); backend::dev_free(s.scratch);
     }
     st.clear();
     backend::dev_free(d_jobs); d_jobs = nullptr;
+    backend::dev_free(d_cjobs); d_cjobs = nullptr;
   }
 
   // planar 4:2:0 frame in host memory -> device `orig` of stream s
@@ -300,7 +325,24 @@ template <typename PIX> class Engine {
     backend::h2d(d_jobs, h_jobs.data(), sizeof(FrameJob<PIX>) * S);
     backend::run_superblocks<PIX>(d_jobs, h_jobs.data(), S);
     if (sp.deblocking) backend::run_deblock<PIX>(d_jobs, h_jobs.data(), S);
-    // TODO CDEF (encode_frame.c:768-783)
+    // CDEF (encode_frame.c:685-689 frame-level guesses, :768-783 search + filter)
+    if (sp.cdef) {
+      for (int s = 0; s < S; s++) {
+        Stream<PIX>& q = st[s];
+        CdefJob<PIX>& C = h_cjobs[s];
+        C.rec = q.rec.p; C.src = q.tmp.p; C.org = q.orig.p;
+        C.width = sp.width; C.height = sp.height; C.bitdepth = sp.bitdepth;
+        C.cells = q.cells; C.cs = sp.width / 4; C.nfb_h = nfb_h; C.nfb_v = nfb_v;
+        C.speed = sp.cdef - 1; C.damping = 5;
+        C.cdef_bits = fp[s].frame_type == F_I ? 3 : 3 - (fp[s].qp + 4) / 16;
+        if (C.speed == 3) C.cdef_bits = 0;
+        C.qp = fp[s].qp;
+        C.dir = q.cdef_dir; C.var = q.cdef_var; C.fb_compact = q.cdef_fbc; C.mse = q.cdef_mse; C.sel = q.cdef_sel;
+        C.fb_sel = q.cdef_fbsel; C.res = q.cdef_res; C.tot = q.cdef_tot;
+      }
+      backend::h2d(d_cjobs, h_cjobs.data(), sizeof(CdefJob<PIX>) * S);
+      backend::run_cdef<PIX>(d_cjobs, h_cjobs.data(), S);
+    }
     // sliding window: the slot shifted out becomes ref[0] (encode_frame.c:826-835)
     std::vector<Plane3<PIX>> dst(S);
     for (int s = 0; s < S; s++) {
@@ -326,7 +368,12 @@ template <typename PIX> class Engine {
       for (int r = 0; r < f.num_ref; r++) b.put(6, f.ref_array[r] + 1);
       b.put(16, f.frame_num);
       CdefHeader ch;
-      write_cdef_params(b, -1, 0, ch);
+      const int cdef_pos = b.nbits;
+      if (sp.cdef) {
+        ch.bits = h_cjobs[s].cdef_bits;
+        for (int i = 0; i < 8; i++) ch.strengths[i] = ch.uv_strengths[i] = 127;
+      }
+      write_cdef_params(b, -1, sp.cdef, ch);
       backend::d2h(nb.data(), q.sb_nbits, nsb * sizeof(int));
       backend::d2h(stt.data(), q.sb_status, nsb * sizeof(int));
       for (int i = 0; i < nsb; i++) {
@@ -335,6 +382,18 @@ template <typename PIX> class Engine {
         words.resize(nw);
         backend::d2h(words.data(), q.sb_bits + (size_t)i * kSbWords, nw * 4);
         b.append_words(words.data(), nb[i]);
+      }
+      if (sp.cdef) {
+        CdefResult R;
+        backend::d2h(&R, q.cdef_res, sizeof(R));
+        if (h_cjobs[s].cdef_bits != 0 && R.nb_bits) {
+          std::vector<int> sel(R.sb_count);
+          if (R.sb_count) backend::d2h(sel.data(), q.cdef_sel, R.sb_count * sizeof(int));
+          for (int i = 0; i < R.sb_count; i++) b.put(R.nb_bits, (uint32_t)sel[i]);
+        }
+        ch.bits = R.nb_bits;
+        for (int i = 0; i < 8; i++) { ch.strengths[i] = R.strengths[i]; ch.uv_strengths[i] = R.uv_strengths[i]; }
+        write_cdef_params(b, cdef_pos, 1, ch);
       }
       // flush_all_bits framing (putbits.c:45-83)
       uint32_t nbytes = (uint32_t)b.bytes.size();
