@@ -1,0 +1,107 @@
+/* thor_hip.h - C ABI of libthor_hip.so, the MI355X (gfx950) implementation of the Thor encoder's
+ * per-block hot path.  Plain C: pointers and sizes only, no C++/torch types.
+ *
+ * Three groups of entry points:
+ *
+ *  (1) The drop-in seam.  encode_frame_lbd / encode_frame_hbd are the only symbols the reference
+ *      front end (enc/mainenc.o) imports from the hot path (enc/encode_frame.h:32-33, called at
+ *      enc/mainenc.c:548).  Linking the reference's mainenc/strings/putbits/putvlc/write_bits
+ *      objects against this library instead of encode_frame.o/encode_block.o gives a Thorenc that
+ *      runs the block path on the GPU.  They take the reference's own
+ *      encoder_info_t (enc/mainenc.h:158-184); its layout is restated in thor_abi.h.
+ *
+ *  (2) The sequence API used by bench.py / the tests: N independent closed streams (what the
+ *      reference produces with -skip c*F -n F) encoded in lock step on one GPU,
+ *      with the low-delay GOP decisions of enc/mainenc.c:261-523 made on the host.
+ *
+ *  (3) Kernel-level batch entry points for known-answer tests against the scalar reference
+ *      functions (sad_calc encode_block.c:417, get_inter_prediction_luma inter_prediction.c:117,
+ *      transform/quantize/dequantize/inverse_transform, deblock_frame_y/uv common_frame.c:47/354).
+ *
+ * Error convention: like the reference's fatalerror() (common/global.h:38-44) unrecoverable
+ * conditions (no GPU, HIP failure, bit-buffer overflow) print to stderr and abort(); the
+ * sequence API additionally returns 0 on success / non-zero on bad arguments.
+ */
+#ifndef THOR_HIP_H
+#define THOR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- (1) drop-in seam ------------------------------------------------------------------- */
+struct thor_encoder_info; /* == reference encoder_info_t, see thor_abi.h */
+void encode_frame_lbd(struct thor_encoder_info* encoder_info); /* replaces enc/encode_frame.c:637 (SAMPLE=uint8_t)  */
+void encode_frame_hbd(struct thor_encoder_info* encoder_info); /* replaces enc/encode_frame_hbd.c (SAMPLE=uint16_t) */
+
+/* ---- (2) sequence API --------------------------------------------------------------------- */
+typedef struct thor_hip_params { /* the enc_params fields this path honours (enc/mainenc.h:35-112) */
+  int width, height, qp;
+  int bitdepth, input_bitdepth;
+  float frame_rate;
+  float lambda_coeffI, lambda_coeffP;
+  float early_skip_thr;
+  int enable_tb_split, enable_pb_split, max_num_ref, HQperiod;
+  int num_reorder_pics, interp_ref;
+  int dqpP, dqpI;
+  float mqpP;
+  int intra_period, intra_rdo, encoder_speed;
+  int deblocking, cdef, clpf, use_block_contexts, enable_bipred;
+  int cfl_intra, cfl_inter;
+} thor_hip_params;
+
+typedef struct thor_hip_encoder thor_hip_encoder;
+
+/* Fill *p with the reference defaults (enc/strings.c:287-356) and then apply a Thorenc config
+ * file ("-name value" tokens, ';' comments).  cfg_path may be NULL. Returns 0 on success. */
+int thor_hip_params_from_config(thor_hip_params* p, const char* cfg_path);
+
+/* Apply one "-name value" option (same names as enc/strings.c:287-356) on top of *p. Returns 0 if known. */
+int thor_hip_params_set(thor_hip_params* p, const char* name, const char* value);
+
+int thor_hip_device_count(void);
+thor_hip_encoder* thor_hip_open(const thor_hip_params* p, int num_streams, int device);
+void thor_hip_close(thor_hip_encoder* e);
+
+/* Copy one planar 4:2:0 frame (bitdepth 8: bytes; >8: little-endian uint16) of stream `stream`
+ * into HBM staging slot `slot` (slots are allocated on demand). */
+int thor_hip_stage_frame(thor_hip_encoder* e, int stream, int slot, const void* yuv);
+/* Encode the next frame of every stream from staging slot slots[stream] (inputs already resident
+ * in HBM).  Blocks until the bits of all streams are assembled on the host. */
+int thor_hip_encode_staged(thor_hip_encoder* e, const int* slots);
+/* Convenience: stage + encode one host frame per stream (PCIe inclusive). */
+int thor_hip_encode_frame(thor_hip_encoder* e, const void* const* yuv_per_stream);
+
+/* Finished bitstream of a stream so far (sequence header + framed frames, identical to the file
+ * the reference writes with -of). The pointer stays valid until the next encode call. */
+size_t thor_hip_stream_bytes(const thor_hip_encoder* e, int stream);
+const uint8_t* thor_hip_stream_data(const thor_hip_encoder* e, int stream);
+/* Reconstruction of the most recent frame of a stream (what the reference writes with -rf). */
+int thor_hip_get_recon(thor_hip_encoder* e, int stream, void* yuv_out);
+
+/* HIP-event time (ms) and launch count of the superblock kernel accumulated since the last
+ * reset; used by bench.py for the roofline figure. */
+void thor_hip_kernel_time(thor_hip_encoder* e, double* sb_ms, long* sb_launches, double* filter_ms);
+void thor_hip_kernel_time_reset(thor_hip_encoder* e);
+
+/* ---- (3) kernel-level batch entry points (known-answer tests) ------------------------------- */
+/* SAD of `n` candidate positions: org is a compact w x h block (stride w); ref points at the
+ * frame sample co-located with the block, stride rstride; cand[2*i],cand[2*i+1] = full-pel (dx,dy).
+ * Follows sad_calc (enc/encode_block.c:417-428). out[i] = SAD. */
+int thor_hip_sad_batch(const uint8_t* org, int w, int h, const uint8_t* ref_plane, int plane_w, int plane_h,
+                       int rstride, int bx, int by, const int* cand, int n, uint32_t* out);
+/* Quarter-pel luma prediction (get_inter_prediction_luma, common/inter_prediction.c:117-181) of a
+ * w x h block at (bx,by) for `n` motion vectors (mv[2*i]=x, mv[2*i+1]=y in 1/4 pel); out: n*w*h. */
+int thor_hip_interp_luma(const uint8_t* ref_plane, int plane_w, int plane_h, int rstride, int pad, int bx, int by,
+                         int w, int h, const int16_t* mv, int n, int bipred, uint8_t* out);
+/* residual -> transform -> quantize -> dequantize -> inverse -> reconstruct of `n` size x size
+ * blocks (transform.c:245, encode_block.c:84, common_block.c:45/75, transform.c:467).
+ * org/pred/rec: n*size*size samples; coefq: n*min(size,16)^2; cbp: n flags. */
+int thor_hip_code_tu_batch(const uint8_t* org, const uint8_t* pred, int size, int qp, int coeff_type, int fast, int n,
+                           int16_t* coefq, uint8_t* rec, int* cbp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

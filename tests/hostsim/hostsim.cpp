@@ -49,7 +49,7 @@ template <typename PIX> void run_deblock(const FrameJob<PIX>* jobs, const FrameJ
   }
 }
 template <typename PIX> void run_make_ref(const FrameJob<PIX>* hjobs, const Plane3<PIX>* dst, int S) {
-  for (int s = 0; s < S; s++) make_ref_rows(hjobs[s].rec, dst[s], hjobs[s].cfg.width, hjobs[s].cfg.height, 0, 1);
+  for (int s = 0; s < S; s++) make_ref_rows(hjobs[s].rec, dst[s], hjobs[s].cfg.width, hjobs[s].cfg.height, 0, 1, 0, 1);
 }
 template <typename PIX> void run_cdef(const CdefJob<PIX>* cj, const CdefJob<PIX>*, int S) {
   Team t{0, 1};

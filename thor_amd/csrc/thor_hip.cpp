@@ -1,0 +1,379 @@
+// thor_hip.cpp - libthor_hip.so: gfx950 kernels, device backend and the C ABI (include/thor_hip.h).
+// One 64-lane wavefront (= one workgroup) encodes one 128x128 superblock; superblocks of a frame
+// run in anti-diagonal waves (SB(k,l) needs (k,l-1) and (k-1,l+1)), one
+// kernel launch per wave covering every stream.  There is NO CPU path in this library: every
+// entry point aborts if no HIP device is usable.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "tk_block.h"
+#include "tk_filters.h"
+#include "tk_cdef.h"
+#include "tk_encoder.h"
+#include "tk_cli.h"
+#include "../../include/thor_hip.h"
+
+#define HIPCHECK(x)                                                                              \
+  do {                                                                                           \
+    hipError_t e_ = (x);                                                                         \
+    if (e_ != hipSuccess) {                                                                      \
+      fprintf(stderr, "Run-time error...\nthor_hip: %s failed: %s (%s:%d)\n...now exiting to system...\n", #x, \
+              hipGetErrorString(e_), __FILE__, __LINE__);                                        \
+      abort();                                                                                   \
+    }                                                                                            \
+  } while (0)
+
+namespace tk {
+__device__ Tables g_tab;
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+template <typename PIX> __global__ __launch_bounds__(64) void k_superblocks(const FrameJob<PIX>* jobs, int tdiag) {
+  __shared__ FrameJob<PIX> sJ;
+  {
+    const uint32_t* src = (const uint32_t*)&jobs[blockIdx.y];
+    uint32_t* dst = (uint32_t*)&sJ;
+    for (int i = threadIdx.x; i < (int)(sizeof(FrameJob<PIX>) / 4); i += 64) dst[i] = src[i];
+  }
+  __syncthreads();
+  const FrameJob<PIX>& J = sJ;
+  int kmin = tdiag - (J.sb_cols - 1);
+  kmin = kmin <= 0 ? 0 : (kmin + 1) / 2;
+  const int k = kmin + (int)blockIdx.x, l = tdiag - 2 * k;
+  if (k >= J.sb_rows || l < 0 || l >= J.sb_cols) return;
+  const int sbi = k * J.sb_cols + l;
+  TeamWs<PIX>* ws = (TeamWs<PIX>*)(J.scratch + (size_t)blockIdx.x * J.scratch_bytes);
+  Team t{(int)threadIdx.x, 64};
+  BitSink out;
+  out.buf = J.sb_bits + (size_t)sbi * J.sb_words;
+  out.pos = 0;
+  out.cap = J.sb_words * 32;
+  out.emit = 1;
+  out.ovf = 0;
+  process_sb(t, J, ws, k * kMaxSb, l * kMaxSb, out);
+  if (threadIdx.x == 0) {
+    J.sb_nbits[sbi] = out.pos;
+    J.sb_status[sbi] = out.ovf;
+  }
+}
+
+template <typename PIX> __global__ void k_deblock(const FrameJob<PIX>* jobs, int pass) {
+  const FrameJob<PIX>& J = jobs[blockIdx.y];
+  DbParams P;
+  P.width = J.cfg.width; P.height = J.cfg.height; P.bitdepth = J.cfg.bitdepth;
+  const int qpc = g_tab.chroma_qp[J.qp];
+  P.beta = g_tab.beta[J.qp] << (P.bitdepth - 8);
+  P.tc_y = g_tab.tc[J.qp] >> (12 - P.bitdepth);
+  P.tc_c = g_tab.tc[qpc] >> (12 - P.bitdepth);
+  P.cells = J.cells; P.cs = J.cell_stride;
+  deblock_pass(J.rec, P, pass, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));
+}
+
+template <typename PIX> struct RefJob { Plane3<PIX> rec, ref; int width, height; };
+template <typename PIX> __global__ void k_make_ref(const RefJob<PIX>* rj) {
+  const RefJob<PIX>& R = rj[blockIdx.y];
+  make_ref_rows(R.rec, R.ref, R.width, R.height, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, (int)blockDim.x);
+}
+
+template <typename PIX> __global__ void k_copy_planes(const CdefJob<PIX>* cj) {
+  const CdefJob<PIX>& C = cj[blockIdx.y];
+  const int rows = C.height + C.height;  // Y rows + U rows + V rows
+  for (int it = blockIdx.x; it < rows; it += gridDim.x) {
+    const PIX* s; PIX* d; int w;
+    if (it < C.height) { s = C.rec.y + (size_t)it * C.rec.sy; d = C.src.y + (size_t)it * C.src.sy; w = C.width; }
+    else if (it < C.height + C.height / 2) { int r = it - C.height; s = C.rec.u + (size_t)r * C.rec.sc; d = C.src.u + (size_t)r * C.src.sc; w = C.width / 2; }
+    else { int r = it - C.height - C.height / 2; s = C.rec.v + (size_t)r * C.rec.sc; d = C.src.v + (size_t)r * C.src.sc; w = C.width / 2; }
+    for (int x = threadIdx.x; x < w; x += blockDim.x) d[x] = s[x];
+  }
+}
+template <typename PIX> __global__ void k_cdef(const CdefJob<PIX>* cj, int pass) {
+  const CdefJob<PIX>& C = cj[blockIdx.y];
+  const int gid = (int)(blockIdx.x * blockDim.x + threadIdx.x), gsize = (int)(gridDim.x * blockDim.x);
+  if (pass == 0) cdef_pass_flags(C, gid, gsize);
+  else if (pass == 1) cdef_pass_dir(C, gid, gsize);
+  else if (pass == 2) { if (C.cdef_bits) cdef_pass_mse(C, gid, gsize); }
+  else if (pass == 4) cdef_pass_apply(C, gid, gsize);
+}
+template <typename PIX> __global__ __launch_bounds__(1024) void k_cdef_select(const CdefJob<PIX>* cj) {
+  Team t{(int)threadIdx.x, (int)blockDim.x};
+  cdef_pass_select(t, cj[blockIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// backend
+// ---------------------------------------------------------------------------------------------
+static bool g_inited = false;
+static hipStream_t g_stream = nullptr;
+struct KernelClock {
+  std::vector<hipEvent_t> ev;  // pairs
+  double sb_ms = 0, filt_ms = 0;
+  long sb_launches = 0;
+};
+static KernelClock g_clk;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_sb_events, g_filt_events;
+
+static void ensure_init(int device) {
+  if (g_inited) return;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    fprintf(stderr, "Run-time error...\nthor_hip: no HIP device available - this library has no CPU path\n...now exiting to system...\n");
+    abort();
+  }
+  HIPCHECK(hipSetDevice(device < n ? device : 0));
+  HIPCHECK(hipStreamCreate(&g_stream));
+  static Tables h;
+  init_tables(&h);
+  HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tab), &h, sizeof(h)));
+  g_inited = true;
+}
+
+namespace backend {
+void* dev_alloc(size_t n) {
+  void* p = nullptr;
+  HIPCHECK(hipMalloc(&p, n ? n : 1));
+  HIPCHECK(hipMemsetAsync(p, 0, n ? n : 1, g_stream));
+  return p;
+}
+void dev_free(void* p) { if (p) HIPCHECK(hipFree(p)); }
+void h2d(void* d, const void* h, size_t n) { HIPCHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, g_stream)); HIPCHECK(hipStreamSynchronize(g_stream)); }
+void d2h(void* h, const void* d, size_t n) { HIPCHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, g_stream)); HIPCHECK(hipStreamSynchronize(g_stream)); }
+void dev_memset(void* d, int v, size_t n) { HIPCHECK(hipMemsetAsync(d, v, n, g_stream)); }
+static void harvest(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, double& acc) {
+  for (auto& p : v) {
+    float ms = 0;
+    HIPCHECK(hipEventElapsedTime(&ms, p.first, p.second));
+    acc += ms;
+    HIPCHECK(hipEventDestroy(p.first));
+    HIPCHECK(hipEventDestroy(p.second));
+  }
+  v.clear();
+}
+void dev_sync() {
+  HIPCHECK(hipStreamSynchronize(g_stream));
+  harvest(g_sb_events, g_clk.sb_ms);
+  harvest(g_filt_events, g_clk.filt_ms);
+}
+size_t team_ws_bytes(int pix_bytes) { return pix_bytes == 1 ? sizeof(TeamWs<uint8_t>) : sizeof(TeamWs<uint16_t>); }
+
+static std::pair<hipEvent_t, hipEvent_t> ev_begin() {
+  std::pair<hipEvent_t, hipEvent_t> p;
+  HIPCHECK(hipEventCreate(&p.first));
+  HIPCHECK(hipEventCreate(&p.second));
+  HIPCHECK(hipEventRecord(p.first, g_stream));
+  return p;
+}
+
+template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S) {
+  const int cols = hjobs[0].sb_cols, rows = hjobs[0].sb_rows;
+  auto ev = ev_begin();
+  for (int t = 0; t <= (cols - 1) + 2 * (rows - 1); t++) {
+    int n = 0;
+    for (int k = 0; k < rows; k++) { int l = t - 2 * k; if (l >= 0 && l < cols) n++; }
+    if (!n) continue;
+    hipLaunchKernelGGL(k_superblocks<PIX>, dim3(n, S), dim3(64), 0, g_stream, jobs, t);
+    g_clk.sb_launches++;
+  }
+  HIPCHECK(hipEventRecord(ev.second, g_stream));
+  g_sb_events.push_back(ev);
+  HIPCHECK(hipGetLastError());
+}
+template <typename PIX> void run_deblock(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S) {
+  const int items = (hjobs[0].cfg.width / 8) * (hjobs[0].cfg.height / 8);
+  auto ev = ev_begin();
+  for (int pass = 0; pass < 4; pass++)
+    hipLaunchKernelGGL(k_deblock<PIX>, dim3((items + 63) / 64, S), dim3(64), 0, g_stream, jobs, pass);
+  HIPCHECK(hipEventRecord(ev.second, g_stream));
+  g_filt_events.push_back(ev);
+  HIPCHECK(hipGetLastError());
+}
+template <typename PIX> void run_make_ref(const FrameJob<PIX>* hjobs, const Plane3<PIX>* dst, int S) {
+  static RefJob<PIX>* d_rj = nullptr;
+  static int cap = 0;
+  std::vector<RefJob<PIX>> h(S);
+  for (int s = 0; s < S; s++) { h[s].rec = hjobs[s].rec; h[s].ref = dst[s]; h[s].width = hjobs[s].cfg.width; h[s].height = hjobs[s].cfg.height; }
+  if (cap < S) { if (d_rj) HIPCHECK(hipFree(d_rj)); HIPCHECK(hipMalloc(&d_rj, sizeof(RefJob<PIX>) * S)); cap = S; }
+  HIPCHECK(hipMemcpyAsync(d_rj, h.data(), sizeof(RefJob<PIX>) * S, hipMemcpyHostToDevice, g_stream));
+  HIPCHECK(hipStreamSynchronize(g_stream));  // h goes out of scope
+  const int rows = hjobs[0].cfg.height * 2 + 4 * kPadY;
+  auto ev = ev_begin();
+  hipLaunchKernelGGL(k_make_ref<PIX>, dim3(rows, S), dim3(256), 0, g_stream, d_rj);
+  HIPCHECK(hipEventRecord(ev.second, g_stream));
+  g_filt_events.push_back(ev);
+  HIPCHECK(hipGetLastError());
+}
+template <typename PIX> void run_cdef(const CdefJob<PIX>* cj, const CdefJob<PIX>* hcj, int S) {
+  const int blocks8 = (hcj[0].width / 8) * (hcj[0].height / 8);
+  const int total = cdef_total_strengths(hcj[0].speed);
+  auto ev = ev_begin();
+  hipLaunchKernelGGL(k_copy_planes<PIX>, dim3(hcj[0].height * 2, S), dim3(256), 0, g_stream, cj);
+  hipLaunchKernelGGL(k_cdef<PIX>, dim3(64, S), dim3(256), 0, g_stream, cj, 0);
+  hipLaunchKernelGGL(k_cdef<PIX>, dim3((blocks8 + 63) / 64, S), dim3(64), 0, g_stream, cj, 1);
+  hipLaunchKernelGGL(k_cdef<PIX>, dim3((blocks8 * total + 63) / 64, S), dim3(64), 0, g_stream, cj, 2);
+  hipLaunchKernelGGL(k_cdef_select<PIX>, dim3(S), dim3(1024), 0, g_stream, cj);
+  hipLaunchKernelGGL(k_cdef<PIX>, dim3((blocks8 + 63) / 64, S), dim3(64), 0, g_stream, cj, 4);
+  HIPCHECK(hipEventRecord(ev.second, g_stream));
+  g_filt_events.push_back(ev);
+  HIPCHECK(hipGetLastError());
+}
+template void run_superblocks<uint8_t>(const FrameJob<uint8_t>*, const FrameJob<uint8_t>*, int);
+template void run_deblock<uint8_t>(const FrameJob<uint8_t>*, const FrameJob<uint8_t>*, int);
+template void run_make_ref<uint8_t>(const FrameJob<uint8_t>*, const Plane3<uint8_t>*, int);
+template void run_cdef<uint8_t>(const CdefJob<uint8_t>*, const CdefJob<uint8_t>*, int);
+}  // namespace backend
+}  // namespace tk
+
+// ---------------------------------------------------------------------------------------------
+// C ABI - sequence API
+// ---------------------------------------------------------------------------------------------
+using namespace tk;
+
+struct thor_hip_encoder {
+  Engine<uint8_t> eng;
+  SeqParams sp;
+  int S = 0;
+  std::vector<std::vector<DevFrame<uint8_t>>> staged;  // [stream][slot]
+  std::vector<uint8_t> rec_host;
+};
+
+static SeqParams to_seq(const thor_hip_params& p) {
+  SeqParams s;
+  s.width = p.width; s.height = p.height; s.qp = p.qp; s.bitdepth = p.bitdepth; s.input_bitdepth = p.input_bitdepth;
+  s.frame_rate = p.frame_rate; s.lambda_coeffI = p.lambda_coeffI; s.lambda_coeffP = p.lambda_coeffP;
+  s.early_skip_thr = p.early_skip_thr; s.enable_tb_split = p.enable_tb_split; s.enable_pb_split = p.enable_pb_split;
+  s.max_num_ref = p.max_num_ref; s.HQperiod = p.HQperiod; s.num_reorder_pics = p.num_reorder_pics; s.interp_ref = p.interp_ref;
+  s.dqpP = p.dqpP; s.dqpI = p.dqpI; s.mqpP = p.mqpP; s.intra_period = p.intra_period; s.intra_rdo = p.intra_rdo;
+  s.encoder_speed = p.encoder_speed; s.deblocking = p.deblocking; s.cdef = p.cdef; s.clpf = p.clpf;
+  s.use_block_contexts = p.use_block_contexts; s.enable_bipred = p.enable_bipred; s.cfl_intra = p.cfl_intra; s.cfl_inter = p.cfl_inter;
+  return s;
+}
+static void from_seq(thor_hip_params* p, const SeqParams& s) {
+  p->width = s.width; p->height = s.height; p->qp = s.qp; p->bitdepth = s.bitdepth; p->input_bitdepth = s.input_bitdepth;
+  p->frame_rate = s.frame_rate; p->lambda_coeffI = s.lambda_coeffI; p->lambda_coeffP = s.lambda_coeffP;
+  p->early_skip_thr = s.early_skip_thr; p->enable_tb_split = s.enable_tb_split; p->enable_pb_split = s.enable_pb_split;
+  p->max_num_ref = s.max_num_ref; p->HQperiod = s.HQperiod; p->num_reorder_pics = s.num_reorder_pics; p->interp_ref = s.interp_ref;
+  p->dqpP = s.dqpP; p->dqpI = s.dqpI; p->mqpP = s.mqpP; p->intra_period = s.intra_period; p->intra_rdo = s.intra_rdo;
+  p->encoder_speed = s.encoder_speed; p->deblocking = s.deblocking; p->cdef = s.cdef; p->clpf = s.clpf;
+  p->use_block_contexts = s.use_block_contexts; p->enable_bipred = s.enable_bipred; p->cfl_intra = s.cfl_intra; p->cfl_inter = s.cfl_inter;
+}
+
+static int unsupported(const SeqParams& s) {
+  // This path implements the high-efficiency low-delay operating point family; reject the rest
+  // loudly rather than silently producing a different stream.
+  if (s.bitdepth != 8 || s.input_bitdepth != 8) return fprintf(stderr, "thor_hip: only 8-bit is implemented in this round\n"), 1;
+  if (s.num_reorder_pics != 0 || s.interp_ref != 0) return fprintf(stderr, "thor_hip: B frames / interpolated refs not implemented in this round\n"), 1;
+  if (s.encoder_speed != 0) return fprintf(stderr, "thor_hip: encoder_speed > 0 not implemented\n"), 1;
+  if (s.clpf != 0) return fprintf(stderr, "thor_hip: CLPF not implemented\n"), 1;
+  if (s.width % 8 || s.height % 8 || s.width < 16 || s.height < 16) return fprintf(stderr, "thor_hip: bad geometry\n"), 1;
+  if (s.max_num_ref < 1 || s.max_num_ref > 4) return fprintf(stderr, "thor_hip: max_num_ref out of range\n"), 1;
+  return 0;
+}
+
+extern "C" {
+
+int thor_hip_params_from_config(thor_hip_params* p, const char* cfg_path) {
+  CliArgs a;
+  a.sp.width = 1920; a.sp.height = 1080; a.sp.frame_rate = 60.f;  // enc/strings.c defaults
+  if (cfg_path) {
+    std::vector<std::string> t = {"-cf", cfg_path};
+    cli_apply(a, t);
+  }
+  from_seq(p, a.sp);
+  return 0;
+}
+
+int thor_hip_params_set(thor_hip_params* p, const char* name, const char* value) {
+  if (!p || !name || !value) return 1;
+  CliArgs a;
+  a.sp = to_seq(*p);
+  std::vector<std::string> t = {name, value};
+  cli_apply(a, t);
+  from_seq(p, a.sp);
+  return 0;
+}
+
+int thor_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+thor_hip_encoder* thor_hip_open(const thor_hip_params* p, int num_streams, int device) {
+  if (!p || num_streams < 1) return nullptr;
+  SeqParams s = to_seq(*p);
+  if (unsupported(s)) return nullptr;
+  ensure_init(device);
+  thor_hip_encoder* e = new thor_hip_encoder;
+  e->sp = s;
+  e->S = num_streams;
+  e->eng.open(s, num_streams);
+  e->staged.resize(num_streams);
+  return e;
+}
+
+void thor_hip_close(thor_hip_encoder* e) {
+  if (!e) return;
+  for (auto& v : e->staged)
+    for (auto& f : v)
+      if (f.base_y) f.release();
+  e->eng.close();
+  delete e;
+}
+
+int thor_hip_stage_frame(thor_hip_encoder* e, int stream, int slot, const void* yuv) {
+  if (!e || stream < 0 || stream >= e->S || slot < 0 || !yuv) return 1;
+  auto& v = e->staged[stream];
+  if ((int)v.size() <= slot) v.resize(slot + 1);
+  if (!v[slot].base_y) v[slot].alloc(e->sp.width, e->sp.height, 0);
+  DevFrame<uint8_t> keep = e->eng.st[stream].orig;
+  e->eng.st[stream].orig = v[slot];
+  e->eng.upload_orig(stream, (const uint8_t*)yuv);
+  e->eng.st[stream].orig = keep;
+  return 0;
+}
+
+int thor_hip_encode_staged(thor_hip_encoder* e, const int* slots) {
+  if (!e || !slots) return 1;
+  std::vector<DevFrame<uint8_t>> keep(e->S);
+  std::vector<FrameParams> fp(e->S);
+  for (int s = 0; s < e->S; s++) {
+    if (slots[s] < 0 || slots[s] >= (int)e->staged[s].size() || !e->staged[s][slots[s]].base_y) return 2;
+    keep[s] = e->eng.st[s].orig;
+    e->eng.st[s].orig = e->staged[s][slots[s]];
+    fp[s] = e->eng.next_frame_params(s);
+  }
+  e->eng.encode_frames(fp);
+  for (int s = 0; s < e->S; s++) e->eng.st[s].orig = keep[s];
+  return 0;
+}
+
+int thor_hip_encode_frame(thor_hip_encoder* e, const void* const* yuv) {
+  if (!e || !yuv) return 1;
+  std::vector<FrameParams> fp(e->S);
+  for (int s = 0; s < e->S; s++) {
+    e->eng.upload_orig(s, (const uint8_t*)yuv[s]);
+    fp[s] = e->eng.next_frame_params(s);
+  }
+  e->eng.encode_frames(fp);
+  return 0;
+}
+
+size_t thor_hip_stream_bytes(const thor_hip_encoder* e, int stream) { return e->eng.st[stream].out.size(); }
+const uint8_t* thor_hip_stream_data(const thor_hip_encoder* e, int stream) { return e->eng.st[stream].out.data(); }
+int thor_hip_get_recon(thor_hip_encoder* e, int stream, void* yuv_out) {
+  if (!e || stream < 0 || stream >= e->S || !yuv_out) return 1;
+  e->eng.download_rec(stream, (uint8_t*)yuv_out);
+  return 0;
+}
+void thor_hip_kernel_time(thor_hip_encoder*, double* sb_ms, long* sb_launches, double* filter_ms) {
+  if (sb_ms) *sb_ms = g_clk.sb_ms;
+  if (sb_launches) *sb_launches = g_clk.sb_launches;
+  if (filter_ms) *filter_ms = g_clk.filt_ms;
+}
+void thor_hip_kernel_time_reset(thor_hip_encoder*) { g_clk.sb_ms = g_clk.filt_ms = 0; g_clk.sb_launches = 0; }
+
+}  // extern "C"

@@ -98,7 +98,7 @@ TK_DEV void bs_mv(BitSink& b, mv_t mv, mv_t mvp) {
 
 // write_coeff (enc/write_bits.c:145-241). coeff: qsize x qsize row-major (qsize=min(size,16)),
 // type bit0 = chroma, bit1 = intra block.
-TK_DEV void bs_coeff(BitSink& b, const int16_t* coeff, int size, int type) {
+TK_DEVNI void bs_coeff(BitSink& b, const int16_t* coeff, int size, int type) {
   const int qsize = size < kMaxQuant ? size : kMaxQuant;
   const int N = qsize * qsize;
   const int16_t* izz = qsize == 4 ? TK_TAB.izz4 : (qsize == 8 ? TK_TAB.izz8 : TK_TAB.izz16);
@@ -215,7 +215,7 @@ TK_DEV int cbp_code(int cbp) {  // cbp_table (enc/write_bits.c:382)
 
 // write_block (enc/write_bits.c:360-600).  cy/cu/cv: quantised coefficients, TU t of a
 // tb-split block at offset t*256 (MAX_QUANT_SIZE^2) like the reference.
-TK_DEV int bs_block(BitSink& b, const SynCtx& s, const BlkParam& p, const int16_t* cy, const int16_t* cu,
+TK_DEVNI int bs_block(BitSink& b, const SynCtx& s, const BlkParam& p, const int16_t* cy, const int16_t* cu,
                     const int16_t* cv) {
   const int start = b.pos;
   const int size = s.size, size_uv = size >> 1;

@@ -165,7 +165,7 @@ TK_DEV void ssd_acc(const Team& t, unsigned long long* acc, const PIX* a, int as
 
 // cost_calc (encode_block.c:916-926) on the trial recon in ws->rec_* vs. the original frame.
 template <typename PIX>
-TK_DEV unsigned rd_cost(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int nbits, double lambda) {
+TK_DEVNI unsigned rd_cost(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int nbits, double lambda) {
   if (t.rank == 0) ws->acc[0] = 0;
   t.sync();
   const int yc = nd.ypos >> 1, xc = nd.xpos >> 1, sc = nd.size >> 1;
@@ -185,7 +185,7 @@ TK_DEV unsigned rd_cost(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, 
 // prediction (stride cstride>>1), ry: reconstructed luma (stride `stride`), n = luma size.
 // ---------------------------------------------------------------------------------
 template <typename PIX>
-TK_DEV void improve_uv(const Team& t, TeamWs<PIX>* ws, const PIX* y, PIX* u, PIX* v, const PIX* ry, int n, int cstride,
+TK_DEVNI void improve_uv(const Team& t, TeamWs<PIX>* ws, const PIX* y, PIX* u, PIX* v, const PIX* ry, int n, int cstride,
                        int stride, int bitdepth) {
   const int nc = n >> 1, lognc = ilog2(nc), cs = cstride >> 1;
   for (int k = t.rank; k < 9; k += t.size) ws->acc[k] = 0;
@@ -296,7 +296,7 @@ TK_DEV int code_inter_plane(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* 
 }
 
 template <typename PIX>
-TK_DEV int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BlkParam& p, BitSink& bs) {
+TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BlkParam& p, BitSink& bs) {
   const EncCfg& c = J.cfg;
   const int size = nd.size, sizeC = size >> 1;
   const int yc = nd.ypos >> 1, xc = nd.xpos >> 1;
@@ -480,7 +480,7 @@ template <typename PIX> TK_DEV void add_cands4(const Team& t, TeamWs<PIX>* ws, i
 
 // search_bipred_prediction_params, me_mode 0 (encode_block.c:1739-1832) - P and B frames.
 template <typename PIX>
-TK_DEV void search_bipred(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int part,
+TK_DEVNI void search_bipred(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int part,
                           const mv_t* mv_center, mv_t mvp, int* ref_idx0, int* ref_idx1, mv_t* mv_arr0, mv_t* mv_arr1) {
   const EncCfg& c = J.cfg;
   const int size = nd.size;
@@ -531,7 +531,7 @@ TK_DEV void search_bipred(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
 // mode_decision_rdo (encode_block.c:1835-2121).  Result in nd.best; returns min cost.
 // ---------------------------------------------------------------------------------
 template <typename PIX>
-TK_DEV unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd) {
+TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd) {
   const EncCfg& c = J.cfg;
   const int size = nd.size;
   const double lambda = J.lambda;
@@ -699,7 +699,7 @@ TK_DEV int early_skip_subC(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* w
 }
 
 template <typename PIX>
-TK_DEV int check_early_skip(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, const BlkParam& p) {
+TK_DEVNI int check_early_skip(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, const BlkParam& p) {
   const EncCfg& c = J.cfg;
   const int size = nd.size, size0 = size < 32 ? size : 32;
   const int qpY = J.qp, qpC = TK_TAB.chroma_qp[qpY];
@@ -737,7 +737,7 @@ TK_DEV int check_early_skip(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* 
 // Final encode of a CB: recompute (encode_block final), write recon + cell state, emit bits.
 // ---------------------------------------------------------------------------------
 template <typename PIX>
-TK_DEV int final_encode(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BitSink& out) {
+TK_DEVNI int final_encode(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BitSink& out) {
   BlkParam p = nd.best;
   BitSink cnt;
   cnt.buf = nullptr; cnt.pos = 0; cnt.cap = 0; cnt.emit = 0; cnt.ovf = 0;

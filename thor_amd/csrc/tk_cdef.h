@@ -49,7 +49,7 @@ TK_DEV int cdef_priconv(int speed, int i) {
   const int t[4] = {0, 1, 3, 6};
   return t[i & 3];
 }
-TK_DEV int cdef_total_strengths(int speed) { return speed == 0 ? 64 : (speed == 1 ? 32 : 16); }
+TK_HD int cdef_total_strengths(int speed) { return speed == 0 ? 64 : (speed == 1 ? 32 : 16); }
 
 TK_DEV int cdef_dx(int d, int k) {
   const int8_t t[8][2] = {{1, 2}, {1, 2}, {1, 2}, {1, 2}, {1, 2}, {0, 1}, {0, 0}, {0, -1}};

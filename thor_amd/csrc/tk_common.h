@@ -18,11 +18,13 @@
 #include <string.h>
 #include <stdlib.h>
 #define TK_DEV static inline
+#define TK_HD static inline
 #define TK_CONST static const
 #define TK_HOST 1
 #else
 #include <hip/hip_runtime.h>
 #define TK_DEV __device__ __forceinline__
+#define TK_HD __host__ __device__ __forceinline__
 #define TK_DEVNI __device__ __noinline__
 #define TK_CONST __device__ const
 #define TK_HOST 0

@@ -106,9 +106,10 @@ TK_DEV void deblock_pass(const Plane3<PIX>& rec, const DbParams& P, int pass, in
 }
 
 // create_reference_frame: copy + replicate-pad (pad luma 160, chroma 80).
-// One work item per padded row; item ids cover Y then U then V.
+// One work item per padded row (Y rows, then U, then V); `lane`/`nlanes` stride along the row.
 template <typename PIX>
-TK_DEV void make_ref_rows(const Plane3<PIX>& rec, const Plane3<PIX>& ref, int width, int height, int gid, int gsize) {
+TK_DEV void make_ref_rows(const Plane3<PIX>& rec, const Plane3<PIX>& ref, int width, int height, int gid, int gsize,
+                          int lane, int nlanes) {
   const int py = kPadY, pc = kPadY / 2;
   const int hy = height + 2 * py, hc = height / 2 + 2 * pc;
   const int total = hy + 2 * hc;
@@ -122,7 +123,7 @@ TK_DEV void make_ref_rows(const Plane3<PIX>& rec, const Plane3<PIX>& ref, int wi
     const int sr = clampi(row, 0, h - 1);
     const PIX* s = src + sr * ss;
     PIX* d = dst + row * ds;
-    for (int x = -pad; x < w + pad; x++) d[x] = s[clampi(x, 0, w - 1)];
+    for (int x = -pad + lane; x < w + pad; x += nlanes) d[x] = s[clampi(x, 0, w - 1)];
   }
 }
 

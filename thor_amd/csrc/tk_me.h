@@ -93,7 +93,7 @@ TK_DEV void pick_best(const MeWs* w, int n, unsigned& min_sad, mv_t& mv_opt, int
 }
 
 template <typename PIX>
-TK_DEV unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const PIX* ref, const MeArgs& a, mv_t mvc,
+TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const PIX* ref, const MeArgs& a, mv_t mvc,
                                 mv_t mvp, int ref_idx, mv_t* mv_out) {
   const int s = a.sign ? -1 : 1;
   const int sh = a.bitdepth - 8;

@@ -198,7 +198,7 @@ TK_DEV void copy_block(const Team& t, PIX* dst, int dstride, const PIX* src, int
 // One transform unit: residual -> T -> Q -> (IQ -> IT -> recon | recon = pred). Returns cbp bit.
 // coeff_type: bit0 chroma, bit1 = (frame_type == I) [sic: frame type, Appendix B.6].
 template <typename PIX>
-TK_DEV int code_tu(const Team& t, XformWs* ws, const PIX* org, int ostride, const PIX* pred, int pstride, PIX* rec,
+TK_DEVNI int code_tu(const Team& t, XformWs* ws, const PIX* org, int ostride, const PIX* pred, int pstride, PIX* rec,
                    int rstride, int size, int qp, int coeff_type, int fast, int16_t* coefq, int bitdepth) {
   fwd_transform(t, ws, org, ostride, pred, pstride, size, fast, bitdepth);
   int cbp = quantize_team(t, ws, coefq, qp, size, (coeff_type >> 1) & 1);
