@@ -17,7 +17,9 @@ void h2d(void* d, const void* h, size_t n) { memcpy(d, h, n); }
 void d2h(void* h, const void* d, size_t n) { memcpy(h, d, n); }
 void dev_memset(void* d, int v, size_t n) { memset(d, v, n); }
 void dev_sync() {}
-size_t team_ws_bytes(int pix_bytes) { return pix_bytes == 1 ? sizeof(TeamWs<uint8_t>) : sizeof(TeamWs<uint16_t>); }
+size_t team_ws_bytes(int pix_bytes) {
+  return pix_bytes == 1 ? sizeof(BigWs<uint8_t>) + sizeof(SmallWs<uint8_t>) : sizeof(BigWs<uint16_t>) + sizeof(SmallWs<uint16_t>);
+}
 
 template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>*, int S) {
   Team t{0, 1};
@@ -26,7 +28,8 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
     for (int k = 0; k < J.sb_rows; k++)
       for (int l = 0; l < J.sb_cols; l++) {
         const int sbi = k * J.sb_cols + l;
-        TeamWs<PIX>* ws = (TeamWs<PIX>*)J.scratch;
+        TeamWs<PIX> wsv = make_ws((SmallWs<PIX>*)(J.scratch + sizeof(BigWs<PIX>)), (BigWs<PIX>*)J.scratch);
+        TeamWs<PIX>* ws = &wsv;
         BitSink out;
         out.buf = J.sb_bits + (size_t)sbi * J.sb_words; out.pos = 0; out.cap = J.sb_words * 32; out.emit = 1; out.ovf = 0;
         process_sb(t, J, ws, k * kMaxSb, l * kMaxSb, out);

@@ -47,8 +47,12 @@ template <typename PIX> __global__ __launch_bounds__(64) void k_superblocks(cons
   const int k = kmin + (int)blockIdx.x, l = tdiag - 2 * k;
   if (k >= J.sb_rows || l < 0 || l >= J.sb_cols) return;
   const int sbi = k * J.sb_cols + l;
-  TeamWs<PIX>* ws = (TeamWs<PIX>*)(J.scratch + (size_t)blockIdx.x * J.scratch_bytes);
+  __shared__ SmallWs<PIX> sws;
+  TeamWs<PIX> wsv = make_ws(&sws, (BigWs<PIX>*)(J.scratch + (size_t)blockIdx.x * J.scratch_bytes));
+  TeamWs<PIX>* ws = &wsv;
   Team t{(int)threadIdx.x, 64};
+  if (threadIdx.x < kProfSlots) sws.prof[threadIdx.x] = 0;
+  __syncthreads();
   BitSink out;
   out.buf = J.sb_bits + (size_t)sbi * J.sb_words;
   out.pos = 0;
@@ -60,6 +64,10 @@ template <typename PIX> __global__ __launch_bounds__(64) void k_superblocks(cons
     J.sb_nbits[sbi] = out.pos;
     J.sb_status[sbi] = out.ovf;
   }
+#ifdef THOR_PROF
+  __syncthreads();
+  if (J.prof && threadIdx.x < kProfSlots) atomicAdd((unsigned long long*)&J.prof[threadIdx.x], (unsigned long long)sws.prof[threadIdx.x]);
+#endif
 }
 
 template <typename PIX> __global__ void k_deblock(const FrameJob<PIX>* jobs, int pass) {
@@ -158,7 +166,7 @@ void dev_sync() {
   harvest(g_sb_events, g_clk.sb_ms);
   harvest(g_filt_events, g_clk.filt_ms);
 }
-size_t team_ws_bytes(int pix_bytes) { return pix_bytes == 1 ? sizeof(TeamWs<uint8_t>) : sizeof(TeamWs<uint16_t>); }
+size_t team_ws_bytes(int pix_bytes) { return pix_bytes == 1 ? sizeof(BigWs<uint8_t>) : sizeof(BigWs<uint16_t>); }
 
 static std::pair<hipEvent_t, hipEvent_t> ev_begin() {
   std::pair<hipEvent_t, hipEvent_t> p;
@@ -374,6 +382,7 @@ void thor_hip_kernel_time(thor_hip_encoder*, double* sb_ms, long* sb_launches, d
   if (sb_launches) *sb_launches = g_clk.sb_launches;
   if (filter_ms) *filter_ms = g_clk.filt_ms;
 }
+void thor_hip_read_prof(thor_hip_encoder* e, long long out[16]) { backend::d2h(out, e->eng.d_prof, 16 * sizeof(long long)); }
 void thor_hip_kernel_time_reset(thor_hip_encoder*) { g_clk.sb_ms = g_clk.filt_ms = 0; g_clk.sb_launches = 0; }
 
 }  // extern "C"

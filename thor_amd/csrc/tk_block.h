@@ -27,19 +27,51 @@ struct Node {
   BlkParam best;
 };
 
-template <typename PIX> struct TeamWs {
+// Per-team working set.  The small, latency-critical part (transform tiles, candidate tables,
+// coefficient buffers, the recursion stack) lives in LDS on the GPU; the sample blocks (up to
+// 128x128) live in a per-team global scratch arena that stays L1/L2 resident.
+enum { kProfSlots = 16 };
+template <typename PIX> struct SmallWs {
   XformWs xf;
   MeWs me;
   IntraEdge<PIX> edge;
+  int16_t coef_y[4 * 256], coef_u[4 * 256], coef_v[4 * 256];
+  unsigned long long acc[12];
+  Node stack[5];
+  long long prof[kProfSlots];
+};
+template <typename PIX> struct BigWs {
   PIX pred_y[kMaxSb * kMaxSb], pred_u[kMaxSb * kMaxSb / 4], pred_v[kMaxSb * kMaxSb / 4];
   PIX p0_y[kMaxSb * kMaxSb], p0_u[kMaxSb * kMaxSb / 4], p0_v[kMaxSb * kMaxSb / 4];
   PIX p1_y[kMaxSb * kMaxSb], p1_u[kMaxSb * kMaxSb / 4], p1_v[kMaxSb * kMaxSb / 4];
   PIX rec_y[kMaxSb * kMaxSb], rec_u[kMaxSb * kMaxSb / 4], rec_v[kMaxSb * kMaxSb / 4];
   PIX org8[kMaxSb * kMaxSb];
-  int16_t coef_y[4 * 256], coef_u[4 * 256], coef_v[4 * 256];
-  unsigned long long acc[12];
-  Node stack[5];
 };
+template <typename PIX> struct TeamWs {  // view (lives in registers)
+  XformWs* xfp;
+  MeWs* mep;
+  IntraEdge<PIX>* edgep;
+  int16_t *coef_y, *coef_u, *coef_v;
+  unsigned long long* acc;
+  Node* stack;
+  long long* prof;
+  PIX *pred_y, *pred_u, *pred_v, *p0_y, *p0_u, *p0_v, *p1_y, *p1_u, *p1_v, *rec_y, *rec_u, *rec_v, *org8;
+};
+template <typename PIX> TK_DEV TeamWs<PIX> make_ws(SmallWs<PIX>* s, BigWs<PIX>* g) {
+  TeamWs<PIX> w;
+  w.xfp = &s->xf; w.mep = &s->me; w.edgep = &s->edge;
+  w.coef_y = s->coef_y; w.coef_u = s->coef_u; w.coef_v = s->coef_v;
+  w.acc = s->acc; w.stack = s->stack; w.prof = s->prof;
+  s->xf.prof = s->prof; s->me.prof = s->prof;
+  w.pred_y = g->pred_y; w.pred_u = g->pred_u; w.pred_v = g->pred_v;
+  w.p0_y = g->p0_y; w.p0_u = g->p0_u; w.p0_v = g->p0_v;
+  w.p1_y = g->p1_y; w.p1_u = g->p1_u; w.p1_v = g->p1_v;
+  w.rec_y = g->rec_y; w.rec_u = g->rec_u; w.rec_v = g->rec_v; w.org8 = g->org8;
+  return w;
+}
+
+enum { PF_SB = 0, PF_ESKIP, PF_ME_FULL, PF_ME_SUB, PF_PRED_INTER, PF_PRED_INTRA, PF_TU, PF_BITS, PF_COST, PF_FINAL,
+       PF_CFL, PF_BIPRED_PREP, PF_QUANT };
 
 // ---------------------------------------------------------------------------------
 // availability (common_block.h:52-95)
@@ -166,6 +198,7 @@ TK_DEV void ssd_acc(const Team& t, unsigned long long* acc, const PIX* a, int as
 // cost_calc (encode_block.c:916-926) on the trial recon in ws->rec_* vs. the original frame.
 template <typename PIX>
 TK_DEVNI unsigned rd_cost(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int nbits, double lambda) {
+  TK_PROF_T0();
   if (t.rank == 0) ws->acc[0] = 0;
   t.sync();
   const int yc = nd.ypos >> 1, xc = nd.xpos >> 1, sc = nd.size >> 1;
@@ -177,6 +210,7 @@ TK_DEVNI unsigned rd_cost(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
   t.sync();
   unsigned long long cost = (ssd >> (J.cfg.bitdepth * 2 - 16)) + (unsigned long long)(long long)mul_add_nofma(lambda, (double)nbits, 0.5);
   if (cost > (1ull << 30)) cost = 1ull << 30;
+  TK_PROF_ADD(ws, PF_COST);
   return (unsigned)cost;
 }
 
@@ -256,6 +290,7 @@ TK_DEVNI void improve_uv(const Team& t, TeamWs<PIX>* ws, const PIX* y, PIX* u, P
 template <typename PIX>
 TK_DEV void predict_inter(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, const BlkParam& p,
                           int split) {
+  TK_PROF_T0();
   const EncCfg& c = J.cfg;
   const int bi = (p.mode == M_BIPRED) || ((p.mode == M_SKIP || p.mode == M_MERGE) && p.dir == 2);
   if (bi) {
@@ -271,6 +306,7 @@ TK_DEV void predict_inter(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
                    p.mv0, J.sign[p.ref0], c.width, c.height, c.enable_bipred, split, c.bitdepth);
   }
   t.sync();
+  TK_PROF_ADD(ws, PF_PRED_INTER);
 }
 
 // residual coding of one plane of an inter block (encode_and_reconstruct_block_inter :1275-1338)
@@ -280,14 +316,14 @@ TK_DEV int code_inter_plane(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* 
   const int bd = J.cfg.bitdepth;
   if (!tb_split) {
     int fast = (size == 64 && J.cfg.encoder_speed > 0) || J.cfg.encoder_speed > 1;
-    return code_tu(t, &ws->xf, org, ostride, pred, size, rec, size, size, qp, coeff_type, fast, coef, bd);
+    return code_tu(t, ws->xfp, org, ostride, pred, size, rec, size, size, qp, coeff_type, fast, coef, bd);
   }
   const int s2 = size / 2;
   int cbp = 0, index = 0;
   for (int i = 0; i < size; i += s2)
     for (int j = 0; j < size; j += s2) {
       int fast = size == 64 || J.cfg.encoder_speed > 1;
-      int bit = code_tu(t, &ws->xf, org + i * ostride + j, ostride, pred + i * size + j, size, rec + i * size + j, size,
+      int bit = code_tu(t, ws->xfp, org + i * ostride + j, ostride, pred + i * size + j, size, rec + i * size + j, size,
                         s2, qp, coeff_type, fast, coef + index, bd);
       cbp = (cbp << 1) + bit;
       index += 256;
@@ -323,19 +359,19 @@ TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
       int index = 0;
       for (int i = 0; i < size; i += s2)
         for (int j = 0; j < size; j += s2) {
-          make_edges(t, &ws->edge, fy, J.rec.sy, ws->rec_y + i * size + j, size, i, j, nd.ypos, nd.xpos, s2, ur, dl, 1, bd);
-          pred_intra(t, &ws->edge, nd.ypos + i, nd.xpos + j, s2, ws->pred_y + i * size + j, size, p.intra_mode, bd);
+          make_edges(t, ws->edgep, fy, J.rec.sy, ws->rec_y + i * size + j, size, i, j, nd.ypos, nd.xpos, s2, ur, dl, 1, bd);
+          pred_intra(t, ws->edgep, nd.ypos + i, nd.xpos + j, s2, ws->pred_y + i * size + j, size, p.intra_mode, bd);
           t.sync();
-          int bit = code_tu(t, &ws->xf, oy + i * J.orig.sy + j, J.orig.sy, ws->pred_y + i * size + j, size,
+          int bit = code_tu(t, ws->xfp, oy + i * J.orig.sy + j, J.orig.sy, ws->pred_y + i * size + j, size,
                             ws->rec_y + i * size + j, size, s2, qpY, ftI | 0, c.encoder_speed > 1, ws->coef_y + index, bd);
           cbp_y = (cbp_y << 1) + bit;
           index += 256;
         }
     } else {
-      make_edges(t, &ws->edge, fy, J.rec.sy, (const PIX*)nullptr, 0, 0, 0, nd.ypos, nd.xpos, size, ur, dl, 0, bd);
-      pred_intra(t, &ws->edge, nd.ypos, nd.xpos, size, ws->pred_y, size, p.intra_mode, bd);
+      make_edges(t, ws->edgep, fy, J.rec.sy, (const PIX*)nullptr, 0, 0, 0, nd.ypos, nd.xpos, size, ur, dl, 0, bd);
+      pred_intra(t, ws->edgep, nd.ypos, nd.xpos, size, ws->pred_y, size, p.intra_mode, bd);
       t.sync();
-      cbp_y = code_tu(t, &ws->xf, oy, J.orig.sy, ws->pred_y, size, ws->rec_y, size, size, qpY, ftI | 0,
+      cbp_y = code_tu(t, ws->xfp, oy, J.orig.sy, ws->pred_y, size, ws->rec_y, size, size, qpY, ftI | 0,
                       c.encoder_speed > 1, ws->coef_y, bd);
     }
     // chroma (encode_and_reconstruct_block_intra_uv :1170-1273)
@@ -345,34 +381,34 @@ TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
       int index = 0;
       for (int i = 0; i < sizeC; i += s2)
         for (int j = 0; j < sizeC; j += s2) {
-          make_edges(t, &ws->edge, fu, J.rec.sc, ws->rec_u + i * sizeC + j, sizeC, i, j, yc, xc, s2, ur, dl, 1, bd);
-          pred_intra(t, &ws->edge, yc + i, xc + j, s2, ws->pred_u + i * sizeC + j, sizeC, p.intra_mode, bd);
+          make_edges(t, ws->edgep, fu, J.rec.sc, ws->rec_u + i * sizeC + j, sizeC, i, j, yc, xc, s2, ur, dl, 1, bd);
+          pred_intra(t, ws->edgep, yc + i, xc + j, s2, ws->pred_u + i * sizeC + j, sizeC, p.intra_mode, bd);
           t.sync();
-          make_edges(t, &ws->edge, fv, J.rec.sc, ws->rec_v + i * sizeC + j, sizeC, i, j, yc, xc, s2, ur, dl, 1, bd);
-          pred_intra(t, &ws->edge, yc + i, xc + j, s2, ws->pred_v + i * sizeC + j, sizeC, p.intra_mode, bd);
+          make_edges(t, ws->edgep, fv, J.rec.sc, ws->rec_v + i * sizeC + j, sizeC, i, j, yc, xc, s2, ur, dl, 1, bd);
+          pred_intra(t, ws->edgep, yc + i, xc + j, s2, ws->pred_v + i * sizeC + j, sizeC, p.intra_mode, bd);
           t.sync();
           if (c.cfl_intra)  // sic: luma pointers offset in CHROMA units (encode_block.c:1199)
             improve_uv(t, ws, ws->pred_y + i * sizeC + j, ws->pred_u + i * sizeC + j, ws->pred_v + i * sizeC + j,
                        ws->rec_y + (i << 1) * size + (j << 1), s2 << 1, sizeC << 1, size, bd);
-          int bu = code_tu(t, &ws->xf, ou + i * J.orig.sc + j, J.orig.sc, ws->pred_u + i * sizeC + j, sizeC,
+          int bu = code_tu(t, ws->xfp, ou + i * J.orig.sc + j, J.orig.sc, ws->pred_u + i * sizeC + j, sizeC,
                            ws->rec_u + i * sizeC + j, sizeC, s2, qpC, ftI | 1, c.encoder_speed > 1, ws->coef_u + index, bd);
           cbp_u = (cbp_u << 1) + bu;
-          int bv = code_tu(t, &ws->xf, ov + i * J.orig.sc + j, J.orig.sc, ws->pred_v + i * sizeC + j, sizeC,
+          int bv = code_tu(t, ws->xfp, ov + i * J.orig.sc + j, J.orig.sc, ws->pred_v + i * sizeC + j, sizeC,
                            ws->rec_v + i * sizeC + j, sizeC, s2, qpC, ftI | 1, c.encoder_speed > 1, ws->coef_v + index, bd);
           cbp_v = (cbp_v << 1) + bv;
           index += 256;
         }
     } else {
-      make_edges(t, &ws->edge, fu, J.rec.sc, (const PIX*)nullptr, 0, 0, 0, yc, xc, sizeC, ur, dl, 0, bd);
-      pred_intra(t, &ws->edge, yc, xc, sizeC, ws->pred_u, sizeC, p.intra_mode, bd);
+      make_edges(t, ws->edgep, fu, J.rec.sc, (const PIX*)nullptr, 0, 0, 0, yc, xc, sizeC, ur, dl, 0, bd);
+      pred_intra(t, ws->edgep, yc, xc, sizeC, ws->pred_u, sizeC, p.intra_mode, bd);
       t.sync();
-      make_edges(t, &ws->edge, fv, J.rec.sc, (const PIX*)nullptr, 0, 0, 0, yc, xc, sizeC, ur, dl, 0, bd);
-      pred_intra(t, &ws->edge, yc, xc, sizeC, ws->pred_v, sizeC, p.intra_mode, bd);
+      make_edges(t, ws->edgep, fv, J.rec.sc, (const PIX*)nullptr, 0, 0, 0, yc, xc, sizeC, ur, dl, 0, bd);
+      pred_intra(t, ws->edgep, yc, xc, sizeC, ws->pred_v, sizeC, p.intra_mode, bd);
       t.sync();
       if (c.cfl_intra) improve_uv(t, ws, ws->pred_y, ws->pred_u, ws->pred_v, ws->rec_y, size, size, size, bd);
-      cbp_u = code_tu(t, &ws->xf, ou, J.orig.sc, ws->pred_u, sizeC, ws->rec_u, sizeC, sizeC, qpC, ftI | 1,
+      cbp_u = code_tu(t, ws->xfp, ou, J.orig.sc, ws->pred_u, sizeC, ws->rec_u, sizeC, sizeC, qpC, ftI | 1,
                       c.encoder_speed > 1, ws->coef_u, bd);
-      cbp_v = code_tu(t, &ws->xf, ov, J.orig.sc, ws->pred_v, sizeC, ws->rec_v, sizeC, sizeC, qpC, ftI | 1,
+      cbp_v = code_tu(t, ws->xfp, ov, J.orig.sc, ws->pred_v, sizeC, ws->rec_v, sizeC, sizeC, qpC, ftI | 1,
                       c.encoder_speed > 1, ws->coef_v, bd);
     }
   } else {
@@ -394,7 +430,10 @@ TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
   p.cbp_y = (uint8_t)cbp_y;
   p.cbp_u = (uint8_t)cbp_u;
   p.cbp_v = (uint8_t)cbp_v;
-  return bs_block(bs, nd.syn, p, ws->coef_y, ws->coef_u, ws->coef_v);
+  TK_PROF_T0();
+  int nb_ = bs_block(bs, nd.syn, p, ws->coef_y, ws->coef_u, ws->coef_v);
+  TK_PROF_ADD(ws, PF_BITS);
+  return nb_;
 }
 
 // One RDO trial: count bits, evaluate cost, keep `best` (copy_best_parameters, :1615-1677).
@@ -442,20 +481,20 @@ TK_DEV unsigned search_inter(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>*
   mv_t mv, mvp2 = mvp;
   if (part == P_NONE) {
     a.width = size; a.height = size;
-    sad += motion_estimate(t, &ws->me, org, ref_y, a, mvc, mvp2, ref_idx, &mv);
+    sad += motion_estimate(t, ws->mep, org, ref_y, a, mvc, mvp2, ref_idx, &mv);
     mv_arr[0] = mv_arr[1] = mv_arr[2] = mv_arr[3] = mv;
   } else if (part == P_HOR) {
     a.width = size; a.height = size / 2;
     for (int index = 0; index < 4; index += 2) {
       int py = index >> 1;
-      sad += motion_estimate(t, &ws->me, org + py * (size / 2) * ostride, ref_y + py * (size / 2) * ref.sy, a, mvc, mvp2, ref_idx, &mv);
+      sad += motion_estimate(t, ws->mep, org + py * (size / 2) * ostride, ref_y + py * (size / 2) * ref.sy, a, mvc, mvp2, ref_idx, &mv);
       mv_arr[index] = mv; mv_arr[index + 1] = mv;
       mvp2 = mv_arr[0];
     }
   } else if (part == P_VER) {
     a.width = size / 2; a.height = size;
     for (int index = 0; index < 2; index++) {
-      sad += motion_estimate(t, &ws->me, org + index * (size / 2), ref_y + index * (size / 2), a, mvc, mvp2, ref_idx, &mv);
+      sad += motion_estimate(t, ws->mep, org + index * (size / 2), ref_y + index * (size / 2), a, mvc, mvp2, ref_idx, &mv);
       mv_arr[index] = mv; mv_arr[index + 2] = mv;
       mvp2 = mv_arr[0];
     }
@@ -463,7 +502,7 @@ TK_DEV unsigned search_inter(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>*
     a.width = size / 2; a.height = size / 2;
     for (int index = 0; index < 4; index++) {
       int px = index & 1, py = index >> 1;
-      sad += motion_estimate(t, &ws->me, org + py * (size / 2) * ostride + px * (size / 2),
+      sad += motion_estimate(t, ws->mep, org + py * (size / 2) * ostride + px * (size / 2),
                              ref_y + py * (size / 2) * ref.sy + px * (size / 2), a, mvc, mvp2, ref_idx, &mv);
       mv_arr[index] = mv;
       mvp2 = mv_arr[0];
@@ -474,7 +513,7 @@ TK_DEV unsigned search_inter(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>*
 
 template <typename PIX> TK_DEV void add_cands4(const Team& t, TeamWs<PIX>* ws, int ref_idx, const mv_t* mv4) {
   if (t.rank == 0)
-    for (int i = 0; i < 4; i++) add_mvcand(&ws->me, ref_idx, mv4[i]);
+    for (int i = 0; i < 4; i++) add_mvcand(ws->mep, ref_idx, mv4[i]);
   t.sync();
 }
 
@@ -572,7 +611,7 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
       const int min_idx = (J.frame_type == F_B && J.interp_ref > 2) ? 1 : 0;
       for (int r = min_idx; r < J.num_ref; r++) {
         mvp = get_mv_pred(J.cells, J.cell_stride, nd.ypos, nd.xpos, c.width, c.height, size, kMaxSb);
-        if (t.rank == 0) add_mvcand(&ws->me, r, mvp);
+        if (t.rank == 0) add_mvcand(ws->mep, r, mvp);
         t.sync();
         nd.syn.mvp = mvp;
         mv_center[r] = mvp;
@@ -650,22 +689,22 @@ TK_DEV int early_skip_sub(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
     int b = (int16_t)((int)org[(2 * i) * ostride + 2 * j + 1] - (int)pred[(2 * i) * pstride + 2 * j + 1]);
     int cc = (int16_t)((int)org[(2 * i + 1) * ostride + 2 * j] - (int)pred[(2 * i + 1) * pstride + 2 * j]);
     int d = (int16_t)((int)org[(2 * i + 1) * ostride + 2 * j + 1] - (int)pred[(2 * i + 1) * pstride + 2 * j + 1]);
-    ws->xf.in[k] = (int16_t)((a + b + cc + d + 2) >> 2);
+    ws->xfp->in[k] = (int16_t)((a + b + cc + d + 2) >> 2);
   }
   t.sync();
-  fwd_transform_block(t, &ws->xf, s2, bd);
+  fwd_transform_block(t, ws->xfp, s2, bd);
   const int shift2 = 21 - ilog2(s2) + qp / 6;
   const double fql = (double)(1 << shift2) / (double)quant_scale(qp % 6);
   const double rel = 0.5 * thr;  // float -> double promotion as in the reference
   const int threshold = (int)(rel * fql);
-  if (t.rank == 0) ws->xf.flag = 0;
+  if (t.rank == 0) ws->xfp->flag = 0;
   t.sync();
   int f = 0;
   for (int k = t.rank; k < s2 * s2; k += t.size)
-    if (iabs((int)ws->xf.coef[k]) > threshold) f = 1;
-  if (f) team_or((unsigned*)&ws->xf.flag, 1u);
+    if (iabs((int)ws->xfp->coef[k]) > threshold) f = 1;
+  if (f) team_or((unsigned*)&ws->xfp->flag, 1u);
   t.sync();
-  int r = ws->xf.flag;
+  int r = ws->xfp->flag;
   t.sync();
   return r != 0;
 }
@@ -676,24 +715,31 @@ TK_DEV int early_skip_subC(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* w
   const int shift2 = 21 - 5 + qp / 6;
   const double fql = (double)(1 << shift2) / (double)quant_scale(qp % 6);
   const int threshold = ((int)(thr * fql)) << (J.cfg.bitdepth - 8);
-  if (t.rank == 0) ws->xf.flag = 0;
+  if (t.rank == 0) ws->xfp->flag = 0;
   t.sync();
-  // calc_cbp (encode_block.c:2182-2212): column sums (pairs of columns for 4x4)
+  // calc_cbp as the reference EXECUTES it, i.e. calc_cbp_simd (enc/enc_kernels.c:827-907, selected at
+  // encode_block.c:2225 because use_simd = 1): int16 column sums of the residual; for 16/8 wide
+  // blocks |sum| > thr per column; for 4x4 the SIMD code tests (col[2k+1] + |col[2k]|) > thr, which
+  // is NOT the scalar |col[2k] + col[2k+1]| > thr - the oracle binary runs the SIMD form.
   const int ncol = size == 4 ? 2 : size;
   int f = 0;
   for (int col = t.rank; col < ncol; col += t.size) {
-    int sum = 0;
-    for (int i = 0; i < size; i++) {
-      if (size == 4)
-        sum += (int16_t)((int)org[i * ostride + 2 * col] - (int)pred[i * pstride + 2 * col]) +
-               (int16_t)((int)org[i * ostride + 2 * col + 1] - (int)pred[i * pstride + 2 * col + 1]);
-      else sum += (int16_t)((int)org[i * ostride + col] - (int)pred[i * pstride + col]);
+    if (size == 4) {
+      int lo = 0, hi = 0;
+      for (int i = 0; i < 4; i++) {
+        lo = (int16_t)(lo + (int16_t)((int)org[i * ostride + 2 * col] - (int)pred[i * pstride + 2 * col]));
+        hi = (int16_t)(hi + (int16_t)((int)org[i * ostride + 2 * col + 1] - (int)pred[i * pstride + 2 * col + 1]));
+      }
+      if (hi + (int)(int16_t)iabs(lo) > threshold) f = 1;
+    } else {
+      int sum = 0;
+      for (int i = 0; i < size; i++) sum = (int16_t)(sum + (int16_t)((int)org[i * ostride + col] - (int)pred[i * pstride + col]));
+      if ((int16_t)iabs(sum) > (int16_t)threshold) f = 1;
     }
-    if (iabs(sum) > threshold) f = 1;
   }
-  if (f) team_or((unsigned*)&ws->xf.flag, 1u);
+  if (f) team_or((unsigned*)&ws->xfp->flag, 1u);
   t.sync();
-  int r = ws->xf.flag;
+  int r = ws->xfp->flag;
   t.sync();
   return r != 0;
 }
@@ -738,6 +784,7 @@ TK_DEVNI int check_early_skip(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>
 // ---------------------------------------------------------------------------------
 template <typename PIX>
 TK_DEVNI int final_encode(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BitSink& out) {
+  TK_PROF_T0();
   BlkParam p = nd.best;
   BitSink cnt;
   cnt.buf = nullptr; cnt.pos = 0; cnt.cap = 0; cnt.emit = 0; cnt.ovf = 0;
@@ -777,6 +824,7 @@ TK_DEVNI int final_encode(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
     cell.pad = 0;
   }
   t.sync();
+  TK_PROF_ADD(ws, PF_FINAL);
   return nbits;
 }
 
@@ -785,10 +833,11 @@ TK_DEVNI int final_encode(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
 // ---------------------------------------------------------------------------------
 template <typename PIX>
 TK_DEV void process_sb(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, int sb_y, int sb_x, BitSink& out) {
+  TK_PROF_T0();
   const EncCfg& c = J.cfg;
   const int fw = c.width, fh = c.height;
   if (t.rank == 0)
-    for (int r = 0; r < kMaxRefs; r++) { ws->me.mvcand_num[r] = 0; ws->me.mvcand_mask[r] = 0; }
+    for (int r = 0; r < kMaxRefs; r++) { ws->mep->mvcand_num[r] = 0; ws->mep->mvcand_mask[r] = 0; }
   t.sync();
   int sp = 0;
   unsigned ret = 0;  // value "returned" by the node that was just popped
@@ -833,7 +882,10 @@ TK_DEV void process_sb(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, i
         p.intra_mode = 0; p.pb_part = P_NONE; p.tb_param = 0; p.tb_split = 0; p.cbp_y = p.cbp_u = p.cbp_v = 0;
         for (int k = 0; k < nd.syn.num_skip; k++) {
           set_cand(p, nd.skip[k], k, M_SKIP);
-          if (check_early_skip(t, J, ws, nd, p)) {
+          TK_PROF_T0();
+          int es_ = check_early_skip(t, J, ws, nd, p);
+          TK_PROF_ADD(ws, PF_ESKIP);
+          if (es_) {
             any = 1;
             unsigned cost = rdo_trial(t, J, ws, nd, p, J.lambda);
             if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); t.sync(); }
@@ -843,6 +895,9 @@ TK_DEV void process_sb(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, i
           int nbits = final_encode(t, J, ws, nd, out);
           // reference recomputes cost_calc on the final recon: identical to min_cost of that candidate
           ret = rd_cost(t, J, ws, nd, nbits, J.lambda);
+#if TK_HOST
+          if (getenv("THOR_DBG")) fprintf(stderr, "F %d y %d x %d s %d ES mode %d idx %d cost %u bits %d\n", J.frame_num, nd.ypos, nd.xpos, nd.size, nd.best.mode, nd.best.skip_idx, ret, nbits);
+#endif
           have_ret = 1;
           sp--;
           continue;
@@ -903,6 +958,9 @@ TK_DEV void process_sb(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, i
       if (nd.encode_this_size || nd.encode_rect) {
         cost = mode_decision(t, J, ws, nd);
         t.sync();
+#if TK_HOST
+        if (getenv("THOR_DBG")) fprintf(stderr, "F %d y %d x %d s %d RDO mode %d cost %u small %u ref %d part %d tb %d mv %d %d\n", J.frame_num, nd.ypos, nd.xpos, nd.size, nd.best.mode, cost, nd.cost_small, nd.best.ref0, nd.best.pb_part, nd.best.tb_param, nd.best.mv0[0].x, nd.best.mv0[0].y);
+#endif
         if (cost <= nd.cost_small) {
           out.pos = nd.bitpos0;
           final_encode(t, J, ws, nd, out);
@@ -913,6 +971,7 @@ TK_DEV void process_sb(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, i
       sp--;
     }
   }
+  TK_PROF_ADD(ws, PF_SB);
 }
 
 }  // namespace tk

@@ -17,6 +17,7 @@
 #if defined(THOR_HOSTSIM)
 #include <string.h>
 #include <stdlib.h>
+#include <stdio.h>
 #define TK_DEV static inline
 #define TK_HD static inline
 #define TK_CONST static const
@@ -69,6 +70,49 @@ TK_DEV void team_or(unsigned* p, unsigned v) {
   atomicOr(p, v);
 #endif
 }
+
+// Cross-lane helpers.  A team of 1 lane (host simulation) degenerates to the identity, so code
+// written against them is also the serial algorithm.
+TK_DEV unsigned long long team_ballot(const Team& t, int pred) {
+#if TK_HOST
+  (void)t;
+  return pred ? 1ull : 0ull;
+#else
+  (void)t;
+  return __ballot(pred);
+#endif
+}
+TK_DEV int team_sum(const Team& t, int v) {
+#if TK_HOST
+  (void)t;
+  return v;
+#else
+  (void)t;
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+#endif
+}
+TK_DEV int team_max(const Team& t, int v) {
+#if TK_HOST
+  (void)t;
+  return v;
+#else
+  (void)t;
+  for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(v, d); v = o > v ? o : v; }
+  return v;
+#endif
+}
+// index of the highest set bit of m strictly below `rank`, or -1
+TK_DEV int prev_set(unsigned long long m, int rank) {
+  m &= (rank >= 64) ? ~0ull : ((1ull << rank) - 1ull);
+  if (!m) return -1;
+#if TK_HOST
+  return 63 - __builtin_clzll(m);
+#else
+  return 63 - __clzll((long long)m);
+#endif
+}
+TK_DEV int top_set(unsigned long long m) { return prev_set(m, 64); }
 
 // IEEE double multiply-add WITHOUT contraction: the reference is built -std=c99
 // (=> -ffp-contract=off), so lambda*bits+0.5 is a rounded product followed by a
@@ -196,6 +240,7 @@ template <typename PIX> struct FrameJob {
   int* sb_status;          // 0 ok, !=0 overflow/internal error
   uint8_t* scratch;        // per-team scratch arena, scratch_bytes each
   size_t scratch_bytes;
+  long long* prof;         // optional cycle-counter sink (THOR_PROF builds), 16 slots
 };
 
 }  // namespace tk

@@ -159,6 +159,7 @@ template <typename PIX> class Engine {
   std::vector<CdefJob<PIX>> h_cjobs;
   int nfb_h = 0, nfb_v = 0;
   size_t ws_bytes = 0;
+  long long* d_prof = nullptr;  // 16 cycle counters summed over all superblocks (THOR_PROF builds)
 
   void open(const SeqParams& p, int num_streams) {
     sp = p; S = num_streams;
@@ -201,6 +202,7 @@ template <typename PIX> class Engine {
     h_jobs.resize(S);
     d_cjobs = (CdefJob<PIX>*)backend::dev_alloc(sizeof(CdefJob<PIX>) * S);
     h_cjobs.resize(S);
+    d_prof = (long long*)backend::dev_alloc(16 * sizeof(long long));
   }
   void close() {
     for (auto& s : st) {
@@ -214,6 +216,7 @@ template <typename PIX> class Engine {
     st.clear();
     backend::dev_free(d_jobs); d_jobs = nullptr;
     backend::dev_free(d_cjobs); d_cjobs = nullptr;
+    backend::dev_free(d_prof); d_prof = nullptr;
   }
 
   // planar 4:2:0 frame in host memory -> device `orig` of stream s
@@ -320,6 +323,7 @@ template <typename PIX> class Engine {
       J.sb_cols = sb_cols; J.sb_rows = sb_rows;
       J.sb_bits = q.sb_bits; J.sb_words = kSbWords; J.sb_nbits = q.sb_nbits; J.sb_status = q.sb_status;
       J.scratch = q.scratch; J.scratch_bytes = ws_bytes;
+      J.prof = d_prof;
       if (f.frame_type == F_I) backend::dev_memset(q.cells, 0, (size_t)(sp.width / 4) * (sp.height / 4) * sizeof(DbCell));
     }
     backend::h2d(d_jobs, h_jobs.data(), sizeof(FrameJob<PIX>) * S);

@@ -8,6 +8,7 @@
 #pragma once
 #include "tk_common.h"
 #include "tk_pred.h"
+#include "tk_xform.h"
 
 namespace tk {
 
@@ -21,6 +22,7 @@ struct MeWs {
   mv_t mvcand[kMaxRefs][64];
   int mvcand_num[kMaxRefs];
   unsigned long long mvcand_mask[kMaxRefs];
+  long long* prof;
 };
 
 TK_DEV int mv_len1(int a) {
@@ -95,6 +97,7 @@ TK_DEV void pick_best(const MeWs* w, int n, unsigned& min_sad, mv_t& mv_opt, int
 template <typename PIX>
 TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const PIX* ref, const MeArgs& a, mv_t mvc,
                                 mv_t mvp, int ref_idx, mv_t* mv_out) {
+  TK_PROF_T0();
   const int s = a.sign ? -1 : 1;
   const int sh = a.bitdepth - 8;
   unsigned min_sad = kCostInit;
@@ -210,7 +213,11 @@ TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const 
     }
   }
 
+  TK_PROF_ADD(w, 2);
   // --- half-pel then quarter-pel (encode_block.c:628-663)
+#if defined(THOR_PROF) && !TK_HOST
+  pt0_ = (long long)__builtin_readcyclecounter();
+#endif
   unsigned cmin = min_sad;
   for (int pass = 0; pass < 2; pass++) {
     const int d = pass == 0 ? 2 : 1;
@@ -238,6 +245,7 @@ TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const 
     // mv_opt += delta of the winning position (none => unchanged)
     mv_opt = mk_mv(mv_opt.x + (best.x - base.x), mv_opt.y + (best.y - base.y));
   }
+  TK_PROF_ADD(w, 3);
   *mv_out = mv_opt;
   return cmin < min_sad ? cmin : min_sad;
 }

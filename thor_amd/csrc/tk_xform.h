@@ -7,6 +7,16 @@
 #pragma once
 #include "tk_common.h"
 
+#ifndef TK_PROF_T0
+#if defined(THOR_PROF) && !TK_HOST
+#define TK_PROF_T0() long long pt0_ = (long long)__builtin_readcyclecounter()
+#define TK_PROF_ADD(ws, id) do { if (t.rank == 0) (ws)->prof[id] += (long long)__builtin_readcyclecounter() - pt0_; } while (0)
+#else
+#define TK_PROF_T0() do {} while (0)
+#define TK_PROF_ADD(ws, id) do {} while (0)
+#endif
+#endif
+
 namespace tk {
 
 struct XformWs {
@@ -16,6 +26,7 @@ struct XformWs {
   int16_t rcoef[16 * 16]; // de-quantised coefficients, compact
   int16_t itmp[16 * 32];  // inverse stage-1, [coef col i][sample j]
   int flag;               // team-shared scalar result
+  long long* prof;        // cycle counters (THOR_PROF builds)
 };
 
 TK_DEV const int16_t* dct_matrix(int n) {
@@ -200,8 +211,16 @@ TK_DEV void copy_block(const Team& t, PIX* dst, int dstride, const PIX* src, int
 template <typename PIX>
 TK_DEVNI int code_tu(const Team& t, XformWs* ws, const PIX* org, int ostride, const PIX* pred, int pstride, PIX* rec,
                    int rstride, int size, int qp, int coeff_type, int fast, int16_t* coefq, int bitdepth) {
+  TK_PROF_T0();
   fwd_transform(t, ws, org, ostride, pred, pstride, size, fast, bitdepth);
+  long long pq0_ = 0; (void)pq0_;
+#if defined(THOR_PROF) && !TK_HOST
+  pq0_ = (long long)__builtin_readcyclecounter();
+#endif
   int cbp = quantize_team(t, ws, coefq, qp, size, (coeff_type >> 1) & 1);
+#if defined(THOR_PROF) && !TK_HOST
+  if (t.rank == 0) ws->prof[12] += (long long)__builtin_readcyclecounter() - pq0_;
+#endif
   if (cbp) {
     dequantize(t, ws, coefq, qp, size);
     inv_transform_recon(t, ws, pred, pstride, rec, rstride, size, bitdepth);
@@ -209,6 +228,7 @@ TK_DEVNI int code_tu(const Team& t, XformWs* ws, const PIX* org, int ostride, co
     copy_block(t, rec, rstride, pred, pstride, size, size);
     t.sync();
   }
+  TK_PROF_ADD(ws, 6);
   return cbp;
 }
 
