@@ -165,6 +165,91 @@ struct BlkParam {  // block_param_t without the coefficient arrays (common/types
   mv_t mv0[4], mv1[4];
 };
 
+// Number of bits write_coeff produces, evaluated W = team.size scan positions at a time (count only;
+// must be called by ALL lanes of the team).  The level/run mode is again a {identity, ->run, ->level}
+// automaton (zero -> run mode, |c| > 1 -> level mode, |c| == 1 keeps the mode), so ballots give each
+// position its mode, its adaptive-VLC flag and its run length.  With W = 1 this is the serial loop.
+TK_DEV int coeff_bits_team(const Team& t, const int16_t* coeff, int size, int type) {
+  const int qsize = size < kMaxQuant ? size : kMaxQuant;
+  const int N = qsize * qsize;
+  const int16_t* izz = qsize == 4 ? TK_TAB.izz4 : (qsize == 8 ? TK_TAB.izz8 : TK_TAB.izz16);
+  const int chroma = type & 1, intra = (type >> 1) & 1;
+  const uint32_t eob_pos = chroma ? 0u : 2u;
+  const int runtab = (chroma && size <= 8) ? 10 : 6;
+  const int W = t.size;
+  int last = 0;
+  for (int base = 0; base < N; base += W) {
+    const int p = base + t.rank;
+    const unsigned long long m = team_ballot(t, p < N && coeff[izz[p]] != 0);
+    if (m) last = base + top_set(m);
+  }
+  int bits = 0;  // per-lane partial, reduced at the end
+  int head = 0;  // uniform part
+  if (chroma) {
+    const int c0 = coeff[izz[0]];
+    if (last == 0 && iabs(c0) == 1) return 2;
+    head = 1;
+  }
+  int carryL = 1;                        // mode entering the round (1 = level mode)
+  int carry_prevL = 0, carry_gt3 = 0;    // state of position base-1
+  int carry_q = -1;
+  int lastL = 0, last_gt3 = 0;
+  for (int base = 0; base <= last; base += W) {
+    const int p = base + t.rank;
+    const int active = p <= last;
+    const int c = active ? (int)coeff[izz[p]] : 0;
+    const int a = iabs(c);
+    const unsigned long long mK = team_ballot(t, active && a != 1), mBig = team_ballot(t, active && a > 1);
+    const int j = prev_set(mK, t.rank);
+    const int modeL = j < 0 ? carryL : (int)((mBig >> j) & 1ull);
+    const unsigned long long mL = team_ballot(t, active && modeL), mGt3 = team_ballot(t, active && a > 3);
+    const unsigned long long mQ = team_ballot(t, active && (a != 0 || modeL));
+    if (active) {
+      if (modeL) {
+        int adaptive = 0;
+        if (!chroma) {
+          if (p == 0) adaptive = intra;
+          else {
+            const int prevL = t.rank > 0 ? (int)((mL >> (t.rank - 1)) & 1ull) : carry_prevL;
+            const int prevG = t.rank > 0 ? (int)((mGt3 >> (t.rank - 1)) & 1ull) : carry_gt3;
+            adaptive = prevL ? prevG : 0;
+          }
+        }
+        bits += vlc_len(adaptive, (uint32_t)a) + (a > 0);
+      } else if (a != 0) {
+        const int jq = prev_set(mQ, t.rank);
+        const int q = jq < 0 ? carry_q : base + jq;
+        const int run = p - 1 - q;
+        const uint32_t cn = (a == 1) ? (uint32_t)((run * 5) / 4) : (uint32_t)(run * 5 + 4);
+        bits += vlc_len(runtab, cn + (cn >= eob_pos));
+        bits += (a > 1) ? vlc_len(0, (uint32_t)((a - 2) * 2 + (c < 0))) : 1;
+      }
+    }
+    // state of the coefficient at `last` (for the trailing symbols)
+    if (last >= base && last < base + W) {
+      const int li = last - base;
+      lastL = (int)((mL >> li) & 1ull);
+      last_gt3 = (int)((mGt3 >> li) & 1ull);
+    }
+    const int jj = top_set(mK);
+    if (jj >= 0) carryL = (int)((mBig >> jj) & 1ull);
+    const int wl = W - 1;
+    carry_prevL = (int)((mL >> wl) & 1ull);
+    carry_gt3 = (int)((mGt3 >> wl) & 1ull);
+    const int jq2 = top_set(mQ);
+    if (jq2 >= 0) carry_q = base + jq2;
+  }
+  int pos = last + 1;
+  // carryL is now the mode after consuming coefficient `last`
+  if (pos < N && carryL) {
+    const int adaptive = chroma ? 0 : (lastL ? last_gt3 : 0);
+    head += vlc_len(adaptive, 0);
+    pos++;
+  }
+  if (pos < N) head += vlc_len(runtab, eob_pos);
+  return head + team_sum(t, bits);
+}
+
 // write_super_mode (enc/write_bits.c:257-358).
 TK_DEV void bs_super_mode(BitSink& b, const SynCtx& s, int mode, int ref0, int split_flag) {
   if (s.frame_type != F_I) {
@@ -215,8 +300,14 @@ TK_DEV int cbp_code(int cbp) {  // cbp_table (enc/write_bits.c:382)
 
 // write_block (enc/write_bits.c:360-600).  cy/cu/cv: quantised coefficients, TU t of a
 // tb-split block at offset t*256 (MAX_QUANT_SIZE^2) like the reference.
+// `t`: team for cooperative counting (b.emit == 0, all lanes call) or nullptr (single-lane emission).
+TK_DEV void bs_coeff_any(BitSink& b, const Team* t, const int16_t* coeff, int size, int type) {
+  if (!b.emit && t) b.pos += coeff_bits_team(*t, coeff, size, type);
+  else bs_coeff(b, coeff, size, type);
+}
+
 TK_DEVNI int bs_block(BitSink& b, const SynCtx& s, const BlkParam& p, const int16_t* cy, const int16_t* cu,
-                    const int16_t* cv) {
+                    const int16_t* cv, const Team* tm) {
   const int start = b.pos;
   const int size = s.size, size_uv = size >> 1;
   const int mode = p.mode;
@@ -274,28 +365,28 @@ TK_DEVNI int bs_block(BitSink& b, const SynCtx& s, const BlkParam& p, const int1
     bs_vlc(b, 0, (uint32_t)code);
 
     if (tb_split == 0) {
-      if (p.cbp_y) bs_coeff(b, cy, size, coeff_type | 0);
-      if (p.cbp_u) bs_coeff(b, cu, size_uv, coeff_type | 1);
-      if (p.cbp_v) bs_coeff(b, cv, size_uv, coeff_type | 1);
+      if (p.cbp_y) bs_coeff_any(b, tm, cy, size, coeff_type | 0);
+      if (p.cbp_u) bs_coeff_any(b, tm, cu, size_uv, coeff_type | 1);
+      if (p.cbp_v) bs_coeff_any(b, tm, cv, size_uv, coeff_type | 1);
     } else if (size_uv > 4) {
       for (int t = 0; t < 4; t++) {
         int ty = (p.cbp_y >> (3 - t)) & 1, tu = (p.cbp_u >> (3 - t)) & 1, tv = (p.cbp_v >> (3 - t)) & 1;
         int c = cbp_code(ty + (tu << 1) + (tv << 2));
         if (s.ctx_cbp == 0 && c < 2) c = 1 - c;
         bs_vlc(b, 0, (uint32_t)c);
-        if (ty) bs_coeff(b, cy + t * 256, size / 2, coeff_type | 0);
-        if (tu) bs_coeff(b, cu + t * 256, size_uv / 2, coeff_type | 1);
-        if (tv) bs_coeff(b, cv + t * 256, size_uv / 2, coeff_type | 1);
+        if (ty) bs_coeff_any(b, tm, cy + t * 256, size / 2, coeff_type | 0);
+        if (tu) bs_coeff_any(b, tm, cu + t * 256, size_uv / 2, coeff_type | 1);
+        if (tv) bs_coeff_any(b, tm, cv + t * 256, size_uv / 2, coeff_type | 1);
       }
     } else {
       for (int t = 0; t < 4; t++) {
         int ty = (p.cbp_y >> (3 - t)) & 1;
         bs_put(b, 1, (uint32_t)ty);
-        if (ty) bs_coeff(b, cy + t * 256, size / 2, coeff_type | 0);
+        if (ty) bs_coeff_any(b, tm, cy + t * 256, size / 2, coeff_type | 0);
       }
       bs_vlc(b, 13, (uint32_t)(p.cbp_u + 2 * p.cbp_v));
-      if (p.cbp_u) bs_coeff(b, cu, size_uv, coeff_type | 1);
-      if (p.cbp_v) bs_coeff(b, cv, size_uv, coeff_type | 1);
+      if (p.cbp_u) bs_coeff_any(b, tm, cu, size_uv, coeff_type | 1);
+      if (p.cbp_v) bs_coeff_any(b, tm, cv, size_uv, coeff_type | 1);
     }
   }
   return b.pos - start;

@@ -331,8 +331,11 @@ TK_DEV int code_inter_plane(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* 
   return cbp;
 }
 
+// reuse_pred: the inter prediction of this (mode, refs, MVs) is already in ws->pred_* (previous trial
+// of the same candidate with another tb_param) - exact, the prediction does not depend on tb_param.
 template <typename PIX>
-TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BlkParam& p, BitSink& bs) {
+TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BlkParam& p, BitSink& bs,
+                          int reuse_pred = 0) {
   const EncCfg& c = J.cfg;
   const int size = nd.size, sizeC = size >> 1;
   const int yc = nd.ypos >> 1, xc = nd.xpos >> 1;
@@ -413,7 +416,7 @@ TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
     }
   } else {
     const int split = (p.mode == M_INTER || p.mode == M_BIPRED) ? c.enable_pb_split : 0;
-    predict_inter(t, J, ws, nd, p, split);
+    if (!(reuse_pred && !c.cfl_inter)) predict_inter(t, J, ws, nd, p, split);
     if (p.mode == M_SKIP || zero_block) {
       copy_block(t, ws->rec_y, size, ws->pred_y, size, nd.bw, nd.bh);
       copy_block(t, ws->rec_u, sizeC, ws->pred_u, sizeC, nd.bw >> 1, nd.bh >> 1);
@@ -431,17 +434,18 @@ TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
   p.cbp_u = (uint8_t)cbp_u;
   p.cbp_v = (uint8_t)cbp_v;
   TK_PROF_T0();
-  int nb_ = bs_block(bs, nd.syn, p, ws->coef_y, ws->coef_u, ws->coef_v);
+  int nb_ = bs_block(bs, nd.syn, p, ws->coef_y, ws->coef_u, ws->coef_v, &t);
   TK_PROF_ADD(ws, PF_BITS);
   return nb_;
 }
 
 // One RDO trial: count bits, evaluate cost, keep `best` (copy_best_parameters, :1615-1677).
 template <typename PIX>
-TK_DEV unsigned rdo_trial(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BlkParam& p, double lambda) {
+TK_DEV unsigned rdo_trial(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BlkParam& p, double lambda,
+                          int reuse_pred = 0) {
   BitSink cnt;
   cnt.buf = nullptr; cnt.pos = 0; cnt.cap = 0; cnt.emit = 0; cnt.ovf = 0;
-  int nbits = encode_block(t, J, ws, nd, p, cnt);
+  int nbits = encode_block(t, J, ws, nd, p, cnt, reuse_pred);
   return rd_cost(t, J, ws, nd, nbits, lambda);
 }
 
@@ -599,7 +603,7 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
         set_cand(p, nd.merge[k], k, M_MERGE);
         for (int tb = 0; tb <= max_tb - 1; tb++) {
           p.tb_param = (int8_t)tb;
-          unsigned cost = rdo_trial(t, J, ws, nd, p, lambda);
+          unsigned cost = rdo_trial(t, J, ws, nd, p, lambda, tb > 0);
           if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
         }
       }
@@ -628,7 +632,7 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
           const int min_tb = c.encoder_speed < 1 ? -1 : 0;
           for (int tb = min_tb; tb <= max_tb - 1; tb++) {
             p.tb_param = (int8_t)tb;
-            unsigned cost = rdo_trial(t, J, ws, nd, p, lambda);
+            unsigned cost = rdo_trial(t, J, ws, nd, p, lambda, tb > min_tb);
             if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
           }
         }
@@ -644,31 +648,45 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
         for (int i = 0; i < 4; i++) { p.mv0[i] = a0[i]; p.mv1[i] = a1[i]; }
         for (int tb = 0; tb <= max_tb - 1; tb++) {
           p.tb_param = (int8_t)tb;
-          unsigned cost = rdo_trial(t, J, ws, nd, p, lambda);
+          unsigned cost = rdo_trial(t, J, ws, nd, p, lambda, tb > 0);
           if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
         }
         // TODO(B frames): motion_estimate_bi joint search (encode_block.c:2052-2068)
       }
     }
-    // intra
+    // intra (encode_block.c:2070-2114).  The reference re-encodes the winning mode for both
+    // tb_param values after the search; those trials are repeats of trials already made (same inputs,
+    // deterministic), so their costs are taken from the search instead of being recomputed.
     p.mode = M_INTRA;
     int intra_mode = 0;
+    unsigned best_tb_cost[2] = {kCostInit, kCostInit};
     if (c.intra_rdo) {
       unsigned min_intra = kCostInit;
       for (int m = 0; m < J.num_intra_modes; m++) {
         p.intra_mode = (int8_t)m;
+        unsigned tbc[2] = {kCostInit, kCostInit};
+        int improved = 0;
         for (int tb = 0; tb <= max_tb - 1; tb++) {
           p.tb_param = (int8_t)tb;
           unsigned cost = rdo_trial(t, J, ws, nd, p, lambda);
-          if (cost < min_intra) { min_intra = cost; intra_mode = m; }
+          tbc[tb] = cost;
+          if (cost < min_intra) { min_intra = cost; intra_mode = m; improved = 1; }
         }
+        if (improved) { best_tb_cost[0] = tbc[0]; best_tb_cost[1] = tbc[1]; }
       }
-    }
-    p.intra_mode = (int8_t)intra_mode;
-    for (int tb = 0; tb <= max_tb - 1; tb++) {
-      p.tb_param = (int8_t)tb;
-      unsigned cost = rdo_trial(t, J, ws, nd, p, lambda);
-      if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
+      p.intra_mode = (int8_t)intra_mode;
+      for (int tb = 0; tb <= max_tb - 1; tb++) {
+        p.tb_param = (int8_t)tb;
+        unsigned cost = best_tb_cost[tb];
+        if (cost < min_cost) { min_cost = cost; p.cbp_y = p.cbp_u = p.cbp_v = 0; if (t.rank == 0) keep_best(nd, p); }
+      }
+    } else {
+      p.intra_mode = (int8_t)intra_mode;
+      for (int tb = 0; tb <= max_tb - 1; tb++) {
+        p.tb_param = (int8_t)tb;
+        unsigned cost = rdo_trial(t, J, ws, nd, p, lambda);
+        if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
+      }
     }
   }
   return min_cost;
@@ -689,7 +707,7 @@ TK_DEV int early_skip_sub(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
     int b = (int16_t)((int)org[(2 * i) * ostride + 2 * j + 1] - (int)pred[(2 * i) * pstride + 2 * j + 1]);
     int cc = (int16_t)((int)org[(2 * i + 1) * ostride + 2 * j] - (int)pred[(2 * i + 1) * pstride + 2 * j]);
     int d = (int16_t)((int)org[(2 * i + 1) * ostride + 2 * j + 1] - (int)pred[(2 * i + 1) * pstride + 2 * j + 1]);
-    ws->xfp->in[k] = (int16_t)((a + b + cc + d + 2) >> 2);
+    ws->xfp->in[j * s2 + i] = (int16_t)((a + b + cc + d + 2) >> 2);  // transposed (fwd_core layout)
   }
   t.sync();
   fwd_transform_block(t, ws->xfp, s2, bd);
@@ -792,7 +810,7 @@ TK_DEVNI int final_encode(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
   // bits (one lane), then recon copy and cells (all lanes)
   if (t.rank == 0) {
     BitSink w = out;
-    bs_block(w, nd.syn, p, ws->coef_y, ws->coef_u, ws->coef_v);
+    bs_block(w, nd.syn, p, ws->coef_y, ws->coef_u, ws->coef_v, nullptr);
     out.ovf |= w.ovf;
   }
   out.pos += nbits;
@@ -838,7 +856,7 @@ TK_DEV void process_sb(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, i
   const int fw = c.width, fh = c.height;
   if (t.rank == 0)
     for (int r = 0; r < kMaxRefs; r++) { ws->mep->mvcand_num[r] = 0; ws->mep->mvcand_mask[r] = 0; }
-  t.sync();
+  xform_tables_init(t, ws->xfp);
   int sp = 0;
   unsigned ret = 0;  // value "returned" by the node that was just popped
   int have_ret = 0;

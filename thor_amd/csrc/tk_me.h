@@ -74,6 +74,46 @@ TK_DEV void sad_many(const Team& t, int* sad, int ncand, const PIX* org, int ost
   t.sync();
 }
 
+// |a-b| summed over 4 horizontally adjacent samples (a: 4-sample aligned, b: any alignment).
+template <typename PIX> TK_DEV int sad4(const PIX* a, const PIX* b) {
+  return iabs((int)a[0] - (int)b[0]) + iabs((int)a[1] - (int)b[1]) + iabs((int)a[2] - (int)b[2]) + iabs((int)a[3] - (int)b[3]);
+}
+#if !TK_HOST
+template <> __device__ __forceinline__ int sad4<uint8_t>(const uint8_t* a, const uint8_t* b) {
+  uint32_t va, vb;
+  __builtin_memcpy(&va, a, 4);
+  __builtin_memcpy(&vb, b, 4);
+  return (int)__builtin_amdgcn_sad_u8(va, vb, 0u);  // v_sad_u8: 4 byte-SADs per lane-op
+}
+#endif
+
+// sad[c] = SAD(org block, block at base(c)) for c < ncand; full-pel candidates given as pointers.
+// Work item = (candidate, row, group of 4 samples).
+template <typename PIX, class F>
+TK_DEV void sad_many_ptr(const Team& t, int* sad, int ncand, const PIX* org, int ostride, int w, int h, int rstride, F base) {
+  for (int c = t.rank; c < ncand; c += t.size) sad[c] = 0;
+  t.sync();
+  const int gpr = w >> 2, nit = h * gpr;
+  if (nit >= t.size) {
+    for (int c = 0; c < ncand; c++) {
+      const PIX* b = base(c);
+      int local = 0;
+      for (int r = t.rank; r < nit; r += t.size) {
+        int i = r / gpr, g = r - i * gpr;
+        local += sad4(org + i * ostride + 4 * g, b + i * rstride + 4 * g);
+      }
+      team_add(&sad[c], local);
+    }
+  } else {
+    for (int it = t.rank; it < ncand * nit; it += t.size) {
+      int c = it / nit, r = it - c * nit;
+      int i = r / gpr, g = r - i * gpr;
+      team_add(&sad[c], sad4(org + i * ostride + 4 * g, base(c) + i * rstride + 4 * g));
+    }
+  }
+  t.sync();
+}
+
 struct MeArgs {
   int cb_size;           // `size` argument of motion_estimate = CB size
   int ostride;           // stride of the original-sample block
@@ -103,9 +143,9 @@ TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const 
   unsigned min_sad = kCostInit;
   mv_t mv_opt = mk_mv(0, 0);
   mv_t mv_ref = mk_mv(((mvc.x + 2) >> 2) << 2, ((mvc.y + 2) >> 2) << 2);
-  auto fullpel = [&](int c, int i, int j) -> int {
+  auto fullpel = [&](int c) -> const PIX* {
     mv_t m = w->cmv[c];
-    return (int)ref[(i + s * (m.y >> 2)) * a.rstride + j + s * (m.x >> 2)];
+    return ref + (s * (m.y >> 2)) * a.rstride + s * (m.x >> 2);
   };
 
   // --- telescope (encode_block.c:529-561)
@@ -126,7 +166,7 @@ TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const 
     }
     n = step < 32 ? 24 : 25;
     t.sync();
-    sad_many(t, w->sad, n, org, a.ostride, a.width, a.height, fullpel);
+    sad_many_ptr(t, w->sad, n, org, a.ostride, a.width, a.height, a.rstride, fullpel);
     for (int c = t.rank; c < n; c += t.size) {
       mv_t m = w->cmv[c];
       w->cost[c] = ((unsigned)w->sad[c] >> sh) + mv_cost(a.lam, m.y - mvp.y, m.x - mvp.x);
@@ -148,15 +188,15 @@ TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const 
       }
       t.sync();
       if (wide) {
-        auto widepel = [&](int c5, int i, int j) -> int {
+        auto widepel = [&](int c5) -> const PIX* {
           int c = c5 / 5, o = c5 - c * 5;
           int off = o == 0 ? -3 : o == 1 ? -1 : o == 2 ? 0 : o == 3 ? 1 : 3;
           mv_t m = w->cmv[c];
-          return (int)ref[(i + s * (m.y >> 2)) * a.rstride + j + s * (m.x >> 2) + off];
+          return ref + (s * (m.y >> 2)) * a.rstride + s * (m.x >> 2) + off;
         };
-        sad_many(t, w->sad, n * 5, org, a.ostride, a.width, a.height, widepel);
+        sad_many_ptr(t, w->sad, n * 5, org, a.ostride, a.width, a.height, a.rstride, widepel);
       } else {
-        sad_many(t, w->sad, n, org, a.ostride, a.width, a.height, fullpel);
+        sad_many_ptr(t, w->sad, n, org, a.ostride, a.width, a.height, a.rstride, fullpel);
       }
       for (int c = t.rank; c < n; c += t.size) {
         mv_t m = w->cmv[c];
@@ -195,7 +235,7 @@ TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const 
                             a.cb_size, a.cb_size, a.sign);
       }
       t.sync();
-      sad_many(t, w->sad, n, org, a.ostride, a.width, a.height, fullpel);
+      sad_many_ptr(t, w->sad, n, org, a.ostride, a.width, a.height, a.rstride, fullpel);
       for (int c = t.rank; c < n; c += t.size) {
         mv_t m = w->cmv[c];
         w->cost[c] = ((unsigned)w->sad[c] >> sh) + mv_cost(a.lam, m.y - mvp.y, m.x - mvp.x);

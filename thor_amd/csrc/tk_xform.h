@@ -20,18 +20,42 @@
 namespace tk {
 
 struct XformWs {
-  int16_t in[32 * 32];    // (down-scaled) residual fed to the core transform
-  int16_t tmp[16 * 32];   // stage-1 output, [coef i][sample j]
+  int16_t in[32 * 32];    // (down-scaled) residual fed to the core transform, TRANSPOSED: in[col*size1 + row]
+  int16_t tmp[16 * 32];   // stage-1 output, [row j][coef i] (stride qsize)
   int16_t coef[16 * 16];  // forward coefficients, compact
   int16_t rcoef[16 * 16]; // de-quantised coefficients, compact
   int16_t itmp[16 * 32];  // inverse stage-1, [coef col i][sample j]
   int flag;               // team-shared scalar result
   long long* prof;        // cycle counters (THOR_PROF builds)
+  // team-local copies of the constant tables (LDS on the GPU): DCT bases, their transposes, scans
+  int16_t dct[16 + 64 + 256 + 1024];
+  int16_t dctT[16 + 64 + 256 + 1024];
+  int16_t izz[16 + 64 + 256];
 };
 
-TK_DEV const int16_t* dct_matrix(int n) {
-  return n == 4 ? TK_TAB.dct4 : n == 8 ? TK_TAB.dct8 : n == 16 ? TK_TAB.dct16 : TK_TAB.dct32;
+TK_DEV int dct_off(int n) { return n == 4 ? 0 : n == 8 ? 16 : n == 16 ? 80 : 336; }
+TK_DEV const int16_t* dct_matrix(const XformWs* ws, int n) { return ws->dct + dct_off(n); }
+TK_DEV const int16_t* dct_matrixT(const XformWs* ws, int n) { return ws->dctT + dct_off(n); }
+TK_DEV const int16_t* izz_table(const XformWs* ws, int qsize) { return ws->izz + (qsize == 4 ? 0 : qsize == 8 ? 16 : 80); }
+// Fill the team-local tables (call once per team before any transform).
+TK_DEV void xform_tables_init(const Team& t, XformWs* ws) {
+  for (int n = 4; n <= 32; n *= 2) {
+    const int16_t* M = n == 4 ? TK_TAB.dct4 : n == 8 ? TK_TAB.dct8 : n == 16 ? TK_TAB.dct16 : TK_TAB.dct32;
+    int16_t* d = ws->dct + dct_off(n);
+    int16_t* dT = ws->dctT + dct_off(n);
+    for (int k = t.rank; k < n * n; k += t.size) {
+      int i = k / n, j = k - i * n;
+      d[k] = M[k];
+      dT[j * n + i] = M[k];
+    }
+  }
+  for (int k = t.rank; k < 16; k += t.size) ws->izz[k] = TK_TAB.izz4[k];
+  for (int k = t.rank; k < 64; k += t.size) ws->izz[16 + k] = TK_TAB.izz8[k];
+  for (int k = t.rank; k < 256; k += t.size) ws->izz[80 + k] = TK_TAB.izz16[k];
+  t.sync();
 }
+
+TK_DEV void fwd_core(const Team& t, XformWs* ws, int size1, int qsize, int shift_1);
 
 // Forward transform of (org - pred) -> ws->coef (qsize x qsize compact).
 template <typename PIX>
@@ -57,53 +81,41 @@ TK_DEV void fwd_transform(const Team& t, XformWs* ws, const PIX* org, int ostrid
           sum = clampi((int16_t)sum + r, -16384, 16383);
         }
     }
-    ws->in[k] = (int16_t)sum;
+    ws->in[j * size1 + i] = (int16_t)sum;  // transposed store: conflict-free column reads in stage 1
   }
   t.sync();
-  const int16_t* M = dct_matrix(size1);
-  const int shift_1 = ilog2(size) + ilog2(scale) + bitdepth - 8;
+  fwd_core(t, ws, size1, qsize, ilog2(size) + ilog2(scale) + bitdepth - 8);
+}
+
+// Core 2-D transform of the (transposed) size1 x size1 block in ws->in -> ws->coef (qsize x qsize).
+// Stage 1 (rows):   tmp[j][i] = (sum_q M[i][q] * in[j][q] + add1) >> shift1   -> stored [row j][coef i]
+// Stage 2 (cols):   coef[i][j] = (sum_q M[i][q] * tmp[q][j] + add2) >> shift2
+// Lane mappings are chosen so that every LDS access is either consecutive across lanes or a broadcast.
+TK_DEV void fwd_core(const Team& t, XformWs* ws, int size1, int qsize, int shift_1) {
+  const int16_t* M = dct_matrix(ws, size1);
+  const int16_t* MT = dct_matrixT(ws, size1);
   const int add_1 = 1 << (shift_1 - 1);
   const int shift_2 = ilog2(size1) + 5;
   const int add_2 = 1 << (shift_2 - 1);
   for (int k = t.rank; k < qsize * size1; k += t.size) {
-    int i = k / size1, j = k - i * size1;
+    int j = k / qsize, i = k - j * qsize;  // i (coefficient) fastest
     int sum = 0;
-    for (int q = 0; q < size1; q++) sum += M[i * size1 + q] * ws->in[j * size1 + q];
-    ws->tmp[i * size1 + j] = (int16_t)((sum + add_1) >> shift_1);
+    for (int q = 0; q < size1; q++) sum += MT[q * size1 + i] * ws->in[q * size1 + j];
+    ws->tmp[j * qsize + i] = (int16_t)((sum + add_1) >> shift_1);
   }
   t.sync();
   for (int k = t.rank; k < qsize * qsize; k += t.size) {
     int i = k / qsize, j = k - i * qsize;
     int sum = 0;
-    for (int q = 0; q < size1; q++) sum += M[i * size1 + q] * ws->tmp[j * size1 + q];
+    for (int q = 0; q < size1; q++) sum += M[i * size1 + q] * ws->tmp[q * qsize + j];
     ws->coef[i * qsize + j] = (int16_t)((sum + add_2) >> shift_2);
   }
   t.sync();
 }
 
-// Same core transform but on an explicit int16 input block (early-skip path).
+// Same core transform on an explicit int16 block already stored TRANSPOSED in ws->in (early skip).
 TK_DEV void fwd_transform_block(const Team& t, XformWs* ws, int size, int bitdepth) {
-  // ws->in holds size x size (size <= 16) already; fast = 0, no scaling.
-  const int qsize = size;
-  const int16_t* M = dct_matrix(size);
-  const int shift_1 = ilog2(size) + bitdepth - 8;
-  const int add_1 = 1 << (shift_1 - 1);
-  const int shift_2 = ilog2(size) + 5;
-  const int add_2 = 1 << (shift_2 - 1);
-  for (int k = t.rank; k < qsize * size; k += t.size) {
-    int i = k / size, j = k - i * size;
-    int sum = 0;
-    for (int q = 0; q < size; q++) sum += M[i * size + q] * ws->in[j * size + q];
-    ws->tmp[i * size + j] = (int16_t)((sum + add_1) >> shift_1);
-  }
-  t.sync();
-  for (int k = t.rank; k < qsize * qsize; k += t.size) {
-    int i = k / qsize, j = k - i * qsize;
-    int sum = 0;
-    for (int q = 0; q < size; q++) sum += M[i * size + q] * ws->tmp[j * size + q];
-    ws->coef[i * qsize + j] = (int16_t)((sum + add_2) >> shift_2);
-  }
-  t.sync();
+  fwd_core(t, ws, size, size, ilog2(size) + bitdepth - 8);
 }
 
 // quantize (encode_block.c:84-160), serial zigzag state machine. Returns cbp (0/1).
@@ -144,12 +156,57 @@ TK_DEV int quantize_serial(const int16_t* coef, int16_t* coefq, int qp, int size
   return cbp;
 }
 
+// Same function as quantize_serial, evaluated W = team.size scan positions at a time.
+// The level_mode state is a 2-state automaton whose per-coefficient transition is one of
+// {identity, ->0, ->1} (never a swap, because the level under mode 1 is >= the level under mode 0),
+// so the state entering a position is the target of the nearest earlier constant transition; a
+// ballot + count-leading-zeros finds it.  With W = 1 this is literally the serial loop.
 TK_DEV int quantize_team(const Team& t, XformWs* ws, int16_t* coefq, int qp, int size, int intra_block) {
-  if (t.rank == 0) ws->flag = quantize_serial(ws->coef, coefq, qp, size, intra_block);
+  const int qsize = size < kMaxQuant ? size : kMaxQuant;
+  const int N = qsize * qsize;
+  const int16_t* izz = izz_table(ws, qsize);
+  const int scale = quant_scale(qp % 6);
+  const int shift2 = 21 - ilog2(size) + qp / 6;
+  const int offl = intra_block ? (38 << (shift2 - 8)) : -(26 << (shift2 - 8));
+  const int off0 = (intra_block ? 102 : 51) << (shift2 - 8);
+  const int off1 = (intra_block ? 115 : 90) << (shift2 - 8);
+  const int W = t.size;
+  // last_pos: highest position whose level under the "last position" offset is non-zero
+  int last_pos = -1;
+  for (int base = 0; base < N; base += W) {
+    const int p = base + t.rank;
+    int nz = 0;
+    if (p < N) {
+      int l = iabs((int)ws->coef[izz[p]]) * scale + offl;
+      nz = ((l > 0 ? l : -l) >> shift2) != 0;
+    }
+    const unsigned long long m = team_ballot(t, nz);
+    if (m) last_pos = base + top_set(m);
+  }
+  int carry = 1, cbp = 0;
+  for (int base = 0; base < N; base += W) {
+    const int p = base + t.rank;
+    const int active = p < N && p <= last_pos;
+    int c = 0, lev0 = 0, lev1 = 0;
+    if (active) {
+      c = ws->coef[izz[p]];
+      const int ac = scale * iabs(c);
+      const int level0 = ac >> shift2;
+      lev1 = (ac + (level0 > 0 ? off1 : off0)) >> shift2;   // level_mode == 1
+      lev0 = (ac + (level0 > 1 ? off1 : off0)) >> shift2;   // level_mode == 0
+    }
+    const int to0 = active && lev1 == 0, to1 = active && lev0 > 1;
+    const unsigned long long mK = team_ballot(t, to0 || to1), mV = team_ballot(t, to1);
+    const int j = prev_set(mK, t.rank);
+    const int mode = j < 0 ? carry : (int)((mV >> j) & 1ull);
+    const int lev = mode ? lev1 : lev0;
+    if (p < N) coefq[izz[p]] = (int16_t)(c < 0 ? -lev : lev);
+    cbp |= team_ballot(t, active && lev != 0) != 0ull;
+    const int jj = top_set(mK);
+    if (jj >= 0) carry = (int)((mV >> jj) & 1ull);
+  }
   t.sync();
-  int r = ws->flag;
-  t.sync();
-  return r;
+  return cbp;
 }
 
 // dequantize (common_block.c:45-73): coefq -> ws->rcoef, int16 truncation as in the reference.
@@ -174,7 +231,7 @@ TK_DEV void inv_transform_recon(const Team& t, XformWs* ws, const PIX* pred, int
   const int n = size < 32 ? size : 32;
   const int scale = size / n;
   const int qsize = n < kMaxQuant ? n : kMaxQuant;
-  const int16_t* M = dct_matrix(n);
+  const int16_t* M = dct_matrix(ws, n);
   const int shift_2 = 20 - bitdepth, add_2 = 1 << (shift_2 - 1);
   // stage 1: itmp[i*n + j] = clip((sum_k M[k][j]*rcoef[k][i] + 64) >> 7)   i < qsize, j < n
   for (int k = t.rank; k < qsize * n; k += t.size) {

@@ -20,7 +20,7 @@ static double now_s(void) {
 int main(int argc, char** argv) {
   thor_hip_params p;
   const char *inf = NULL, *of = NULL, *rf = NULL;
-  int n = 600, skip = 0, S = 1, i;
+  int n = 600, skip = 0, S = 1, i, wrap = 0;
   thor_hip_params_from_config(&p, NULL);
   /* config files first, explicit options afterwards (same precedence as the reference) */
   for (i = 1; i + 1 < argc; i += 2)
@@ -34,6 +34,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(k, "-n")) n = atoi(v);
     else if (!strcmp(k, "-skip")) skip = atoi(v);
     else if (!strcmp(k, "-streams")) S = atoi(v);
+    else if (!strcmp(k, "-wrap")) wrap = atoi(v); /* clip length: frame index taken modulo this (throughput tests) */
     else thor_hip_params_set(&p, k, v);
   }
   if (!inf) { fprintf(stderr, "usage: %s -cf cfg -if in.yuv -width W -height H -qp Q -n N ...\n", argv[0]); return 2; }
@@ -46,6 +47,7 @@ int main(int argc, char** argv) {
   for (int s = 0; s < S; s++)
     for (int f = 0; f < n; f++) {
       size_t idx = (size_t)skip + (size_t)s * n + f;
+      if (wrap > 0) idx %= (size_t)wrap;
       if (fseek(fi, (long)(idx * fsz), SEEK_SET) || fread(frame, 1, fsz, fi) != fsz) { fprintf(stderr, "short read at frame %zu\n", idx); return 4; }
       thor_hip_stage_frame(e, s, f, frame);
     }
