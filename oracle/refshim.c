@@ -1,0 +1,23 @@
+/* refshim.c - TEST INFRASTRUCTURE.  Compiled only by oracle/Makefile (target reflib) when the
+ * reference tree is present.  It #includes the reference's enc/encode_block.c BY PATH (nothing is
+ * copied into this repository) to reach its file-static kernels, and exports thin wrappers so that
+ * tests/golden/gen_kat.py can record known-answer vectors from the real reference code. */
+#define STR2(x) #x
+#define STR(x) STR2(x)
+#include STR(REFDIR/enc/encode_block.c)
+#include "simd.h"
+
+void ref_init(int simd) { use_simd = simd; }
+unsigned ref_sad_calc(uint8_t* a, uint8_t* b, int astride, int bstride, int w, int h) { return sad_calc(a, b, astride, bstride, w, h); }
+int ref_quantize(int16_t* coeff, int16_t* coeffq, int qp, int size, int coeff_block_type) {
+  return quantize(coeff, coeffq, qp, size, coeff_block_type, NULL);
+}
+int ref_quote_mv_bits(int dy, int dx) { return quote_mv_bits(dy, dx); }
+/* bit length of write_coeff (enc/write_bits.c:145) for one coefficient block */
+int ref_coeff_bits(int16_t* coeff, int size, int type) {
+  static uint8_t buf[1 << 16];
+  stream_t s;
+  s.bytesize = sizeof buf; s.bytepos = 0; s.bitstream = buf; s.bitbuf = 0; s.bitrest = 32;
+  write_coeff(&s, coeff, size, type);
+  return get_bit_pos(&s);
+}

@@ -1,0 +1,278 @@
+/* thor_oracle.c - TEST INFRASTRUCTURE (never linked into, imported or called by the product).
+ *
+ * Plain-C restatement of the reference's kernel-level arithmetic on the per-block encode path,
+ * used as the checker for the kernel-level entry points of libthor_hip.so (tests/ and
+ * __graft_entry__.smoke()).  Every function cites the reference code it follows.  The restatement
+ * is pinned: tests/test_oracle_c.py checks it against known-answer vectors recorded from the real
+ * reference functions (tests/golden/kat.npz, produced by tests/golden/gen_kat.py through
+ * oracle/_ref/libthorref.so), and, when /root/reference is present, against the live reference.
+ * The frame-level oracle is the reference encoder itself (oracle/_ref/Thorenc).
+ *
+ * 8-bit samples, 4:2:0.  Build: gcc -O2 -std=c99 -fPIC -shared -ffp-contract=off
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static int ilog2(unsigned v) { int n = 0; while (v >>= 1) n++; return n; }
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+/* ---- SAD: sad_calc, enc/encode_block.c:417-428 ----------------------------------------- */
+unsigned orc_sad(const uint8_t* a, int astride, const uint8_t* b, int bstride, int w, int h) {
+  unsigned s = 0;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) s += (unsigned)abs((int)a[y * astride + x] - (int)b[y * bstride + x]);
+  return s;
+}
+
+/* ---- ME bit estimate: quote_mv_bits, enc/encode_block.c:467-515 ------------------------ */
+static int mvlen(int d) {
+  d = abs(d);
+  if (d < 1) return 2;
+  if (d < 2) return 4;
+  if (d < 4) return 5;
+  if (d < 36) return 6 + ((d - 4) >> 3);
+  return 11 + ((d - 36) >> 4);
+}
+int orc_quote_mv_bits(int dy, int dx) { return mvlen(dx) + mvlen(dy); }
+
+/* ---- quarter-pel luma prediction: get_inter_prediction_luma, common/inter_prediction.c:117-181,
+ *      taps common/common_kernels.c:1905-1917.  ref points at the block's co-located sample. ---- */
+static const int TAPS_STD[4][6] = {{0, 0, 64, 0, 0, 0}, {1, -7, 55, 19, -5, 1}, {1, -7, 38, 38, -7, 1}, {1, -5, 19, 55, -7, 1}};
+static const int TAPS_BI[4][6] = {{0, 0, 64, 0, 0, 0}, {2, -10, 59, 17, -5, 1}, {1, -8, 39, 39, -8, 1}, {1, -5, 17, 59, -10, 2}};
+void orc_interp_luma(uint8_t* dst, int dstride, const uint8_t* ref, int rstride, int w, int h, int mvx, int mvy, int sign,
+                     int bipred, int pic_w, int pic_h, int xpos, int ypos) {
+  if (sign) { mvx = -mvx; mvy = -mvy; }
+  int fy = mvy & 3, fx = mvx & 3, iy = mvy >> 2, ix = mvx >> 2;
+  if (iy > pic_h - ypos) iy = pic_h - ypos;
+  if (iy < -xpos - h) iy = -xpos - h; /* sic: xpos, inter_prediction.c:129 */
+  if (ix > pic_w - xpos) ix = pic_w - xpos;
+  if (ix < -xpos - w) ix = -xpos - w;
+  const int(*T)[6] = bipred ? TAPS_BI : TAPS_STD;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      const uint8_t* p = ref + (y + iy) * rstride + x + ix;
+      int v;
+      if (!fx && !fy) v = p[0];
+      else if (fx == 2 && fy == 2 && bipred < 2) {
+        int s = p[-rstride] + p[-rstride + 1] + p[-1] + 2 * p[0] + 2 * p[1] + p[2] + p[rstride - 1] + 2 * p[rstride] +
+                2 * p[rstride + 1] + p[rstride + 2] + p[2 * rstride] + p[2 * rstride + 1];
+        v = clampi((s + 8) >> 4, 0, 255);
+      } else {
+        int acc = 0;
+        for (int n = 0; n < 6; n++) {
+          int col = 0;
+          for (int m = 0; m < 6; m++) col += T[fy][m] * p[(m - 2) * rstride + n - 2];
+          acc += T[fx][n] * col;
+        }
+        v = clampi((acc + 2048) >> 12, 0, 255);
+      }
+      dst[y * dstride + x] = (uint8_t)v;
+    }
+}
+
+/* ---- HEVC-style integer DCT bases (common/transform.c:37-241) generated from the cosine table --- */
+static int hevc_cos(int k) {
+  static const int mag[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                              61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9,  4,  0};
+  k &= 127;
+  if (k <= 32) return mag[k];
+  if (k <= 64) return -mag[64 - k];
+  if (k <= 96) return -mag[k - 64];
+  return mag[128 - k];
+}
+static int dctm(int n, int i, int j) { return hevc_cos(i * (2 * j + 1) * (32 / n)); }
+
+/* forward transform: transform(), common/transform.c:245-309.  block: size x size residual,
+ * coeff: compact q x q (q = min(size,16)). */
+void orc_fwd_transform(const int16_t* block, int16_t* coeff, int size, int fast, int bitdepth) {
+  int q = size < 16 ? size : 16, size1 = size, scale = 1;
+  int16_t* in = (int16_t*)malloc(sizeof(int16_t) * 32 * 32);
+  int16_t* tmp = (int16_t*)malloc(sizeof(int16_t) * 16 * 32);
+  if (size > (32 >> fast)) {
+    size1 = 32 >> fast;
+    scale = size / size1;
+    for (int i = 0; i < size1; i++)
+      for (int j = 0; j < size1; j++) {
+        int16_t s = 0;
+        for (int m = 0; m < scale; m++)
+          for (int n = 0; n < scale; n++) s = (int16_t)clampi(s + block[(i * scale + m) * size + j * scale + n], -16384, 16383);
+        in[i * size1 + j] = s;
+      }
+  } else
+    memcpy(in, block, sizeof(int16_t) * size * size);
+  int sh1 = ilog2(size) + ilog2(scale) + bitdepth - 8, sh2 = ilog2(size1) + 5;
+  for (int i = 0; i < q; i++)
+    for (int j = 0; j < size1; j++) {
+      int s = 0;
+      for (int k = 0; k < size1; k++) s += dctm(size1, i, k) * in[j * size1 + k];
+      tmp[i * size1 + j] = (int16_t)((s + (1 << (sh1 - 1))) >> sh1);
+    }
+  for (int i = 0; i < q; i++)
+    for (int j = 0; j < q; j++) {
+      int s = 0;
+      for (int k = 0; k < size1; k++) s += dctm(size1, i, k) * tmp[j * size1 + k];
+      coeff[i * q + j] = (int16_t)((s + (1 << (sh2 - 1))) >> sh2);
+    }
+  free(in);
+  free(tmp);
+}
+
+/* zigzag scan position of (i,j) in an n x n block (common/common_tables.c:29-66) */
+static void zigzag(int n, int* zz) {
+  int idx = 0;
+  for (int d = 0; d <= 2 * (n - 1); d++)
+    for (int t = 0; t < n; t++) {
+      int i = (d & 1) ? t : n - 1 - t, j = d - i;
+      if (j < 0 || j >= n) continue;
+      zz[i * n + j] = idx++;
+    }
+}
+
+static const int QSCALE[6] = {26214, 23302, 20560, 18396, 16384, 14564};
+static const int DQSCALE[6] = {40, 45, 51, 57, 64, 72};
+
+/* quantize(), enc/encode_block.c:84-160 (no weight matrix).  coeff/coeffq compact q x q. */
+int orc_quantize(const int16_t* coeff, int16_t* coeffq, int qp, int size, int intra_block) {
+  int q = size < 16 ? size : 16, N = q * q, zz[256], sc[256], sq[256];
+  zigzag(q, zz);
+  int64_t scale = QSCALE[qp % 6];
+  int shift2 = 21 - ilog2(size) + qp / 6;
+  for (int i = 0; i < N; i++) { sc[zz[i]] = coeff[i]; sq[i] = 0; }
+  int64_t off = (intra_block ? 38 : -26) * ((int64_t)1 << (shift2 - 8));
+  int level = 0, pos = N - 1;
+  while (level == 0 && pos >= 0) {
+    int64_t l = (int64_t)abs(sc[pos]) * scale + off;
+    level = (int)((l > 0 ? l : -l) >> shift2);
+    pos--;
+  }
+  int last = level ? pos + 1 : pos, cbp = 0, level_mode = 1;
+  int64_t o0 = (int64_t)(intra_block ? 102 : 51) << (shift2 - 8), o1 = (int64_t)(intra_block ? 115 : 90) << (shift2 - 8);
+  for (pos = 0; pos <= last; pos++) {
+    int c = sc[pos];
+    int64_t ac = scale * abs(c);
+    int l0 = (int)(ac >> shift2);
+    int lev = (int)((ac + ((l0 > (1 - level_mode)) ? o1 : o0)) >> shift2);
+    sq[pos] = c < 0 ? -lev : lev;
+    cbp |= lev != 0;
+    if (level_mode) { if (lev == 0) level_mode = 0; } else if (lev > 1) level_mode = 1;
+  }
+  for (int i = 0; i < N; i++) coeffq[i] = (int16_t)sq[zz[i]];
+  return cbp;
+}
+
+/* dequantize(), common/common_block.c:45-73 (compact in, compact out) */
+void orc_dequantize(const int16_t* coeffq, int16_t* rcoeff, int qp, int size) {
+  int q = size < 16 ? size : 16, ls = qp / 6, rs = ilog2(size) - 1;
+  int64_t scale = DQSCALE[qp % 6];
+  for (int i = 0; i < q * q; i++) {
+    int64_t c = coeffq[i];
+    rcoeff[i] = ls >= rs ? (int16_t)((c * scale) * ((int64_t)1 << (ls - rs))) : (int16_t)((c * scale + ((int64_t)1 << (rs - ls - 1))) >> (rs - ls));
+  }
+}
+
+/* inverse_transform(), common/transform.c:411-494: rcoeff compact q x q -> block size x size */
+void orc_inv_transform(const int16_t* rcoeff, int16_t* block, int size, int bitdepth) {
+  int n = size < 32 ? size : 32, scale = size / n, q = n < 16 ? n : 16, sh2 = 20 - bitdepth;
+  int16_t* tmp = (int16_t*)malloc(sizeof(int16_t) * 16 * 32);
+  for (int i = 0; i < q; i++)
+    for (int j = 0; j < n; j++) {
+      int s = 0;
+      for (int k = 0; k < q; k++) s += dctm(n, k, j) * rcoeff[k * q + i];
+      tmp[i * n + j] = (int16_t)clampi((s + 64) >> 7, -32768, 32767);
+    }
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) {
+      int s = 0;
+      for (int k = 0; k < q; k++) s += dctm(n, k, j) * tmp[k * n + i];
+      int r = clampi((s + (1 << (sh2 - 1))) >> sh2, -32768, 32767);
+      for (int m = 0; m < scale; m++)
+        for (int x = 0; x < scale; x++) block[(scale * i + m) * size + scale * j + x] = (int16_t)r;
+    }
+  free(tmp);
+}
+
+/* One transform unit end to end (encode_and_reconstruct_block_inter non-split branch,
+ * enc/encode_block.c:1319-1330): residual, T, Q, IQ, IT, reconstruct_block (common_block.c:75-84).
+ * coeff_type bit1 = intra-frame flag. Returns cbp; coefq compact. */
+int orc_code_tu(const uint8_t* org, const uint8_t* pred, int size, int qp, int coeff_type, int fast, int16_t* coefq, uint8_t* rec) {
+  int n2 = size * size;
+  int16_t* res = (int16_t*)malloc(sizeof(int16_t) * n2);
+  int16_t* rb = (int16_t*)malloc(sizeof(int16_t) * n2);
+  int16_t co[256], rc[256];
+  for (int i = 0; i < n2; i++) res[i] = (int16_t)((int)org[i] - (int)pred[i]);
+  orc_fwd_transform(res, co, size, fast, 8);
+  int cbp = orc_quantize(co, coefq, qp, size, (coeff_type >> 1) & 1);
+  if (cbp) {
+    orc_dequantize(coefq, rc, qp, size);
+    orc_inv_transform(rc, rb, size, 8);
+    for (int i = 0; i < n2; i++) rec[i] = (uint8_t)clampi(rb[i] + pred[i], 0, 255);
+  } else
+    memcpy(rec, pred, n2);
+  free(res);
+  free(rb);
+  return cbp;
+}
+
+/* ---- VLC lengths (enc/putvlc.c:73-160) and write_coeff bit count (enc/write_bits.c:145-241) ---- */
+static int vlc_len(int n, unsigned cn) {
+  if (n == 6 || n == 7) {
+    if (cn == 0) return 2;
+    if (n == 6) { cn++; n = 2; }
+    else {
+      if (cn == 1) return 3;
+      if (cn < 4) return 4;
+      cn += 4; n = 3;
+    }
+  }
+  if (n <= 5) {
+    unsigned t = 1u << n;
+    if (cn < 5 * t) return 1 + n + (int)(cn >> n);
+    return (5 - n) + 1 + 2 * ilog2(cn - 5 * t + t);
+  }
+  if (n == 8) return cn < 6 ? 2 + (int)(cn >> 1) : 5;
+  if (n == 10) return 1 + 2 * ilog2(cn + 1);
+  return cn == (unsigned)(n - 10) ? n - 10 : (int)cn + 1;
+}
+int orc_coeff_bits(const int16_t* coeff, int size, int type) {
+  int q = size < 16 ? size : 16, N = q * q, zz[256], s[256], bits = 0;
+  zigzag(q, zz);
+  for (int i = 0; i < N; i++) s[zz[i]] = coeff[i];
+  int chroma = type & 1, intra = (type >> 1) & 1, adaptive = intra && !chroma;
+  unsigned eob = chroma ? 0 : 2;
+  int runtab = (chroma && size <= 8) ? 10 : 6;
+  int last = N - 1;
+  while (last > 0 && !s[last]) last--;
+  int pos = 0;
+  if (chroma) {
+    if (last == 0 && abs(s[0]) == 1) return 2;
+    bits += 1;
+  }
+  int level_mode = 1, level = 1, c;
+  while (pos <= last) {
+    if (level_mode)
+      while (pos <= last && level > 0) {
+        c = s[pos++];
+        level = abs(c);
+        bits += vlc_len(adaptive, (unsigned)level) + (level > 0);
+        if (!chroma) adaptive = level > 3;
+      }
+    int run = 0;
+    c = 0;
+    while (c == 0 && pos <= last) {
+      c = s[pos++];
+      run += !c;
+      if (c) {
+        level = abs(c);
+        unsigned cn = level == 1 ? (unsigned)(run * 5 / 4) : (unsigned)(run * 5 + 4);
+        bits += vlc_len(runtab, cn + (cn >= eob));
+        level_mode = level > 1;
+        bits += level > 1 ? vlc_len(0, (unsigned)((level - 2) * 2 + (c < 0))) : 1;
+        run = 0;
+      }
+    }
+  }
+  if (pos < N && level_mode) { bits += vlc_len(adaptive, 0); pos++; }
+  if (pos < N) bits += vlc_len(runtab, eob);
+  return bits;
+}

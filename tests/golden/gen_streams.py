@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Record golden stream / reconstruction hashes from the reference encoder (oracle/_ref/Thorenc) for
+the small committed clips.  Run in the build container after `make -C oracle`; output
+tests/golden/streams.json is committed and is what the GPU tests / smoke() compare with."""
+import gzip, hashlib, json, os, subprocess, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+G = os.path.join(ROOT, 'tests', 'golden')
+CASES = {
+    '192x128_n3_q32': ('clip_192x128_6.yuv.gz', 192, 128, 3, 32, []),
+    '192x128_n6_q32': ('clip_192x128_6.yuv.gz', 192, 128, 6, 32, []),
+    '192x128_n6_q24': ('clip_192x128_6.yuv.gz', 192, 128, 6, 24, []),
+    '192x128_n4_q44': ('clip_192x128_6.yuv.gz', 192, 128, 4, 44, []),
+    '192x128_n3_q32_skip3': ('clip_192x128_6.yuv.gz', 192, 128, 3, 32, ['-skip', '3']),
+    '208x120_n4_q32': ('clip_208x120_4.yuv.gz', 208, 120, 4, 32, []),
+    '208x120_n4_q36_nocdef': ('clip_208x120_4.yuv.gz', 208, 120, 4, 36, ['-cdef', '0']),
+}
+out = {}
+with tempfile.TemporaryDirectory() as d:
+    for name, (clip, w, h, n, qp, extra) in CASES.items():
+        raw = gzip.open(os.path.join(G, clip)).read()
+        open(os.path.join(d, 'in.yuv'), 'wb').write(raw)
+        log = subprocess.run([os.path.join(ROOT, 'oracle/_ref/Thorenc'), '-cf', os.path.join(ROOT, 'configs/ldb_high_efficiency.cfg'),
+                              '-if', os.path.join(d, 'in.yuv'), '-width', str(w), '-height', str(h), '-qp', str(qp), '-n', str(n),
+                              '-f', '30', '-of', os.path.join(d, 'o.bit'), '-rf', os.path.join(d, 'o.yuv')] + extra,
+                             check=True, capture_output=True, text=True).stdout
+        frames = [l.split()[:4] for l in log.splitlines() if len(l.split()) > 4 and l.split()[1] in 'IPB']
+        out[name] = {'clip': clip, 'w': w, 'h': h, 'n': n, 'qp': qp, 'extra': extra,
+                     'bit_md5': hashlib.md5(open(os.path.join(d, 'o.bit'), 'rb').read()).hexdigest(),
+                     'rec_md5': hashlib.md5(open(os.path.join(d, 'o.yuv'), 'rb').read()).hexdigest(),
+                     'bit_bytes': os.path.getsize(os.path.join(d, 'o.bit')), 'frames': frames}
+json.dump(out, open(os.path.join(G, 'streams.json'), 'w'), indent=1)
+print('wrote', len(out), 'cases')

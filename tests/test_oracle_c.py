@@ -1,0 +1,61 @@
+"""The oracle's C restatement (oracle/thor_oracle.c) is pinned against known-answer vectors recorded
+from the REAL reference functions (tests/golden/kat.npz <- tests/golden/gen_kat.py)."""
+import ctypes as C
+import os
+import numpy as np
+import pytest
+from util import GOLD, build_oracle_c, vp
+
+K = np.load(os.path.join(GOLD, 'kat.npz'))
+O = build_oracle_c()
+
+
+def test_sad():
+    plane = K['sad_plane']
+    for i in range(7):
+        org, cand, want = K[f'sad_org{i}'], K[f'sad_cand{i}'], K[f'sad_out{i}']
+        h, w = org.shape
+        got = [O.orc_sad(vp(org), w, C.c_void_p(int(plane.ctypes.data) + (12 + int(dy)) * 96 + 12 + int(dx)), 96, w, h) for dx, dy in cand]
+        assert (np.array(got, dtype=np.uint32) == want).all()
+
+
+def test_quote_mv_bits():
+    got = [O.orc_quote_mv_bits(int(a), int(b)) for a, b in K['mvb_in']]
+    assert (np.array(got) == K['mvb_out']).all()
+
+
+def test_interp_luma():
+    ref = np.ascontiguousarray(K['ip_ref'])
+    pad, pw, ph = 16, 64, 48
+    k = 0
+    while f'ip_geo{k}' in K:
+        w, h, bx, by, bip = [int(v) for v in K[f'ip_geo{k}']]
+        for i, (mx, my) in enumerate(K[f'ip_mv{k}']):
+            out = np.zeros((h, w), dtype=np.uint8)
+            base = int(ref.ctypes.data) + (pad + by) * ref.shape[1] + pad + bx
+            O.orc_interp_luma(vp(out), w, C.c_void_p(base), ref.shape[1], w, h, int(mx), int(my), 0, bip, pw, ph, bx, by)
+            assert (out == K[f'ip_out{k}'][i]).all(), (k, i)
+        k += 1
+    assert k == 8
+
+
+def test_tu_pipeline_and_coeff_bits():
+    k = 0
+    while f'tu_par{k}' in K:
+        size, qp, ctype, fast = [int(v) for v in K[f'tu_par{k}']]
+        org, pred = K[f'tu_org{k}'], K[f'tu_pred{k}']
+        q = min(size, 16)
+        for i in range(org.shape[0]):
+            res = (org[i].astype(np.int16) - pred[i].astype(np.int16))
+            fwd = np.zeros((q, q), dtype=np.int16)
+            O.orc_fwd_transform(vp(np.ascontiguousarray(res)), vp(fwd), size, fast, 8)
+            assert (fwd == K[f'tu_fwd{k}'][i]).all(), ('fwd', k, i)
+            cq = np.zeros((q, q), dtype=np.int16); rec = np.zeros((size, size), dtype=np.uint8)
+            cbp = O.orc_code_tu(vp(np.ascontiguousarray(org[i])), vp(np.ascontiguousarray(pred[i])), size, qp, ctype, fast, vp(cq), vp(rec))
+            assert cbp == K[f'tu_cbp{k}'][i]
+            assert (cq == K[f'tu_coefq{k}'][i]).all(), ('coefq', k, i)
+            assert (rec == K[f'tu_rec{k}'][i]).all(), ('rec', k, i)
+            if cbp:
+                assert O.orc_coeff_bits(vp(cq), size, ctype) == K[f'tu_bits{k}'][i], ('bits', k, i)
+        k += 1
+    assert k == 24

@@ -1,0 +1,31 @@
+"""Pins the frame-level oracle: the reference encoder built by oracle/Makefile reproduces the committed
+golden stream/recon hashes, decodes to its own reconstruction, and the 1-lane host simulation of the
+engine sources (tests/hostsim) produces the identical stream and reconstruction."""
+import os
+import pytest
+from util import (REF_ENC, REF_DEC, golden_streams, golden_clip, run_encoder, decode, md5, build_hostsim)
+
+G = golden_streams()
+needs_ref = pytest.mark.skipif(not os.path.exists(REF_ENC), reason='oracle/_ref not built (make -C oracle)')
+
+
+@needs_ref
+@pytest.mark.parametrize('name', sorted(G))
+def test_reference_reproduces_golden_and_roundtrips(name):
+    c = G[name]
+    bits, rec = run_encoder(REF_ENC, golden_clip(c['clip']), c['w'], c['h'], c['n'], c['qp'], c['extra'])
+    assert md5(bits) == c['bit_md5'] and md5(rec) == c['rec_md5']
+    # the reference's own check.sh property (check.sh:54-75).  NB: with CDEF on, the reference encoder
+    # can shrink cdef_bits when it back-patches the frame header (encode_frame.c:776-782) without moving
+    # the payload, which its own decoder then mis-parses on tiny frames; the property is therefore only
+    # asserted for the CDEF-off case here (and at 1080p in the GPU tests).
+    if '-cdef' in c['extra']:
+        assert decode(bits) == rec
+
+
+@pytest.mark.parametrize('name', ['192x128_n3_q32', '208x120_n4_q32', '192x128_n3_q32_skip3', '192x128_n4_q44'])
+def test_engine_host_simulation_matches_golden(name):
+    c = G[name]
+    bits, rec = run_encoder(build_hostsim(), golden_clip(c['clip']), c['w'], c['h'], c['n'], c['qp'], c['extra'])
+    assert md5(bits) == c['bit_md5'], 'stream differs from the reference'
+    assert md5(rec) == c['rec_md5'], 'reconstruction differs from the reference'

@@ -1,0 +1,70 @@
+"""Shared helpers for the test-suite (test infrastructure; may use oracle/)."""
+import ctypes as C
+import gzip
+import hashlib
+import json
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+CFG = os.path.join(ROOT, 'configs', 'ldb_high_efficiency.cfg')
+REF_ENC = os.path.join(ROOT, 'oracle', '_ref', 'Thorenc')
+REF_DEC = os.path.join(ROOT, 'oracle', '_ref', 'Thordec')
+REF_HIPENC = os.path.join(ROOT, 'oracle', '_ref', 'Thorenc_hip')
+HAVE_REFERENCE_TREE = os.path.exists('/root/reference/enc/mainenc.c')
+
+
+def md5(b):
+    return hashlib.md5(b).hexdigest()
+
+
+def golden_streams():
+    return json.load(open(os.path.join(GOLD, 'streams.json')))
+
+
+def golden_clip(name):
+    return gzip.open(os.path.join(GOLD, name)).read()
+
+
+def build_oracle_c():
+    out = os.path.join(ROOT, 'oracle', 'libthor_oracle.so')
+    src = os.path.join(ROOT, 'oracle', 'thor_oracle.c')
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(['gcc', '-O2', '-std=c99', '-fPIC', '-shared', '-ffp-contract=off', '-o', out, src])
+    return C.CDLL(out)
+
+
+def build_hostsim():
+    """1-lane host simulation of the engine sources (tests only)."""
+    out = os.path.join(ROOT, 'tests', 'hostsim', 'hostsim')
+    src = os.path.join(ROOT, 'tests', 'hostsim', 'hostsim.cpp')
+    csrc = os.path.join(ROOT, 'thor_amd', 'csrc')
+    newest = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc)])
+    if not os.path.exists(out) or os.path.getmtime(out) < newest:
+        subprocess.check_call(['g++', '-std=c++17', '-O2', '-DTHOR_HOSTSIM', '-ffp-contract=off', '-o', out, src])
+    return out
+
+
+def run_encoder(binary, clip_bytes, w, h, n, qp, extra=(), env=None):
+    """Run a Thorenc-compatible CLI (reference, hostsim, thorenc_hip, Thorenc_hip); returns (bits, recon)."""
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, 'in.yuv'), 'wb').write(clip_bytes)
+        cmd = [binary, '-cf', CFG, '-if', os.path.join(d, 'in.yuv'), '-width', str(w), '-height', str(h), '-qp', str(qp),
+               '-n', str(n), '-f', '30', '-of', os.path.join(d, 'o.bit'), '-rf', os.path.join(d, 'o.yuv')] + list(extra)
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, env=env)
+        return open(os.path.join(d, 'o.bit'), 'rb').read(), open(os.path.join(d, 'o.yuv'), 'rb').read()
+
+
+def decode(bits):
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, 's.bit'), 'wb').write(bits)
+        subprocess.run([REF_DEC, os.path.join(d, 's.bit'), os.path.join(d, 'o.yuv')], check=True, stdout=subprocess.DEVNULL)
+        return open(os.path.join(d, 'o.yuv'), 'rb').read()
+
+
+def vp(a):
+    return a.ctypes.data_as(C.c_void_p)

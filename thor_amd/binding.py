@@ -1,0 +1,169 @@
+"""ctypes binding of libthor_hip.so (include/thor_hip.h)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+
+def lib_path():
+    return os.path.join(REPO_ROOT, 'thor_amd', 'libthor_hip.so')
+
+
+def build_native(force=False):
+    """Compile libthor_hip.so (gfx950) and the C front end in-tree with hipcc/gcc."""
+    src = os.path.join(REPO_ROOT, 'thor_amd', 'csrc', 'thor_hip.cpp')
+    out = lib_path()
+    hdrs = [os.path.join(REPO_ROOT, 'thor_amd', 'csrc', f) for f in os.listdir(os.path.join(REPO_ROOT, 'thor_amd', 'csrc'))]
+    hdrs += [os.path.join(REPO_ROOT, 'include', f) for f in os.listdir(os.path.join(REPO_ROOT, 'include'))]
+    newest = max(os.path.getmtime(h) for h in hdrs)
+    if force or not os.path.exists(out) or os.path.getmtime(out) < newest:
+        hipcc = '/opt/rocm/bin/hipcc' if os.path.exists('/opt/rocm/bin/hipcc') else 'hipcc'
+        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
+                               '-o', out, src])
+    tool = os.path.join(REPO_ROOT, 'tools', 'thorenc_hip')
+    tsrc = tool + '.c'
+    if force or not os.path.exists(tool) or os.path.getmtime(tool) < os.path.getmtime(tsrc):
+        subprocess.check_call(['gcc', '-O2', '-std=c99', '-D_POSIX_C_SOURCE=200809L', '-o', tool, tsrc,
+                               '-L' + os.path.join(REPO_ROOT, 'thor_amd'), '-lthor_hip', '-Wl,-rpath,$ORIGIN/../thor_amd'])
+    return out
+
+
+class ThorParams(C.Structure):
+    """thor_hip_params (include/thor_hip.h) == the enc_params fields this path honours."""
+    _fields_ = [('width', C.c_int), ('height', C.c_int), ('qp', C.c_int), ('bitdepth', C.c_int), ('input_bitdepth', C.c_int),
+                ('frame_rate', C.c_float), ('lambda_coeffI', C.c_float), ('lambda_coeffP', C.c_float),
+                ('early_skip_thr', C.c_float), ('enable_tb_split', C.c_int), ('enable_pb_split', C.c_int),
+                ('max_num_ref', C.c_int), ('HQperiod', C.c_int), ('num_reorder_pics', C.c_int), ('interp_ref', C.c_int),
+                ('dqpP', C.c_int), ('dqpI', C.c_int), ('mqpP', C.c_float), ('intra_period', C.c_int), ('intra_rdo', C.c_int),
+                ('encoder_speed', C.c_int), ('deblocking', C.c_int), ('cdef', C.c_int), ('clpf', C.c_int),
+                ('use_block_contexts', C.c_int), ('enable_bipred', C.c_int), ('cfl_intra', C.c_int), ('cfl_inter', C.c_int)]
+
+
+def lib():
+    """Load the HIP library; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise RuntimeError(f'{p} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); there is no CPU path')
+        L = C.CDLL(p)
+        L.thor_hip_open.restype = C.c_void_p
+        L.thor_hip_open.argtypes = [C.POINTER(ThorParams), C.c_int, C.c_int]
+        L.thor_hip_close.argtypes = [C.c_void_p]
+        L.thor_hip_stage_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.thor_hip_encode_staged.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.thor_hip_encode_frame.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.thor_hip_stream_bytes.restype = C.c_size_t
+        L.thor_hip_stream_bytes.argtypes = [C.c_void_p, C.c_int]
+        L.thor_hip_stream_data.restype = C.c_void_p
+        L.thor_hip_stream_data.argtypes = [C.c_void_p, C.c_int]
+        L.thor_hip_get_recon.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.thor_hip_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]
+        L.thor_hip_kernel_time_reset.argtypes = [C.c_void_p]
+        L.thor_hip_params_from_config.argtypes = [C.POINTER(ThorParams), C.c_char_p]
+        L.thor_hip_params_set.argtypes = [C.POINTER(ThorParams), C.c_char_p, C.c_char_p]
+        _LIB = L
+    return _LIB
+
+
+def load_config(cfg_path=None, **overrides):
+    """ThorParams from a Thorenc-style config file plus "-name value" overrides (width=..., qp=...)."""
+    p = ThorParams()
+    lib().thor_hip_params_from_config(C.byref(p), cfg_path.encode() if cfg_path else None)
+    for k, v in overrides.items():
+        lib().thor_hip_params_set(C.byref(p), ('-' + k).encode(), str(v).encode())
+    return p
+
+
+class Encoder:
+    """N independent closed streams encoded in lock step on one GPU (thor_hip_open ... thor_hip_close)."""
+
+    def __init__(self, params, num_streams=1, device=0):
+        self.p = params
+        self.S = num_streams
+        self.h = lib().thor_hip_open(C.byref(params), num_streams, device)
+        if not self.h:
+            raise RuntimeError('thor_hip_open failed (unsupported parameters?)')
+        self.frame_bytes = params.width * params.height * 3 // 2
+
+    def close(self):
+        if self.h:
+            lib().thor_hip_close(self.h)
+            self.h = None
+
+    def stage(self, stream, slot, frame):
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        assert frame.size == self.frame_bytes
+        rc = lib().thor_hip_stage_frame(self.h, stream, slot, frame.ctypes.data_as(C.c_void_p))
+        if rc:
+            raise RuntimeError(f'thor_hip_stage_frame rc={rc}')
+
+    def encode_staged(self, slots):
+        arr = (C.c_int * self.S)(*slots)
+        rc = lib().thor_hip_encode_staged(self.h, arr)
+        if rc:
+            raise RuntimeError(f'thor_hip_encode_staged rc={rc}')
+
+    def bitstream(self, stream):
+        n = lib().thor_hip_stream_bytes(self.h, stream)
+        return C.string_at(lib().thor_hip_stream_data(self.h, stream), n)
+
+    def recon(self, stream):
+        out = np.empty(self.frame_bytes, dtype=np.uint8)
+        rc = lib().thor_hip_get_recon(self.h, stream, out.ctypes.data_as(C.c_void_p))
+        if rc:
+            raise RuntimeError(f'thor_hip_get_recon rc={rc}')
+        return out
+
+    def kernel_time(self):
+        a, b, c = C.c_double(), C.c_long(), C.c_double()
+        lib().thor_hip_kernel_time(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def kernel_time_reset(self):
+        lib().thor_hip_kernel_time_reset(self.h)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def sad_batch(org, ref_plane, bx, by, cand):
+    org = np.ascontiguousarray(org, dtype=np.uint8); ref_plane = np.ascontiguousarray(ref_plane, dtype=np.uint8)
+    cand = np.ascontiguousarray(cand, dtype=np.int32)
+    out = np.zeros(len(cand), dtype=np.uint32)
+    rc = lib().thor_hip_sad_batch(_vp(org), org.shape[1], org.shape[0], _vp(ref_plane), ref_plane.shape[1], ref_plane.shape[0],
+                                  ref_plane.shape[1], bx, by, _vp(cand), len(cand), _vp(out))
+    if rc:
+        raise RuntimeError(f'thor_hip_sad_batch rc={rc}')
+    return out
+
+
+def interp_luma(ref_padded, pad, pic_w, pic_h, bx, by, w, h, mvs, bipred):
+    ref_padded = np.ascontiguousarray(ref_padded, dtype=np.uint8); mvs = np.ascontiguousarray(mvs, dtype=np.int16)
+    out = np.zeros((len(mvs), h, w), dtype=np.uint8)
+    rc = lib().thor_hip_interp_luma(_vp(ref_padded), pic_w, pic_h, ref_padded.shape[1], pad, bx, by, w, h, _vp(mvs), len(mvs),
+                                    bipred, _vp(out))
+    if rc:
+        raise RuntimeError(f'thor_hip_interp_luma rc={rc}')
+    return out
+
+
+def code_tu_batch(org, pred, qp, coeff_type, fast):
+    org = np.ascontiguousarray(org, dtype=np.uint8); pred = np.ascontiguousarray(pred, dtype=np.uint8)
+    n, size = org.shape[0], org.shape[1]
+    q = min(size, 16)
+    coefq = np.zeros((n, q, q), dtype=np.int16); rec = np.zeros_like(org); cbp = np.zeros(n, dtype=np.int32)
+    rc = lib().thor_hip_code_tu_batch(_vp(org), _vp(pred), size, qp, coeff_type, fast, n, _vp(coefq), _vp(rec), _vp(cbp))
+    if rc:
+        raise RuntimeError(f'thor_hip_code_tu_batch rc={rc}')
+    return coefq, rec, cbp

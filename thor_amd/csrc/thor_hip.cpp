@@ -386,3 +386,217 @@ void thor_hip_read_prof(thor_hip_encoder* e, long long out[16]) { backend::d2h(o
 void thor_hip_kernel_time_reset(thor_hip_encoder*) { g_clk.sb_ms = g_clk.filt_ms = 0; g_clk.sb_launches = 0; }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// C ABI - drop-in seam (enc/encode_frame.h:32-33)
+// ---------------------------------------------------------------------------------------------
+#include "../../include/thor_abi.h"
+#include <map>
+
+static void seam_fatal(const char* msg) {  // fatalerror() convention, common/global.h:38-44
+  fprintf(stderr, "Run-time error...\n%s\n...now exiting to system...\n", msg);
+  abort();
+}
+
+static void stream_put1(thor_stream* s, unsigned bit) {  // putbits(1, bit) of enc/putbits.c:109-128
+  if (s->bitrest == 0) {
+    if (s->bytepos + 4 > s->bytesize) seam_fatal("Run out of bits in stream buffer.");
+    for (int i = 3; i >= 0; --i) s->bitstream[s->bytepos++] = (uint8_t)((s->bitbuf >> (8 * i)) & 0xff);
+    s->bitbuf = 0;
+    s->bitrest = 32;
+  }
+  s->bitbuf |= (bit & 1u) << (s->bitrest - 1);
+  s->bitrest -= 1;
+}
+
+struct SeamState {
+  Engine<uint8_t> eng;
+};
+static std::map<const void*, SeamState*> g_seams;
+
+extern "C" void encode_frame_lbd(struct thor_encoder_info* ei) {
+  if (!ei || !ei->params || !ei->orig || !ei->rec || !ei->stream) seam_fatal("encode_frame_lbd: null encoder_info member");
+  const thor_enc_params& ep = *ei->params;
+  thor_frame_info& fi = ei->frame_info;
+  SeamState*& st = g_seams[ei];
+  if (!st) {
+    SeqParams s;
+    s.width = ei->width; s.height = ei->height; s.qp = (int)ep.qp; s.bitdepth = ep.bitdepth; s.input_bitdepth = ep.input_bitdepth;
+    s.frame_rate = ep.frame_rate; s.lambda_coeffI = ep.lambda_coeffI; s.lambda_coeffP = ep.lambda_coeffP;
+    s.early_skip_thr = ep.early_skip_thr; s.enable_tb_split = ep.enable_tb_split; s.enable_pb_split = ep.enable_pb_split;
+    s.max_num_ref = ep.max_num_ref; s.HQperiod = THOR_MAX_REF_FRAMES - 1;  // window large enough for any ref_array the caller builds
+    s.num_reorder_pics = ep.num_reorder_pics; s.interp_ref = ep.interp_ref; s.dqpP = ep.dqpP; s.dqpI = ep.dqpI; s.mqpP = ep.mqpP;
+    s.intra_period = ep.intra_period; s.intra_rdo = ep.intra_rdo; s.encoder_speed = ep.encoder_speed; s.deblocking = ep.deblocking;
+    s.cdef = ep.cdef; s.clpf = ep.clpf; s.use_block_contexts = ep.use_block_contexts; s.enable_bipred = ep.enable_bipred;
+    s.cfl_intra = ep.cfl_intra; s.cfl_inter = ep.cfl_inter; s.log2_sb_size = ep.log2_sb_size;
+    if (ep.subsample != 420 || ep.log2_sb_size != 7 || ep.qmtx || ep.max_delta_qp || ep.bitrate || ep.sync)
+      seam_fatal("thor_hip: unsupported encoder parameters (need 4:2:0, 128x128 SB, no qmtx / delta-QP / rate control / sync)");
+    if (unsupported(s)) seam_fatal("thor_hip: unsupported encoder parameters");
+    ensure_init(0);
+    st = new SeamState;
+    st->eng.raw_frames = true;
+    st->eng.open(s, 1);
+  }
+  Engine<uint8_t>& eng = st->eng;
+  if (fi.frame_type == F_B || fi.interp_ref) seam_fatal("thor_hip: B frames / interpolated references are not implemented in this round");
+  FrameParams f;
+  f.frame_type = fi.frame_type; f.qp = fi.qp; f.num_ref = fi.num_ref; f.frame_num = fi.frame_num; f.interp_ref = 0;
+  f.num_intra_modes = fi.num_intra_modes;
+  for (int r = 0; r < fi.num_ref && r < kMaxRefs; r++) {
+    if (fi.ref_array[r] < 0 || fi.ref_array[r] >= eng.ring_size) seam_fatal("thor_hip: reference index outside the device window");
+    f.ref_array[r] = fi.ref_array[r];
+  }
+  f.lambda_coeff = fi.frame_type == F_I ? ep.lambda_coeffI : ep.lambda_coeffP;
+  fi.lambda_coeff = f.lambda_coeff;
+  fi.lambda = f.lambda_coeff * kSquaredLambdaQP[f.qp];
+  fi.prev_qp = fi.qp;
+  const thor_yuv_frame& o = *ei->orig;
+  eng.upload_planes(0, (const uint8_t*)o.y, o.stride_y, (const uint8_t*)o.u, (const uint8_t*)o.v, o.stride_c);
+  eng.st[0].num_encoded = fi.frame_num;  // only used for bookkeeping
+  std::vector<FrameParams> fp(1, f);
+  eng.encode_frames(fp);
+  // bits -> caller's stream (the caller flushes: enc/mainenc.c:595)
+  HostBits& b = eng.st[0].bits;
+  for (int i = 0; i < b.nbits; i++) stream_put1(ei->stream, (b.bytes[i >> 3] >> (7 - (i & 7))) & 1u);
+  b.bytes.clear(); b.nbits = 0;
+  // reconstruction -> caller's rec frame
+  {
+    thor_yuv_frame& r = *ei->rec;
+    std::vector<uint8_t> tmp((size_t)ei->width * ei->height * 3 / 2);
+    eng.download_rec(0, tmp.data());
+    const int w = ei->width, h = ei->height;
+    for (int i = 0; i < h; i++) memcpy((uint8_t*)r.y + (size_t)i * r.stride_y, &tmp[(size_t)i * w], w);
+    const uint8_t* cu = &tmp[(size_t)w * h]; const uint8_t* cv = cu + (size_t)(w / 2) * (h / 2);
+    for (int i = 0; i < h / 2; i++) {
+      memcpy((uint8_t*)r.u + (size_t)i * r.stride_c, cu + (size_t)i * (w / 2), w / 2);
+      memcpy((uint8_t*)r.v + (size_t)i * r.stride_c, cv + (size_t)i * (w / 2), w / 2);
+    }
+  }
+  // sliding window of the caller's reference pointers + padded copy (enc/encode_frame.c:826-835)
+  {
+    thor_yuv_frame* last = ei->ref[THOR_MAX_REF_FRAMES - 1];
+    memmove(ei->ref + 1, ei->ref, sizeof(thor_yuv_frame*) * (THOR_MAX_REF_FRAMES - 1));
+    ei->ref[0] = last;
+    thor_yuv_frame& d = *ei->ref[0];
+    const DevFrame<uint8_t>& g = eng.st[0].ring[0];
+    d.frame_num = ei->rec->frame_num;
+    const int ph = d.pad_ver_y, pw = d.pad_hor_y, pch = d.pad_ver_c, pcw = d.pad_hor_c;
+    std::vector<uint8_t> row;
+    auto pull = [&](uint8_t* hp, int hs, const uint8_t* dp, int ds, int w, int h, int padw, int padh) {
+      std::vector<uint8_t> buf((size_t)(h + 2 * padh) * ds);
+      backend::d2h(buf.data(), dp - (size_t)padh * ds - padw, buf.size() - (size_t)(ds - (w + 2 * padw)));
+      for (int i = -padh; i < h + padh; i++)
+        memcpy(hp + (ptrdiff_t)i * hs - padw, &buf[(size_t)(i + padh) * ds], w + 2 * padw);
+    };
+    pull((uint8_t*)d.y, d.stride_y, g.p.y, g.p.sy, ei->width, ei->height, pw < kPadY ? pw : kPadY, ph < kPadY ? ph : kPadY);
+    pull((uint8_t*)d.u, d.stride_c, g.p.u, g.p.sc, ei->width / 2, ei->height / 2, pcw < kPadY / 2 ? pcw : kPadY / 2, pch < kPadY / 2 ? pch : kPadY / 2);
+    pull((uint8_t*)d.v, d.stride_c, g.p.v, g.p.sc, ei->width / 2, ei->height / 2, pcw < kPadY / 2 ? pcw : kPadY / 2, pch < kPadY / 2 ? pch : kPadY / 2);
+  }
+  ei->cdef_damping = 5;
+}
+
+extern "C" void encode_frame_hbd(struct thor_encoder_info*) {
+  seam_fatal("thor_hip: encode_frame_hbd (16-bit sample frames) is not implemented in this round");
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI - kernel-level batch entry points (known-answer tests)
+// ---------------------------------------------------------------------------------------------
+namespace tk {
+__global__ __launch_bounds__(64) void k_kat_sad(const uint8_t* org, int w, int h, const uint8_t* refp, int rstride, int bx,
+                                               int by, const int* cand, int n, uint32_t* out) {
+  __shared__ int sad[kMeMaxCand];
+  Team t{(int)threadIdx.x, 64};
+  for (int base = 0; base < n; base += kMeMaxCand) {
+    const int m = n - base < kMeMaxCand ? n - base : kMeMaxCand;
+    auto ptr = [&](int c) -> const uint8_t* {
+      return refp + (size_t)(by + cand[2 * (base + c) + 1]) * rstride + bx + cand[2 * (base + c)];
+    };
+    sad_many_ptr(t, sad, m, org, w, w, h, rstride, ptr);
+    for (int c = threadIdx.x; c < m; c += 64) out[base + c] = (uint32_t)sad[c];
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(64) void k_kat_interp(const uint8_t* ref0, int rstride, int pic_w, int pic_h, int bx, int by, int w,
+                                                  int h, const int16_t* mv, int bipred, uint8_t* out) {
+  Team t{(int)threadIdx.x, 64};
+  const int i = blockIdx.x;
+  pred_luma(t, out + (size_t)i * w * h, w, ref0 + (size_t)by * rstride + bx, rstride, w, h, mk_mv(mv[2 * i], mv[2 * i + 1]), 0,
+            bipred, pic_w, pic_h, bx, by, 8);
+}
+__global__ __launch_bounds__(64) void k_kat_tu(const uint8_t* org, const uint8_t* pred, int size, int qp, int coeff_type, int fast,
+                                              int16_t* coefq, uint8_t* rec, int* cbp) {
+  __shared__ XformWs xf;
+  __shared__ int16_t cq[256];
+  Team t{(int)threadIdx.x, 64};
+  xf.prof = nullptr;
+  xform_tables_init(t, &xf);
+  const int i = blockIdx.x, qs = size < 16 ? size : 16;
+  const size_t o = (size_t)i * size * size;
+  int c = code_tu(t, &xf, org + o, size, pred + o, size, rec + o, size, size, qp, coeff_type, fast, cq, 8);
+  for (int k = threadIdx.x; k < qs * qs; k += 64) coefq[(size_t)i * qs * qs + k] = cq[k];
+  if (threadIdx.x == 0) cbp[i] = c;
+}
+}  // namespace tk
+
+template <typename T> static T* to_dev(const T* h, size_t n) {
+  T* d = (T*)backend::dev_alloc(n * sizeof(T));
+  if (h) backend::h2d(d, h, n * sizeof(T));
+  return d;
+}
+
+extern "C" int thor_hip_sad_batch(const uint8_t* org, int w, int h, const uint8_t* ref_plane, int plane_w, int plane_h, int rstride,
+                                  int bx, int by, const int* cand, int n, uint32_t* out) {
+  if (!org || !ref_plane || !cand || !out || n <= 0 || (w & 3)) return 1;
+  for (int i = 0; i < n; i++) {
+    int x = bx + cand[2 * i], y = by + cand[2 * i + 1];
+    if (x < 0 || y < 0 || x + w > plane_w || y + h > plane_h) return 2;
+  }
+  ensure_init(0);
+  uint8_t* d_org = to_dev(org, (size_t)w * h);
+  uint8_t* d_ref = to_dev(ref_plane, (size_t)rstride * plane_h);
+  int* d_c = to_dev(cand, (size_t)2 * n);
+  uint32_t* d_o = to_dev<uint32_t>(nullptr, n);
+  hipLaunchKernelGGL(k_kat_sad, dim3(1), dim3(64), 0, g_stream, d_org, w, h, d_ref, rstride, bx, by, d_c, n, d_o);
+  HIPCHECK(hipGetLastError());
+  backend::d2h(out, d_o, (size_t)n * 4);
+  backend::dev_free(d_org); backend::dev_free(d_ref); backend::dev_free(d_c); backend::dev_free(d_o);
+  return 0;
+}
+
+extern "C" int thor_hip_interp_luma(const uint8_t* ref_plane, int plane_w, int plane_h, int rstride, int pad, int bx, int by, int w,
+                                    int h, const int16_t* mv, int n, int bipred, uint8_t* out) {
+  if (!ref_plane || !mv || !out || n <= 0) return 1;
+  ensure_init(0);
+  const size_t total = (size_t)rstride * (plane_h + 2 * pad);
+  uint8_t* d_ref = to_dev(ref_plane, total);
+  int16_t* d_mv = to_dev(mv, (size_t)2 * n);
+  uint8_t* d_o = to_dev<uint8_t>(nullptr, (size_t)n * w * h);
+  hipLaunchKernelGGL(k_kat_interp, dim3(n), dim3(64), 0, g_stream, d_ref + (size_t)pad * rstride + pad, rstride, plane_w, plane_h, bx,
+                     by, w, h, d_mv, bipred, d_o);
+  HIPCHECK(hipGetLastError());
+  backend::d2h(out, d_o, (size_t)n * w * h);
+  backend::dev_free(d_ref); backend::dev_free(d_mv); backend::dev_free(d_o);
+  return 0;
+}
+
+extern "C" int thor_hip_code_tu_batch(const uint8_t* org, const uint8_t* pred, int size, int qp, int coeff_type, int fast, int n,
+                                      int16_t* coefq, uint8_t* rec, int* cbp) {
+  if (!org || !pred || !coefq || !rec || !cbp || n <= 0) return 1;
+  if (size != 4 && size != 8 && size != 16 && size != 32 && size != 64 && size != 128) return 2;
+  ensure_init(0);
+  const size_t px = (size_t)n * size * size;
+  const int qs = size < 16 ? size : 16;
+  uint8_t* d_org = to_dev(org, px);
+  uint8_t* d_pred = to_dev(pred, px);
+  uint8_t* d_rec = to_dev<uint8_t>(nullptr, px);
+  int16_t* d_cq = to_dev<int16_t>(nullptr, (size_t)n * qs * qs);
+  int* d_cbp = to_dev<int>(nullptr, n);
+  hipLaunchKernelGGL(k_kat_tu, dim3(n), dim3(64), 0, g_stream, d_org, d_pred, size, qp, coeff_type, fast, d_cq, d_rec, d_cbp);
+  HIPCHECK(hipGetLastError());
+  backend::d2h(coefq, d_cq, (size_t)n * qs * qs * 2);
+  backend::d2h(rec, d_rec, px);
+  backend::d2h(cbp, d_cbp, (size_t)n * 4);
+  backend::dev_free(d_org); backend::dev_free(d_pred); backend::dev_free(d_rec); backend::dev_free(d_cq); backend::dev_free(d_cbp);
+  return 0;
+}

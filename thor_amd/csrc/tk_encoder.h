@@ -159,6 +159,7 @@ template <typename PIX> class Engine {
   std::vector<CdefJob<PIX>> h_cjobs;
   int nfb_h = 0, nfb_v = 0;
   size_t ws_bytes = 0;
+  bool raw_frames = false;  // drop-in mode: no sequence header / framing; caller consumes st[s].bits
   long long* d_prof = nullptr;  // 16 cycle counters summed over all superblocks (THOR_PROF builds)
 
   void open(const SeqParams& p, int num_streams) {
@@ -196,7 +197,7 @@ template <typename PIX> class Engine {
       s.cdef_fbsel = (int*)backend::dev_alloc(nfb * sizeof(int));
       s.cdef_res = (CdefResult*)backend::dev_alloc(sizeof(CdefResult));
       s.cdef_tot = (unsigned long long*)backend::dev_alloc((size_t)kCdefMaxStr * kCdefMaxStr * 8);
-      write_sequence_header(s.bits, sp);
+      if (!raw_frames) write_sequence_header(s.bits, sp);
     }
     d_jobs = (FrameJob<PIX>*)backend::dev_alloc(sizeof(FrameJob<PIX>) * S);
     h_jobs.resize(S);
@@ -235,6 +236,19 @@ template <typename PIX> class Engine {
       for (int i = 0; i < h / 2; i++) memcpy(&tmp[(size_t)i * f.p.sc], cv + (size_t)i * (w / 2), (w / 2) * sizeof(PIX));
       backend::h2d(f.p.v, tmp.data(), tmp.size() * sizeof(PIX));
     }
+  }
+  // planes with arbitrary host strides (drop-in path)
+  void upload_planes(int s, const PIX* y, int sy, const PIX* u, const PIX* v, int sc) {
+    const int w = sp.width, h = sp.height;
+    DevFrame<PIX>& f = st[s].orig;
+    std::vector<PIX> tmp((size_t)f.p.sy * h);
+    for (int i = 0; i < h; i++) memcpy(&tmp[(size_t)i * f.p.sy], y + (size_t)i * sy, w * sizeof(PIX));
+    backend::h2d(f.p.y, tmp.data(), tmp.size() * sizeof(PIX));
+    tmp.assign((size_t)f.p.sc * (h / 2), 0);
+    for (int i = 0; i < h / 2; i++) memcpy(&tmp[(size_t)i * f.p.sc], u + (size_t)i * sc, (w / 2) * sizeof(PIX));
+    backend::h2d(f.p.u, tmp.data(), tmp.size() * sizeof(PIX));
+    for (int i = 0; i < h / 2; i++) memcpy(&tmp[(size_t)i * f.p.sc], v + (size_t)i * sc, (w / 2) * sizeof(PIX));
+    backend::h2d(f.p.v, tmp.data(), tmp.size() * sizeof(PIX));
   }
   void download_rec(int s, PIX* yuv) {
     const int w = sp.width, h = sp.height;
@@ -399,12 +413,13 @@ template <typename PIX> class Engine {
         for (int i = 0; i < 8; i++) { ch.strengths[i] = R.strengths[i]; ch.uv_strengths[i] = R.uv_strengths[i]; }
         write_cdef_params(b, cdef_pos, 1, ch);
       }
+      q.num_encoded++;
+      if (raw_frames) continue;
       // flush_all_bits framing (putbits.c:45-83)
       uint32_t nbytes = (uint32_t)b.bytes.size();
       for (int i = 0; i < 4; i++) q.out.push_back((uint8_t)(nbytes >> (24 - 8 * i)));
       q.out.insert(q.out.end(), b.bytes.begin(), b.bytes.end());
       b.bytes.clear(); b.nbits = 0;
-      q.num_encoded++;
     }
   }
 };
