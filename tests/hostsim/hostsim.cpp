@@ -54,6 +54,20 @@ template <typename PIX> void run_deblock(const FrameJob<PIX>* jobs, const FrameJ
 template <typename PIX> void run_make_ref(const FrameJob<PIX>* hjobs, const Plane3<PIX>* dst, int S) {
   for (int s = 0; s < S; s++) make_ref_rows(hjobs[s].rec, dst[s], hjobs[s].cfg.width, hjobs[s].cfg.height, 0, 1, 0, 1);
 }
+void run_gather(const GatherItem* items, int n, uint32_t* dst) {
+  for (int it = 0; it < n; it++) {
+    const GatherItem& g = items[it];
+    const int nw = (g.nbits + 31) >> 5, sh = (int)(g.dst_bit & 31);
+    const long long w0 = g.dst_bit >> 5;
+    for (int j = 0; j < nw; j++) {
+      uint32_t v = g.src[j];
+      const int valid = g.nbits - 32 * j;
+      if (valid < 32) v &= ~((1u << (32 - valid)) - 1u);
+      if (sh == 0) dst[w0 + j] |= v;
+      else { dst[w0 + j] |= v >> sh; dst[w0 + j + 1] |= v << (32 - sh); }
+    }
+  }
+}
 template <typename PIX> void run_cdef(const CdefJob<PIX>* cj, const CdefJob<PIX>*, int S) {
   Team t{0, 1};
   for (int s = 0; s < S; s++) {

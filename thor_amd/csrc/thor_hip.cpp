@@ -33,7 +33,7 @@ __device__ Tables g_tab;
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-template <typename PIX> __global__ __launch_bounds__(64) void k_superblocks(const FrameJob<PIX>* jobs, int tdiag) {
+template <typename PIX> __global__ __launch_bounds__(64, 2) void k_superblocks(const FrameJob<PIX>* jobs, int tdiag) {
   __shared__ FrameJob<PIX> sJ;
   {
     const uint32_t* src = (const uint32_t*)&jobs[blockIdx.y];
@@ -86,6 +86,27 @@ template <typename PIX> struct RefJob { Plane3<PIX> rec, ref; int width, height;
 template <typename PIX> __global__ void k_make_ref(const RefJob<PIX>* rj) {
   const RefJob<PIX>& R = rj[blockIdx.y];
   make_ref_rows(R.rec, R.ref, R.width, R.height, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, (int)blockDim.x);
+}
+
+// Bit-level concatenation: one workgroup per item.  dst is zero-filled; words are OR-ed in.
+__global__ void k_gather_bits(const backend::GatherItem* items, int n, uint32_t* dst) {
+  const int it = blockIdx.x;
+  if (it >= n) return;
+  const backend::GatherItem g = items[it];
+  const int nw = (g.nbits + 31) >> 5;
+  const int sh = (int)(g.dst_bit & 31);
+  const long long w0 = g.dst_bit >> 5;
+  for (int j = threadIdx.x; j < nw; j += blockDim.x) {
+    uint32_t v = g.src[j];
+    const int valid = g.nbits - 32 * j;           // bits of this word that belong to the string
+    if (valid < 32) v &= ~((1u << (32 - valid)) - 1u);
+    if (sh == 0) atomicOr(&dst[w0 + j], v);
+    else {
+      atomicOr(&dst[w0 + j], v >> sh);
+      const uint32_t lo = v << (32 - sh);
+      if (lo) atomicOr(&dst[w0 + j + 1], lo);
+    }
+  }
 }
 
 template <typename PIX> __global__ void k_copy_planes(const CdefJob<PIX>* cj) {
@@ -226,6 +247,11 @@ template <typename PIX> void run_cdef(const CdefJob<PIX>* cj, const CdefJob<PIX>
   hipLaunchKernelGGL(k_cdef<PIX>, dim3((blocks8 + 63) / 64, S), dim3(64), 0, g_stream, cj, 4);
   HIPCHECK(hipEventRecord(ev.second, g_stream));
   g_filt_events.push_back(ev);
+  HIPCHECK(hipGetLastError());
+}
+void run_gather(const GatherItem* d_items, int n, uint32_t* dst) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_gather_bits, dim3(n), dim3(64), 0, g_stream, d_items, n, dst);
   HIPCHECK(hipGetLastError());
 }
 template void run_superblocks<uint8_t>(const FrameJob<uint8_t>*, const FrameJob<uint8_t>*, int);
@@ -457,8 +483,8 @@ extern "C" void encode_frame_lbd(struct thor_encoder_info* ei) {
   eng.encode_frames(fp);
   // bits -> caller's stream (the caller flushes: enc/mainenc.c:595)
   HostBits& b = eng.st[0].bits;
-  for (int i = 0; i < b.nbits; i++) stream_put1(ei->stream, (b.bytes[i >> 3] >> (7 - (i & 7))) & 1u);
-  b.bytes.clear(); b.nbits = 0;
+  for (int i = 0; i < b.nbits; i++) stream_put1(ei->stream, (unsigned)b.get(i));
+  b.clear();
   // reconstruction -> caller's rec frame
   {
     thor_yuv_frame& r = *ei->rec;

@@ -33,6 +33,9 @@ template <typename PIX> void run_deblock(const FrameJob<PIX>* jobs, const FrameJ
 template <typename PIX> void run_make_ref(const FrameJob<PIX>* hjobs, const Plane3<PIX>* dst, int S);
 // copies rec -> src, then runs the five CDEF passes; cjobs/hcjobs: device/host arrays of S CdefJob
 template <typename PIX> void run_cdef(const CdefJob<PIX>* cjobs, const CdefJob<PIX>* hcjobs, int S);
+// bit-level concatenation of per-SB bit strings: item i copies nbits[i] bits from src[i] to bit offset dst_bit[i] of dst
+struct GatherItem { const uint32_t* src; int nbits; long long dst_bit; };
+void run_gather(const GatherItem* d_items, int n, uint32_t* dst);
 }  // namespace backend
 
 // ---- parameters -------------------------------------------------------------------------
@@ -60,27 +63,41 @@ struct FrameParams {
 
 // ---- host bit writer (MSB first) ---------------------------------------------------------
 struct HostBits {
-  std::vector<uint8_t> bytes;
+  std::vector<uint32_t> w;  // word i holds stream bits [32i, 32i+32), first bit in the MSB
   int nbits = 0;
   void put(int n, uint32_t v) {
-    for (int i = n - 1; i >= 0; i--) {
-      if ((nbits & 7) == 0) bytes.push_back(0);
-      if ((v >> i) & 1u) bytes.back() |= (uint8_t)(0x80u >> (nbits & 7));
-      nbits++;
+    if (n <= 0) return;
+    if (n < 32) v &= (1u << n) - 1u;
+    const int off = nbits & 31, room = 32 - off;
+    if (off == 0) w.push_back(0);
+    if (n <= room) {
+      w.back() |= v << (room - n);
+    } else {
+      const int lo = n - room;
+      w.back() |= v >> lo;
+      w.push_back(v << (32 - lo));
     }
+    nbits += n;
   }
   // append nb bits taken MSB-first from 32-bit words (device BitSink layout)
-  void append_words(const uint32_t* w, int nb) {
+  void append_words(const uint32_t* src, int nb) {
     int i = 0;
-    for (; i + 32 <= nb; i += 32) put(32, w[i >> 5]);
-    if (i < nb) put(nb - i, w[i >> 5] >> (32 - (nb - i)));
+    for (; i + 32 <= nb; i += 32) put(32, src[i >> 5]);
+    if (i < nb) put(nb - i, src[i >> 5] >> (32 - (nb - i)));
   }
-  void overwrite(int pos, int n, uint32_t v) {  // header back-patching
+  void overwrite(int pos, int n, uint32_t v) {  // header back-patching, bit by bit (tiny)
     for (int i = n - 1; i >= 0; i--, pos++) {
-      uint8_t m = (uint8_t)(0x80u >> (pos & 7));
-      if ((v >> i) & 1u) bytes[pos >> 3] |= m; else bytes[pos >> 3] &= (uint8_t)~m;
+      const uint32_t m = 0x80000000u >> (pos & 31);
+      if ((v >> i) & 1u) w[pos >> 5] |= m; else w[pos >> 5] &= ~m;
     }
   }
+  int get(int pos) const { return (int)((w[pos >> 5] >> (31 - (pos & 31))) & 1u); }
+  size_t num_bytes() const { return ((size_t)nbits + 7) / 8; }
+  void to_bytes(std::vector<uint8_t>& out) const {  // big-endian words -> byte stream
+    const size_t nb = num_bytes();
+    for (size_t i = 0; i < nb; i++) out.push_back((uint8_t)(w[i >> 2] >> (24 - 8 * (i & 3))));
+  }
+  void clear() { w.clear(); nbits = 0; }
 };
 
 inline void write_sequence_header(HostBits& b, const SeqParams& p) {  // write_bits.c:49-81 (4:2:0, no qmtx)
@@ -106,9 +123,9 @@ inline void write_cdef_params(HostBits& b, int pos_or_minus1, int cdef_on, const
     for (int i = 0; i < (1 << h.bits); i++) { tmp.put(7, h.strengths[i]); tmp.put(7, h.uv_strengths[i]); }
   } else tmp.put(18, 0);
   if (pos_or_minus1 < 0) {
-    for (int i = 0; i < tmp.nbits; i++) b.put(1, (tmp.bytes[i >> 3] >> (7 - (i & 7))) & 1u);
+    for (int i = 0; i < tmp.nbits; i++) b.put(1, (uint32_t)tmp.get(i));
   } else {
-    for (int i = 0; i < tmp.nbits; i++) b.overwrite(pos_or_minus1 + i, 1, (tmp.bytes[i >> 3] >> (7 - (i & 7))) & 1u);
+    for (int i = 0; i < tmp.nbits; i++) b.overwrite(pos_or_minus1 + i, 1, (uint32_t)tmp.get(i));
   }
 }
 
@@ -159,6 +176,9 @@ template <typename PIX> class Engine {
   std::vector<CdefJob<PIX>> h_cjobs;
   int nfb_h = 0, nfb_v = 0;
   size_t ws_bytes = 0;
+  int* d_nbits_all = nullptr; int* d_status_all = nullptr;   // [S][nsb]
+  uint32_t* d_payload = nullptr; size_t payload_words = 0;   // compacted SB bits of all streams
+  backend::GatherItem* d_items = nullptr;
   bool raw_frames = false;  // drop-in mode: no sequence header / framing; caller consumes st[s].bits
   long long* d_prof = nullptr;  // 16 cycle counters summed over all superblocks (THOR_PROF builds)
 
@@ -175,6 +195,10 @@ template <typename PIX> class Engine {
     ring_size = (p.HQperiod > p.max_num_ref ? p.HQperiod : p.max_num_ref) + 1;
     ws_bytes = (backend::team_ws_bytes((int)sizeof(PIX)) + 255) & ~(size_t)255;
     st.resize(S);
+    d_nbits_all = (int*)backend::dev_alloc((size_t)S * nsb * sizeof(int));
+    d_status_all = (int*)backend::dev_alloc((size_t)S * nsb * sizeof(int));
+    d_items = (backend::GatherItem*)backend::dev_alloc((size_t)S * nsb * sizeof(backend::GatherItem));
+    { int si = 0; for (auto& s : st) { s.sb_nbits = d_nbits_all + (size_t)si * nsb; s.sb_status = d_status_all + (size_t)si * nsb; si++; } }
     const int cw = p.width / 4, chh = p.height / 4;
     for (auto& s : st) {
       s.orig.alloc(p.width, p.height, 0);
@@ -185,8 +209,6 @@ template <typename PIX> class Engine {
       s.cells = (DbCell*)backend::dev_alloc((size_t)cw * chh * sizeof(DbCell));
       backend::dev_memset(s.cells, 0, (size_t)cw * chh * sizeof(DbCell));
       s.sb_bits = (uint32_t*)backend::dev_alloc((size_t)nsb * kSbWords * 4);
-      s.sb_nbits = (int*)backend::dev_alloc(nsb * sizeof(int));
-      s.sb_status = (int*)backend::dev_alloc(nsb * sizeof(int));
       s.scratch = (uint8_t*)backend::dev_alloc(ws_bytes * max_diag);
       const int nfb = nfb_h * nfb_v;
       s.cdef_dir = (int8_t*)backend::dev_alloc((size_t)(p.width / 8) * (p.height / 8));
@@ -211,10 +233,11 @@ template <typename PIX> class Engine {
       backend::dev_free(s.cdef_dir); backend::dev_free(s.cdef_var); backend::dev_free(s.cdef_fbc); backend::dev_free(s.cdef_mse);
       backend::dev_free(s.cdef_sel); backend::dev_free(s.cdef_fbsel); backend::dev_free(s.cdef_res); backend::dev_free(s.cdef_tot);
       for (auto& r : s.ring) r.release();
-      backend::dev_free(s.cells); backend::dev_free(s.sb_bits); backend::dev_free(s.sb_nbits);
-      backend::dev_free(s.sb_status); backend::dev_free(s.scratch);
+      backend::dev_free(s.cells); backend::dev_free(s.sb_bits); backend::dev_free(s.scratch);
     }
     st.clear();
+    backend::dev_free(d_nbits_all); backend::dev_free(d_status_all); backend::dev_free(d_items); backend::dev_free(d_payload);
+    d_nbits_all = d_status_all = nullptr; d_items = nullptr; d_payload = nullptr; payload_words = 0;
     backend::dev_free(d_jobs); d_jobs = nullptr;
     backend::dev_free(d_cjobs); d_cjobs = nullptr;
     backend::dev_free(d_prof); d_prof = nullptr;
@@ -373,9 +396,38 @@ template <typename PIX> class Engine {
     }
     backend::run_make_ref<PIX>(h_jobs.data(), dst.data(), S);
     backend::dev_sync();
-    // bitstream assembly
-    std::vector<int> nb(nsb), stt(nsb);
-    std::vector<uint32_t> words;
+    // bitstream assembly: one D2H of all bit counts, a device-side bit-level gather of the per-SB
+    // strings into one compact buffer, one D2H of that buffer.
+    std::vector<int> nb((size_t)S * nsb), stt((size_t)S * nsb);
+    backend::d2h(nb.data(), d_nbits_all, nb.size() * sizeof(int));
+    backend::d2h(stt.data(), d_status_all, stt.size() * sizeof(int));
+    std::vector<backend::GatherItem> items((size_t)S * nsb);
+    std::vector<long long> stream_off(S + 1, 0);
+    {
+      long long pos = 0;
+      for (int s = 0; s < S; s++) {
+        stream_off[s] = pos;
+        for (int i = 0; i < nsb; i++) {
+          if (stt[(size_t)s * nsb + i]) { fprintf(stderr, "Run-time error...\nthor_hip: superblock %d bit buffer overflow\n...now exiting to system...\n", i); abort(); }
+          backend::GatherItem& g = items[(size_t)s * nsb + i];
+          g.src = st[s].sb_bits + (size_t)i * kSbWords; g.nbits = nb[(size_t)s * nsb + i]; g.dst_bit = pos;
+          pos += g.nbits;
+        }
+        pos = (pos + 31) & ~31ll;  // streams start word aligned
+      }
+      stream_off[S] = pos;
+    }
+    const size_t need_words = (size_t)(stream_off[S] >> 5) + 2;
+    if (need_words > payload_words) {
+      backend::dev_free(d_payload);
+      payload_words = need_words + need_words / 2;
+      d_payload = (uint32_t*)backend::dev_alloc(payload_words * 4);
+    }
+    backend::dev_memset(d_payload, 0, need_words * 4);
+    backend::h2d(d_items, items.data(), items.size() * sizeof(backend::GatherItem));
+    backend::run_gather(d_items, (int)items.size(), d_payload);
+    std::vector<uint32_t> words(need_words);
+    backend::d2h(words.data(), d_payload, need_words * 4);
     for (int s = 0; s < S; s++) {
       Stream<PIX>& q = st[s];
       const FrameParams& f = fp[s];
@@ -392,14 +444,10 @@ template <typename PIX> class Engine {
         for (int i = 0; i < 8; i++) ch.strengths[i] = ch.uv_strengths[i] = 127;
       }
       write_cdef_params(b, -1, sp.cdef, ch);
-      backend::d2h(nb.data(), q.sb_nbits, nsb * sizeof(int));
-      backend::d2h(stt.data(), q.sb_status, nsb * sizeof(int));
-      for (int i = 0; i < nsb; i++) {
-        if (stt[i]) { fprintf(stderr, "thor_hip: superblock %d bit buffer overflow\n", i); abort(); }
-        size_t nw = ((size_t)nb[i] + 31) / 32;
-        words.resize(nw);
-        backend::d2h(words.data(), q.sb_bits + (size_t)i * kSbWords, nw * 4);
-        b.append_words(words.data(), nb[i]);
+      {
+        long long pbits = 0;
+        for (int i = 0; i < nsb; i++) pbits += nb[(size_t)s * nsb + i];
+        b.append_words(words.data() + (stream_off[s] >> 5), (int)pbits);
       }
       if (sp.cdef) {
         CdefResult R;
@@ -416,10 +464,10 @@ template <typename PIX> class Engine {
       q.num_encoded++;
       if (raw_frames) continue;
       // flush_all_bits framing (putbits.c:45-83)
-      uint32_t nbytes = (uint32_t)b.bytes.size();
+      uint32_t nbytes = (uint32_t)b.num_bytes();
       for (int i = 0; i < 4; i++) q.out.push_back((uint8_t)(nbytes >> (24 - 8 * i)));
-      q.out.insert(q.out.end(), b.bytes.begin(), b.bytes.end());
-      b.bytes.clear(); b.nbits = 0;
+      b.to_bytes(q.out);
+      b.clear();
     }
   }
 };

@@ -27,27 +27,20 @@ struct XformWs {
   int16_t itmp[16 * 32];  // inverse stage-1, [coef col i][sample j]
   int flag;               // team-shared scalar result
   long long* prof;        // cycle counters (THOR_PROF builds)
-  // team-local copies of the constant tables (LDS on the GPU): DCT bases, their transposes, scans
+  // team-local copies of the constant tables (LDS on the GPU): DCT bases, scans
   int16_t dct[16 + 64 + 256 + 1024];
-  int16_t dctT[16 + 64 + 256 + 1024];
   int16_t izz[16 + 64 + 256];
 };
 
 TK_DEV int dct_off(int n) { return n == 4 ? 0 : n == 8 ? 16 : n == 16 ? 80 : 336; }
 TK_DEV const int16_t* dct_matrix(const XformWs* ws, int n) { return ws->dct + dct_off(n); }
-TK_DEV const int16_t* dct_matrixT(const XformWs* ws, int n) { return ws->dctT + dct_off(n); }
 TK_DEV const int16_t* izz_table(const XformWs* ws, int qsize) { return ws->izz + (qsize == 4 ? 0 : qsize == 8 ? 16 : 80); }
 // Fill the team-local tables (call once per team before any transform).
 TK_DEV void xform_tables_init(const Team& t, XformWs* ws) {
   for (int n = 4; n <= 32; n *= 2) {
     const int16_t* M = n == 4 ? TK_TAB.dct4 : n == 8 ? TK_TAB.dct8 : n == 16 ? TK_TAB.dct16 : TK_TAB.dct32;
     int16_t* d = ws->dct + dct_off(n);
-    int16_t* dT = ws->dctT + dct_off(n);
-    for (int k = t.rank; k < n * n; k += t.size) {
-      int i = k / n, j = k - i * n;
-      d[k] = M[k];
-      dT[j * n + i] = M[k];
-    }
+    for (int k = t.rank; k < n * n; k += t.size) d[k] = M[k];
   }
   for (int k = t.rank; k < 16; k += t.size) ws->izz[k] = TK_TAB.izz4[k];
   for (int k = t.rank; k < 64; k += t.size) ws->izz[16 + k] = TK_TAB.izz8[k];
@@ -93,14 +86,13 @@ TK_DEV void fwd_transform(const Team& t, XformWs* ws, const PIX* org, int ostrid
 // Lane mappings are chosen so that every LDS access is either consecutive across lanes or a broadcast.
 TK_DEV void fwd_core(const Team& t, XformWs* ws, int size1, int qsize, int shift_1) {
   const int16_t* M = dct_matrix(ws, size1);
-  const int16_t* MT = dct_matrixT(ws, size1);
   const int add_1 = 1 << (shift_1 - 1);
   const int shift_2 = ilog2(size1) + 5;
   const int add_2 = 1 << (shift_2 - 1);
   for (int k = t.rank; k < qsize * size1; k += t.size) {
-    int j = k / qsize, i = k - j * qsize;  // i (coefficient) fastest
+    int i = k / size1, j = k - i * size1;  // row j fastest: M[i][q] is a broadcast, in[q][j] consecutive
     int sum = 0;
-    for (int q = 0; q < size1; q++) sum += MT[q * size1 + i] * ws->in[q * size1 + j];
+    for (int q = 0; q < size1; q++) sum += M[i * size1 + q] * ws->in[q * size1 + j];
     ws->tmp[j * qsize + i] = (int16_t)((sum + add_1) >> shift_1);
   }
   t.sync();
