@@ -33,7 +33,7 @@ __device__ Tables g_tab;
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-template <typename PIX> __global__ __launch_bounds__(64, 2) void k_superblocks(const FrameJob<PIX>* jobs, int tdiag) {
+template <typename PIX> __global__ __launch_bounds__(64, 4) void k_superblocks(const FrameJob<PIX>* jobs, int tdiag) {
   __shared__ FrameJob<PIX> sJ;
   {
     const uint32_t* src = (const uint32_t*)&jobs[blockIdx.y];
@@ -51,7 +51,9 @@ template <typename PIX> __global__ __launch_bounds__(64, 2) void k_superblocks(c
   TeamWs<PIX> wsv = make_ws(&sws, (BigWs<PIX>*)(J.scratch + (size_t)blockIdx.x * J.scratch_bytes));
   TeamWs<PIX>* ws = &wsv;
   Team t{(int)threadIdx.x, 64};
+#ifdef THOR_PROF
   if (threadIdx.x < kProfSlots) sws.prof[threadIdx.x] = 0;
+#endif
   __syncthreads();
   BitSink out;
   out.buf = J.sb_bits + (size_t)sbi * J.sb_words;

@@ -312,6 +312,9 @@ TK_DEVNI int bs_block(BitSink& b, const SynCtx& s, const BlkParam& p, const int1
   const int size = s.size, size_uv = size >> 1;
   const int mode = p.mode;
   const int coeff_type = (mode == M_INTRA) << 1;
+  // coefficient offset of TU t of a tb-split block: t * qs^2, qs = min(TU size, 16)
+  const int qy = size / 2 < kMaxQuant ? size / 2 : kMaxQuant, qc = size_uv / 2 < kMaxQuant ? size_uv / 2 : kMaxQuant;
+  const int sty = qy * qy, stc = qc * qc;
   bs_super_mode(b, s, mode, p.ref0, 0);
 
   if (mode == M_INTRA) {
@@ -374,15 +377,15 @@ TK_DEVNI int bs_block(BitSink& b, const SynCtx& s, const BlkParam& p, const int1
         int c = cbp_code(ty + (tu << 1) + (tv << 2));
         if (s.ctx_cbp == 0 && c < 2) c = 1 - c;
         bs_vlc(b, 0, (uint32_t)c);
-        if (ty) bs_coeff_any(b, tm, cy + t * 256, size / 2, coeff_type | 0);
-        if (tu) bs_coeff_any(b, tm, cu + t * 256, size_uv / 2, coeff_type | 1);
-        if (tv) bs_coeff_any(b, tm, cv + t * 256, size_uv / 2, coeff_type | 1);
+        if (ty) bs_coeff_any(b, tm, cy + t * sty, size / 2, coeff_type | 0);
+        if (tu) bs_coeff_any(b, tm, cu + t * stc, size_uv / 2, coeff_type | 1);
+        if (tv) bs_coeff_any(b, tm, cv + t * stc, size_uv / 2, coeff_type | 1);
       }
     } else {
       for (int t = 0; t < 4; t++) {
         int ty = (p.cbp_y >> (3 - t)) & 1;
         bs_put(b, 1, (uint32_t)ty);
-        if (ty) bs_coeff_any(b, tm, cy + t * 256, size / 2, coeff_type | 0);
+        if (ty) bs_coeff_any(b, tm, cy + t * sty, size / 2, coeff_type | 0);
       }
       bs_vlc(b, 13, (uint32_t)(p.cbp_u + 2 * p.cbp_v));
       if (p.cbp_u) bs_coeff_any(b, tm, cu, size_uv, coeff_type | 1);

@@ -35,10 +35,17 @@ template <typename PIX> struct SmallWs {
   XformWs xf;
   MeWs me;
   IntraEdge<PIX> edge;
-  int16_t coef_y[4 * 256], coef_u[4 * 256], coef_v[4 * 256];
+  // quantised coefficients of the current trial; TU t of a tb-split block at offset t * qs^2 with
+  // qs = min(TU size, 16).  Chroma needs more than 256 entries only for tb-split 64/128 blocks, which
+  // use the BigWs buffers instead.
+  int16_t coef_y[4 * 256], coef_u[256], coef_v[256];
   unsigned long long acc[12];
   Node stack[5];
+#if defined(THOR_PROF)
   long long prof[kProfSlots];
+#else
+  long long prof[1];
+#endif
 };
 template <typename PIX> struct BigWs {
   PIX pred_y[kMaxSb * kMaxSb], pred_u[kMaxSb * kMaxSb / 4], pred_v[kMaxSb * kMaxSb / 4];
@@ -46,12 +53,14 @@ template <typename PIX> struct BigWs {
   PIX p1_y[kMaxSb * kMaxSb], p1_u[kMaxSb * kMaxSb / 4], p1_v[kMaxSb * kMaxSb / 4];
   PIX rec_y[kMaxSb * kMaxSb], rec_u[kMaxSb * kMaxSb / 4], rec_v[kMaxSb * kMaxSb / 4];
   PIX org8[kMaxSb * kMaxSb];
+  int16_t coef_u_big[4 * 256], coef_v_big[4 * 256];
 };
 template <typename PIX> struct TeamWs {  // view (lives in registers)
   XformWs* xfp;
   MeWs* mep;
   IntraEdge<PIX>* edgep;
-  int16_t *coef_y, *coef_u, *coef_v;
+  int16_t *coef_y, *coef_u, *coef_v;          // current (may point at the big chroma buffers)
+  int16_t *coef_u_small, *coef_v_small, *coef_u_big, *coef_v_big;
   unsigned long long* acc;
   Node* stack;
   long long* prof;
@@ -61,6 +70,7 @@ template <typename PIX> TK_DEV TeamWs<PIX> make_ws(SmallWs<PIX>* s, BigWs<PIX>* 
   TeamWs<PIX> w;
   w.xfp = &s->xf; w.mep = &s->me; w.edgep = &s->edge;
   w.coef_y = s->coef_y; w.coef_u = s->coef_u; w.coef_v = s->coef_v;
+  w.coef_u_small = s->coef_u; w.coef_v_small = s->coef_v; w.coef_u_big = g->coef_u_big; w.coef_v_big = g->coef_v_big;
   w.acc = s->acc; w.stack = s->stack; w.prof = s->prof;
   s->xf.prof = s->prof; s->me.prof = s->prof;
   w.pred_y = g->pred_y; w.pred_u = g->pred_u; w.pred_v = g->pred_v;
@@ -188,7 +198,8 @@ template <typename PIX>
 TK_DEV void ssd_acc(const Team& t, unsigned long long* acc, const PIX* a, int as, const PIX* b, int bs, int w, int h) {
   unsigned long long local = 0;
   for (int k = t.rank; k < w * h; k += t.size) {
-    int i = k / w, j = k - i * w;
+    int i, j;
+    split2(mk_div(w), k, i, j);
     int d = (int)a[i * as + j] - (int)b[i * bs + j];
     local += (unsigned long long)(d * d);
   }
@@ -227,7 +238,8 @@ TK_DEVNI void improve_uv(const Team& t, TeamWs<PIX>* ws, const PIX* y, PIX* u, P
   {
     unsigned long long local = 0;
     for (int k = t.rank; k < n * n; k += t.size) {
-      int i = k / n, j = k - i * n;
+      int i, j;
+      split2(mk_div(n), k, i, j);
       int d = (int)ry[i * stride + j] - (int)y[i * n + j];
       local += (unsigned long long)(d * d);
     }
@@ -239,7 +251,8 @@ TK_DEVNI void improve_uv(const Team& t, TeamWs<PIX>* ws, const PIX* y, PIX* u, P
   {
     unsigned long long ls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = t.rank; k < nc * nc; k += t.size) {
-      int i = k / nc, j = k - i * nc;
+      int i, j;
+      split2(mk_div(nc), k, i, j);
       int us = u[i * cs + j], vs = v[i * cs + j];
       int ys = (y[(i * 2) * n + j * 2] + y[(i * 2) * n + j * 2 + 1] + y[(i * 2 + 1) * n + j * 2] + y[(i * 2 + 1) * n + j * 2 + 1] + 2) >> 2;
       ls[0] += ys; ls[1] += us; ls[2] += vs;
@@ -269,7 +282,8 @@ TK_DEVNI void improve_uv(const Team& t, TeamWs<PIX>* ws, const PIX* y, PIX* u, P
       long long bb = b64 + (1 << 15);
       int b = (int)(bb < -(1ll << 31) ? -(1ll << 31) : (bb > ((1ll << 31) - 1) ? ((1ll << 31) - 1) : bb));
       for (int k = t.rank; k < nc * nc; k += t.size) {
-        int i = k / nc, j = k - i * nc;
+        int i, j;
+        split2(mk_div(nc), k, i, j);
         int s = 2;
         for (int q = 0; q < 4; q++) {
           int r = ry[(i * 2 + (q >> 1)) * stride + j * 2 + (q & 1)];
@@ -326,7 +340,7 @@ TK_DEV int code_inter_plane(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* 
       int bit = code_tu(t, ws->xfp, org + i * ostride + j, ostride, pred + i * size + j, size, rec + i * size + j, size,
                         s2, qp, coeff_type, fast, coef + index, bd);
       cbp = (cbp << 1) + bit;
-      index += 256;
+      index += tmin(s2, 16) * tmin(s2, 16);
     }
   return cbp;
 }
@@ -345,6 +359,11 @@ TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
   const int ftI = (J.frame_type == F_I) << 1;
   const int bd = c.bitdepth;
   p.tb_split = (int8_t)tb_split;
+  {
+    const int bigc = tb_split && sizeC >= 32;  // 4 chroma TUs of 16x16 coefficients
+    ws->coef_u = bigc ? ws->coef_u_big : ws->coef_u_small;
+    ws->coef_v = bigc ? ws->coef_v_big : ws->coef_v_small;
+  }
   const PIX* oy = J.orig.y + nd.ypos * J.orig.sy + nd.xpos;
   const PIX* ou = J.orig.u + yc * J.orig.sc + xc;
   const PIX* ov = J.orig.v + yc * J.orig.sc + xc;
@@ -368,7 +387,7 @@ TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
           int bit = code_tu(t, ws->xfp, oy + i * J.orig.sy + j, J.orig.sy, ws->pred_y + i * size + j, size,
                             ws->rec_y + i * size + j, size, s2, qpY, ftI | 0, c.encoder_speed > 1, ws->coef_y + index, bd);
           cbp_y = (cbp_y << 1) + bit;
-          index += 256;
+          index += tmin(s2, 16) * tmin(s2, 16);
         }
     } else {
       make_edges(t, ws->edgep, fy, J.rec.sy, (const PIX*)nullptr, 0, 0, 0, nd.ypos, nd.xpos, size, ur, dl, 0, bd);
@@ -399,7 +418,7 @@ TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
           int bv = code_tu(t, ws->xfp, ov + i * J.orig.sc + j, J.orig.sc, ws->pred_v + i * sizeC + j, sizeC,
                            ws->rec_v + i * sizeC + j, sizeC, s2, qpC, ftI | 1, c.encoder_speed > 1, ws->coef_v + index, bd);
           cbp_v = (cbp_v << 1) + bv;
-          index += 256;
+          index += tmin(s2, 16) * tmin(s2, 16);
         }
     } else {
       make_edges(t, ws->edgep, fu, J.rec.sc, (const PIX*)nullptr, 0, 0, 0, yc, xc, sizeC, ur, dl, 0, bd);
@@ -542,7 +561,8 @@ TK_DEVNI void search_bipred(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* 
                      list ? min0 : min1, J.sign[ref_o], c.width, c.height, c.enable_bipred, part > 0, c.bitdepth);
       t.sync();
       for (int k = t.rank; k < size * size; k += t.size) {
-        int i = k / size, j = k - i * size;
+        int i, j;
+        split2(mk_div(size), k, i, j);
         ws->org8[k] = (PIX)sat_pix(2 * (int)oy[i * J.orig.sy + j] - (int)ws->pred_y[k], c.bitdepth);
       }
       t.sync();
@@ -702,7 +722,8 @@ TK_DEV int early_skip_sub(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
   const int bd = J.cfg.bitdepth;
   const int s2 = size / 2;
   for (int k = t.rank; k < s2 * s2; k += t.size) {
-    int i = k / s2, j = k - i * s2;
+    int i, j;
+    split2(mk_div(s2), k, i, j);
     int a = (int16_t)((int)org[(2 * i) * ostride + 2 * j] - (int)pred[(2 * i) * pstride + 2 * j]);
     int b = (int16_t)((int)org[(2 * i) * ostride + 2 * j + 1] - (int)pred[(2 * i) * pstride + 2 * j + 1]);
     int cc = (int16_t)((int)org[(2 * i + 1) * ostride + 2 * j] - (int)pred[(2 * i + 1) * pstride + 2 * j]);
@@ -826,7 +847,8 @@ TK_DEVNI int final_encode(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
   const int cw = nd.bw / kMinPb, ch = nd.bh / kMinPb;
   const int cbpbits = tbs ? 7 : ((p.cbp_y ? 1 : 0) | (p.cbp_u ? 2 : 0) | (p.cbp_v ? 4 : 0));
   for (int k = t.rank; k < cw * ch; k += t.size) {
-    int m = k / cw, n = k - m * cw;
+    int m, n;
+    split2(mk_div(cw), k, m, n);
     int m0 = div > 0 ? m / div : 0, n0 = div > 0 ? n / div : 0;
     int index = 2 * m0 + n0;
     DbCell& cell = J.cells[(nd.ypos / kMinPb + m) * J.cell_stride + nd.xpos / kMinPb + n];

@@ -102,6 +102,28 @@ TK_DEV int team_max(const Team& t, int v) {
   return v;
 #endif
 }
+TK_DEV int team_shfl_xor(const Team& t, int v, int d) {
+#if TK_HOST
+  (void)t; (void)d;
+  return v;
+#else
+  (void)t;
+  return __shfl_xor(v, d);
+#endif
+}
+TK_DEV unsigned long long team_min64(const Team& t, unsigned long long v) {
+#if TK_HOST
+  (void)t;
+  return v;
+#else
+  (void)t;
+  for (int d = 32; d >= 1; d >>= 1) {
+    unsigned long long o = __shfl_xor(v, d);
+    v = o < v ? o : v;
+  }
+  return v;
+#endif
+}
 // index of the highest set bit of m strictly below `rank`, or -1
 TK_DEV int prev_set(unsigned long long m, int rank) {
   m &= (rank >= 64) ? ~0ull : ((1ull << rank) - 1ull);
@@ -136,6 +158,21 @@ TK_DEV int ilog2(unsigned x) {
 #else
   return 31 - __clz((int)x);
 #endif
+}
+// k -> (k / w, k % w) without an integer division when w is a power of two (the common case: every
+// block / PU / TU dimension; only the frame-edge rectangular blocks are not).
+struct Div2 {
+  int w, sh;
+};
+TK_DEV Div2 mk_div(int w) {
+  Div2 d;
+  d.w = w;
+  d.sh = (w & (w - 1)) ? -1 : ilog2((unsigned)w);
+  return d;
+}
+TK_DEV void split2(const Div2& d, int k, int& i, int& j) {
+  if (d.sh >= 0) { i = k >> d.sh; j = k & (d.w - 1); }
+  else { i = k / d.w; j = k - i * d.w; }
 }
 TK_DEV int sat_pix(int v, int bitdepth) { return clampi(v, 0, (1 << bitdepth) - 1); }
 

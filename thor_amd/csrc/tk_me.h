@@ -12,11 +12,10 @@
 
 namespace tk {
 
-enum { kMeMaxCand = 64 * 5 };
+enum { kMeWideChunk = 12, kMeMaxCand = kMeWideChunk * 5 };  // 5-offset SADs are evaluated 12 candidates at a time
 
 struct MeWs {
   int sad[kMeMaxCand];
-  unsigned cost[64];
   mv_t cmv[64];
   // per-SB candidate lists (frame_info.mvcand[], enc/mainenc.h:146-148), reset per SB
   mv_t mvcand[kMaxRefs][64];
@@ -59,15 +58,18 @@ TK_DEV void sad_many(const Team& t, int* sad, int ncand, const PIX* org, int ost
     for (int c = 0; c < ncand; c++) {
       int local = 0;
       for (int k = t.rank; k < npix; k += t.size) {
-        int i = k / w, j = k - i * w;
+        int i, j;
+        split2(mk_div(w), k, i, j);
         local += iabs((int)org[i * ostride + j] - sample(c, i, j));
       }
       team_add(&sad[c], local);
     }
   } else {
     for (int it = t.rank; it < ncand * npix; it += t.size) {
-      int c = it / npix, k = it - c * npix;
-      int i = k / w, j = k - i * w;
+      int c, k;
+      split2(mk_div(npix), it, c, k);
+      int i, j;
+      split2(mk_div(w), k, i, j);
       team_add(&sad[c], iabs((int)org[i * ostride + j] - sample(c, i, j)));
     }
   }
@@ -91,27 +93,133 @@ template <> __device__ __forceinline__ int sad4<uint8_t>(const uint8_t* a, const
 // Work item = (candidate, row, group of 4 samples).
 template <typename PIX, class F>
 TK_DEV void sad_many_ptr(const Team& t, int* sad, int ncand, const PIX* org, int ostride, int w, int h, int rstride, F base) {
-  for (int c = t.rank; c < ncand; c += t.size) sad[c] = 0;
-  t.sync();
+  // G lanes cooperate on one candidate (G = min(team, items per candidate), a power of two), P = team/G
+  // candidates are evaluated per pass; partial sums are combined with xor-shuffles (no atomics).
   const int gpr = w >> 2, nit = h * gpr;
-  if (nit >= t.size) {
-    for (int c = 0; c < ncand; c++) {
-      const PIX* b = base(c);
-      int local = 0;
-      for (int r = t.rank; r < nit; r += t.size) {
-        int i = r / gpr, g = r - i * gpr;
-        local += sad4(org + i * ostride + 4 * g, b + i * rstride + 4 * g);
-      }
-      team_add(&sad[c], local);
+  const int lg = ilog2((unsigned)gpr);
+  const int G = nit < t.size ? nit : t.size;
+  const int P = t.size / G;
+  const int slot = t.rank / G, sub = t.rank - slot * G;
+  for (int c0 = 0; c0 < ncand; c0 += 2 * P) {
+    const int ca = c0 + slot, cb = c0 + P + slot;
+    int la = 0, lb = 0;
+    if (ca < ncand) {
+      const PIX* b = base(ca);
+      for (int r = sub; r < nit; r += G) { int i = r >> lg, g = r & (gpr - 1); la += sad4(org + i * ostride + 4 * g, b + i * rstride + 4 * g); }
     }
-  } else {
-    for (int it = t.rank; it < ncand * nit; it += t.size) {
-      int c = it / nit, r = it - c * nit;
-      int i = r / gpr, g = r - i * gpr;
-      team_add(&sad[c], sad4(org + i * ostride + 4 * g, base(c) + i * rstride + 4 * g));
+    if (cb < ncand) {
+      const PIX* b = base(cb);
+      for (int r = sub; r < nit; r += G) { int i = r >> lg, g = r & (gpr - 1); lb += sad4(org + i * ostride + 4 * g, b + i * rstride + 4 * g); }
+    }
+    for (int d = G >> 1; d >= 1; d >>= 1) { la += team_shfl_xor(t, la, d); lb += team_shfl_xor(t, lb, d); }
+    if (sub == 0) {
+      if (ca < ncand) sad[ca] = la;
+      if (cb < ncand) sad[cb] = lb;
     }
   }
   t.sync();
+}
+
+// Evaluate n candidates and return min over (cost << 32 | index): the first candidate in evaluation
+// order among those with the smallest cost - exactly the winner of the reference's sequential
+// "if (cost < min) ..." scan.  prep(c) -> per-candidate context, item(ctx, r) -> partial SAD of work
+// item r < nit, cost(c, ctx, sad) -> cost.  G lanes share a candidate, partial sums are combined with
+// xor-shuffles, the final minimum with a 64-bit wave reduction; no LDS traffic, no barriers.
+template <class PrepF, class ItemF, class CostF>
+TK_DEV unsigned long long eval_min(const Team& t, int n, int nit, PrepF prep, ItemF item, CostF cost) {
+  const int G = nit < t.size ? nit : t.size;
+  const int P = t.size / G;
+  const int slot = t.rank / G, sub = t.rank - slot * G;
+  unsigned long long best = ~0ull;
+  for (int c0 = 0; c0 < n; c0 += 2 * P) {
+    const int ca = c0 + slot, cb = c0 + P + slot;
+    const int va = ca < n, vb = cb < n;
+    auto xa = prep(va ? ca : 0);
+    auto xb = prep(vb ? cb : 0);
+    int la = 0, lb = 0;
+    if (va) for (int r = sub; r < nit; r += G) la += item(xa, r);
+    if (vb) for (int r = sub; r < nit; r += G) lb += item(xb, r);
+    for (int d = G >> 1; d >= 1; d >>= 1) { la += team_shfl_xor(t, la, d); lb += team_shfl_xor(t, lb, d); }
+    if (sub == 0) {
+      if (va) { unsigned long long k = ((unsigned long long)cost(ca, xa, la) << 32) | (unsigned)ca; best = k < best ? k : best; }
+      if (vb) { unsigned long long k = ((unsigned long long)cost(cb, xb, lb) << 32) | (unsigned)cb; best = k < best ? k : best; }
+    }
+  }
+  return team_min64(t, best);
+}
+
+// 4-sample load helpers for the packed SAD
+template <typename PIX> struct Px4 { PIX v[4]; };
+template <typename PIX> TK_DEV Px4<PIX> ld4(const PIX* p) {
+  Px4<PIX> r;
+  __builtin_memcpy(&r, p, sizeof(r));
+  return r;
+}
+template <typename PIX> TK_DEV int sad4v(const Px4<PIX>& a, const Px4<PIX>& b) {
+  return iabs((int)a.v[0] - (int)b.v[0]) + iabs((int)a.v[1] - (int)b.v[1]) + iabs((int)a.v[2] - (int)b.v[2]) + iabs((int)a.v[3] - (int)b.v[3]);
+}
+#if !TK_HOST
+template <> __device__ __forceinline__ int sad4v<uint8_t>(const Px4<uint8_t>& a, const Px4<uint8_t>& b) {
+  uint32_t va, vb;
+  __builtin_memcpy(&va, &a, 4);
+  __builtin_memcpy(&vb, &b, 4);
+  return (int)__builtin_amdgcn_sad_u8(va, vb, 0u);
+}
+#endif
+
+// Full-pel candidate evaluation.  Each lane owns up to 16 four-sample groups of a candidate (a whole
+// 8x8 / 4x4 PU), so small PUs need no cross-lane reduction at all and a complete telescope stage or
+// candidate list is one pass; G = items/16 lanes share a candidate for larger PUs (xor-shuffle
+// reduction).  All reference loads of a pass are issued before the first use.
+// cand(c) -> {clipped mv, pointer to the displaced reference block}; returns min (cost<<32 | index).
+template <typename PIX, class CandF, class CostF>
+TK_DEV unsigned long long eval_fullpel(const Team& t, int n, const PIX* org, int ostride, int rstride, int width, int height,
+                                       CandF cand, CostF cost) {
+  const int gpr = width >> 2, lg = ilog2((unsigned)gpr), nit = height * gpr;
+  int G = nit >> 4;
+  if (G < 1) G = 1;
+  if (G > t.size) G = t.size;
+  const int ipl = nit / G;            // items per lane: 4, 8, 16 or a multiple of 16
+  const int P = t.size / G;
+  const int slot = t.rank / G, sub = t.rank - slot * G;
+  unsigned long long best = ~0ull;
+  for (int c0 = 0; c0 < n; c0 += 2 * P) {
+    const int ca = c0 + slot, cb = c0 + P + slot;
+    const int va = ca < n, vb = cb < n;
+    auto xa = cand(va ? ca : 0);
+    auto xb = cand(vb ? cb : 0);
+    int sa = 0, sb = 0;
+    if (va) {
+      for (int k0 = 0; k0 < ipl; k0 += 16) {
+        const int cnt = ipl - k0 < 16 ? ipl - k0 : 16;
+        Px4<PIX> o[16], a[16], b[16];
+#if !TK_HOST
+#pragma unroll
+#endif
+        for (int k = 0; k < 16; k++)
+          if (k < cnt) {
+            const int r = sub + (k0 + k) * G, i = r >> lg, g = r & (gpr - 1);
+            o[k] = ld4(org + i * ostride + 4 * g);
+            a[k] = ld4(xa.p + i * rstride + 4 * g);
+            if (vb) b[k] = ld4(xb.p + i * rstride + 4 * g);
+          }
+#if !TK_HOST
+#pragma unroll
+#endif
+        for (int k = 0; k < 16; k++)
+          if (k < cnt) {
+            sa += sad4v(o[k], a[k]);
+            if (vb) sb += sad4v(o[k], b[k]);
+          }
+      }
+    }
+    for (int d = G >> 1; d >= 1; d >>= 1) { sa += team_shfl_xor(t, sa, d); sb += team_shfl_xor(t, sb, d); }
+    if (sub == 0) {
+      if (va) { unsigned long long k = ((unsigned long long)cost(xa, sa) << 32) | (unsigned)ca; best = k < best ? k : best; }
+      if (vb) { unsigned long long k = ((unsigned long long)cost(xb, sb) << 32) | (unsigned)cb; best = k < best ? k : best; }
+    }
+  }
+  return team_min64(t, best);
 }
 
 struct MeArgs {
@@ -123,16 +231,6 @@ struct MeArgs {
   int enable_bipred, bitdepth;
   double lam;            // sqrt(lambda)
 };
-
-// Pick the first strictly smaller cost in evaluation order (all lanes run this redundantly).
-TK_DEV void pick_best(const MeWs* w, int n, unsigned& min_sad, mv_t& mv_opt, int* which = nullptr) {
-  for (int c = 0; c < n; c++)
-    if (w->cost[c] < min_sad) {
-      min_sad = w->cost[c];
-      mv_opt = w->cmv[c];
-      if (which) *which = c;
-    }
-}
 
 template <typename PIX>
 TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const PIX* ref, const MeArgs& a, mv_t mvc,
@@ -148,35 +246,38 @@ TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const 
     return ref + (s * (m.y >> 2)) * a.rstride + s * (m.x >> 2);
   };
 
+  struct FP { mv_t mv; const PIX* p; };
+  auto fp_cost = [&](const FP& x, int sad) -> unsigned {
+    return ((unsigned)sad >> sh) + mv_cost(a.lam, x.mv.y - mvp.y, x.mv.x - mvp.x);
+  };
+  auto mk_fp = [&](mv_t mv) -> FP {
+    FP x;
+    x.mv = clip_mv(mv, a.ypos, a.xpos, a.fwidth, a.fheight, a.cb_size, a.cb_size, a.sign);
+    x.p = ref + (s * (x.mv.y >> 2)) * a.rstride + s * (x.mv.x >> 2);
+    return x;
+  };
+#if defined(THOR_PROF) && !TK_HOST
+  long long pq_ = (long long)__builtin_readcyclecounter();
+  if (t.rank == 0) w->prof[11] += 1;
+#endif
   // --- telescope (encode_block.c:529-561)
   for (int step = 32; step >= 4; step >>= 1) {
-    const int range = 2 * step;
-    int n = 0;
-    // candidate index in evaluation order: k (y) outer, l (x) inner, centre skipped after step 32
-    for (int idx = t.rank; idx < 25; idx += t.size) {
-      int k = (idx / 5 - 2) * step, l = (idx % 5 - 2) * step;
-      int slot = idx;
-      if (step < 32) {
-        if (idx == 12) continue;
-        if (idx > 12) slot = idx - 1;
-      }
-      (void)range;
-      w->cmv[slot] = clip_mv(mk_mv(mv_ref.x + l, mv_ref.y + k), a.ypos, a.xpos, a.fwidth, a.fheight, a.cb_size,
-                             a.cb_size, a.sign);
-    }
-    n = step < 32 ? 24 : 25;
-    t.sync();
-    sad_many_ptr(t, w->sad, n, org, a.ostride, a.width, a.height, a.rstride, fullpel);
-    for (int c = t.rank; c < n; c += t.size) {
-      mv_t m = w->cmv[c];
-      w->cost[c] = ((unsigned)w->sad[c] >> sh) + mv_cost(a.lam, m.y - mvp.y, m.x - mvp.x);
-    }
-    t.sync();
-    pick_best(w, n, min_sad, mv_opt);
-    t.sync();
+    const int n = step < 32 ? 24 : 25;
+    const mv_t centre = mv_ref;
+    auto tele = [&](int c) -> FP {
+      int idx = (step < 32 && c >= 12) ? c + 1 : c;  // centre skipped after the first step
+      int q = idx / 5;
+      return mk_fp(mk_mv(centre.x + (idx - q * 5 - 2) * step, centre.y + (q - 2) * step));
+    };
+    unsigned long long k = eval_fullpel(t, n, org, a.ostride, a.rstride, a.width, a.height, tele, fp_cost);
+    if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = tele((int)(unsigned)k).mv; }
     mv_ref = mv_opt;
   }
 
+#if defined(THOR_PROF) && !TK_HOST
+  if (t.rank == 0) w->prof[13] += (long long)__builtin_readcyclecounter() - pq_;
+  pq_ = (long long)__builtin_readcyclecounter();
+#endif
   // --- candidate list (encode_block.c:564-581)
   {
     const int n = w->mvcand_num[ref_idx];
@@ -188,62 +289,68 @@ TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const 
       }
       t.sync();
       if (wide) {
-        auto widepel = [&](int c5) -> const PIX* {
-          int c = c5 / 5, o = c5 - c * 5;
-          int off = o == 0 ? -3 : o == 1 ? -1 : o == 2 ? 0 : o == 3 ? 1 : 3;
-          mv_t m = w->cmv[c];
-          return ref + (s * (m.y >> 2)) * a.rstride + s * (m.x >> 2) + off;
-        };
-        sad_many_ptr(t, w->sad, n * 5, org, a.ostride, a.width, a.height, a.rstride, widepel);
-      } else {
-        sad_many_ptr(t, w->sad, n, org, a.ostride, a.width, a.height, a.rstride, fullpel);
-      }
-      for (int c = t.rank; c < n; c += t.size) {
-        mv_t m = w->cmv[c];
-        unsigned sad;
-        int x = 0;
-        if (wide) {
-          unsigned best = 1u << 31;
-          for (int o = 0; o < 5; o++) {
-            unsigned v = (unsigned)w->sad[c * 5 + o];
-            if (v < best) { best = v; x = o == 0 ? -3 : o == 1 ? -1 : o == 2 ? 0 : o == 3 ? 1 : 3; }
+        // 16x16 CBs: 5-offset "widesad" (encode_block.c:430-453): per candidate the offset with the
+        // smallest SAD (ties -> leftmost), then the usual cost with the adjusted mv.
+        unsigned long long bestk = ~0ull;
+        for (int base = 0; base < n; base += kMeWideChunk) {
+          const int m = n - base < kMeWideChunk ? n - base : kMeWideChunk;
+          auto widepel = [&](int c5) -> const PIX* {
+            int c = c5 / 5, o = c5 - c * 5;
+            int off = o == 0 ? -3 : o == 1 ? -1 : o == 2 ? 0 : o == 3 ? 1 : 3;
+            mv_t mm = w->cmv[base + c];
+            return ref + (s * (mm.y >> 2)) * a.rstride + s * (mm.x >> 2) + off;
+          };
+          sad_many_ptr(t, w->sad, m * 5, org, a.ostride, a.width, a.height, a.rstride, widepel);
+          unsigned long long k = ~0ull;
+          for (int lc = t.rank; lc < m; lc += t.size) {
+            const int c = base + lc;
+            mv_t mm = w->cmv[c];
+            int x = 0;
+            unsigned best = 1u << 31;
+            for (int o = 0; o < 5; o++) {
+              unsigned v = (unsigned)w->sad[lc * 5 + o];
+              if (v < best) { best = v; x = o == 0 ? -3 : o == 1 ? -1 : o == 2 ? 0 : o == 3 ? 1 : 3; }
+            }
+            mm.x = (int16_t)(mm.x + ((s * x) << 2));
+            w->cmv[c] = mm;  // adjusted mv, looked up again if this candidate wins
+            unsigned long long kk = ((unsigned long long)((best >> sh) + mv_cost(a.lam, mm.y - mvp.y, mm.x - mvp.x)) << 32) | (unsigned)c;
+            k = kk < k ? kk : k;
           }
-          sad = best;
-        } else sad = (unsigned)w->sad[c];
-        sad >>= sh;
-        m.x = (int16_t)(m.x + ((s * x) << 2));
-        w->cost[c] = sad + mv_cost(a.lam, m.y - mvp.y, m.x - mvp.x);
-        w->cmv[c] = m;
+          t.sync();
+          k = team_min64(t, k);
+          bestk = k < bestk ? k : bestk;
+        }
+        if ((unsigned)(bestk >> 32) < min_sad) { min_sad = (unsigned)(bestk >> 32); mv_opt = w->cmv[(int)(unsigned)bestk]; }
+        t.sync();
+      } else {
+        auto cl = [&](int c) -> FP { return mk_fp(w->cmv[c]); };  // cmv already clipped: clip_mv is idempotent
+        unsigned long long k = eval_fullpel(t, n, org, a.ostride, a.rstride, a.width, a.height, cl, fp_cost);
+        if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = w->cmv[(int)(unsigned)k]; }
+        t.sync();
       }
-      t.sync();
-      pick_best(w, n, min_sad, mv_opt);
-      t.sync();
     }
     mv_ref = mv_opt;
   }
 
+#if defined(THOR_PROF) && !TK_HOST
+  if (t.rank == 0) w->prof[14] += (long long)__builtin_readcyclecounter() - pq_;
+  pq_ = (long long)__builtin_readcyclecounter();
+#endif
   // --- hexagon refinement (encode_block.c:583-616), encoder_speed 0 => up to 5 rounds
   {
     int start = 0, end = 5;
     for (int step = 1; step < 6; step++) {
       const int n = (end - start + 6) % 6 + 1;  // 6 in the first round, 3 afterwards
-      for (int c = t.rank; c < n; c += t.size) {
+      const mv_t centre = mv_ref;
+      auto hex = [&](int c) -> FP {
         int dir = (start + c) % 6;
         int ox = dir == 0 ? 1 : dir == 1 ? 2 : dir == 2 ? 1 : dir == 3 ? -1 : dir == 4 ? -2 : -1;  // "diy" -> x
         int oy = dir == 0 ? -1 : dir == 1 ? 0 : dir == 2 ? 1 : dir == 3 ? 1 : dir == 4 ? 0 : -1;  // "dix" -> y
-        w->cmv[c] = clip_mv(mk_mv(mv_ref.x + ox * 4, mv_ref.y + oy * 4), a.ypos, a.xpos, a.fwidth, a.fheight,
-                            a.cb_size, a.cb_size, a.sign);
-      }
-      t.sync();
-      sad_many_ptr(t, w->sad, n, org, a.ostride, a.width, a.height, a.rstride, fullpel);
-      for (int c = t.rank; c < n; c += t.size) {
-        mv_t m = w->cmv[c];
-        w->cost[c] = ((unsigned)w->sad[c] >> sh) + mv_cost(a.lam, m.y - mvp.y, m.x - mvp.x);
-      }
-      t.sync();
+        return mk_fp(mk_mv(centre.x + ox * 4, centre.y + oy * 4));
+      };
       int which = -1;
-      pick_best(w, n, min_sad, mv_opt, &which);
-      t.sync();
+      unsigned long long k = eval_fullpel(t, n, org, a.ostride, a.rstride, a.width, a.height, hex, fp_cost);
+      if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); which = (int)(unsigned)k; mv_opt = hex(which).mv; }
       int best_dir = which < 0 ? -1 : (start + which) % 6;
       mv_ref = mv_opt;
       start = best_dir ? best_dir - 1 : 5;
@@ -253,6 +360,9 @@ TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const 
     }
   }
 
+#if defined(THOR_PROF) && !TK_HOST
+  if (t.rank == 0) w->prof[15] += (long long)__builtin_readcyclecounter() - pq_;
+#endif
   TK_PROF_ADD(w, 2);
   // --- half-pel then quarter-pel (encode_block.c:628-663)
 #if defined(THOR_PROF) && !TK_HOST
@@ -262,26 +372,28 @@ TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const 
   for (int pass = 0; pass < 2; pass++) {
     const int d = pass == 0 ? 2 : 1;
     const mv_t base = pass == 0 ? mv_ref : mv_opt;
-    for (int c = t.rank; c < 8; c += t.size) {
-      // order: (0,-d) (-d,0) (d,0) (0,d) (-d,-d) (-d,d) (d,-d) (d,d) as (y,x)
+    // order: (0,-d) (-d,0) (d,0) (0,d) (-d,-d) (-d,d) (d,-d) (d,d) as (y,x)
+    struct SP { mv_t mv; SubPel sp; };
+    auto sub_prep = [&](int c) -> SP {
       int oy = c == 0 ? 0 : c == 1 ? -d : c == 2 ? d : c == 3 ? 0 : c == 4 ? -d : c == 5 ? -d : d;
       int ox = c == 0 ? -d : c == 1 ? 0 : c == 2 ? 0 : c == 3 ? d : c == 4 ? -d : c == 5 ? d : c == 6 ? -d : d;
-      w->cmv[c] = mk_mv(base.x + ox, base.y + oy);
-    }
-    t.sync();
-    auto subpel = [&](int c, int i, int j) -> int {
-      SubPel sp = luma_setup(w->cmv[c], a.sign, a.width, a.height, a.fwidth, a.fheight, a.xpos, a.ypos);
-      return luma_sample(ref, a.rstride, i, j, sp, a.enable_bipred, a.bitdepth);
+      SP x;
+      x.mv = mk_mv(base.x + ox, base.y + oy);
+      x.sp = luma_setup(x.mv, a.sign, a.width, a.height, a.fwidth, a.fheight, a.xpos, a.ypos, a.enable_bipred);
+      return x;
     };
-    sad_many(t, w->sad, 8, org, a.ostride, a.width, a.height, subpel);
-    for (int c = t.rank; c < 8; c += t.size) {
-      mv_t m = w->cmv[c];
-      w->cost[c] = ((unsigned)w->sad[c] >> sh) + mv_cost(a.lam, m.y - mvp.y, m.x - mvp.x);
-    }
-    t.sync();
+    const Div2 dw = mk_div(a.width);
+    auto sub_item = [&](const SP& x, int r) -> int {
+      int i, j;
+      split2(dw, r, i, j);
+      return iabs((int)org[i * a.ostride + j] - luma_sample(ref, a.rstride, i, j, x.sp, a.enable_bipred, a.bitdepth));
+    };
+    auto sub_cost = [&](int, const SP& x, int sad) -> unsigned {
+      return ((unsigned)sad >> sh) + mv_cost(a.lam, x.mv.y - mvp.y, x.mv.x - mvp.x);
+    };
+    unsigned long long k = eval_min(t, 8, a.width * a.height, sub_prep, sub_item, sub_cost);
     mv_t best = base;
-    pick_best(w, 8, cmin, best);
-    t.sync();
+    if ((unsigned)(k >> 32) < cmin) { cmin = (unsigned)(k >> 32); best = sub_prep((int)(unsigned)k).mv; }
     // mv_opt += delta of the winning position (none => unchanged)
     mv_opt = mk_mv(mv_opt.x + (best.x - base.x), mv_opt.y + (best.y - base.y));
   }

@@ -35,12 +35,13 @@ TK_DEV mv_t clip_mv(mv_t mv, int ypos, int xpos, int fwidth, int fheight, int bw
   return mk_mv(sign ? -mvx : mvx, sign ? -mvy : mvy);
 }
 
-// One luma prediction sample at (i=row, j=col) of a PU whose reference pointer (at integer
-// displacement 0) is `ref`.  hor_int/ver_int/frac as derived by luma_setup().
+// Sub-pel set-up of one PU / candidate: integer displacement, fractions and the two 6-tap filters
+// (hoisted out of the per-sample code: it is uniform per candidate).
 struct SubPel {
   int hor_int, ver_int, hor_frac, ver_frac;
+  int th[6], tv[6];
 };
-TK_DEV SubPel luma_setup(mv_t mv, int sign, int width, int height, int pic_w, int pic_h, int xpos, int ypos) {
+TK_DEV SubPel luma_setup(mv_t mv, int sign, int width, int height, int pic_w, int pic_h, int xpos, int ypos, int bipred = 0) {
   int mx = sign ? -mv.x : mv.x, my = sign ? -mv.y : mv.y;
   SubPel s;
   s.ver_frac = my & 3;
@@ -52,9 +53,15 @@ TK_DEV SubPel luma_setup(mv_t mv, int sign, int width, int height, int pic_w, in
   hi = tmax(hi, -xpos - width);
   s.ver_int = vi;
   s.hor_int = hi;
+  for (int m = 0; m < 6; m++) {
+    s.th[m] = luma_tap(bipred, s.hor_frac, m);
+    s.tv[m] = luma_tap(bipred, s.ver_frac, m);
+  }
   return s;
 }
 
+// One luma prediction sample at (i=row, j=col) of a PU whose reference pointer (at integer
+// displacement 0) is `ref`.
 template <typename PIX>
 TK_DEV int luma_sample(const PIX* ref, int stride, int i, int j, const SubPel& s, int bipred, int bitdepth) {
   const PIX* p = ref + (i + s.ver_int) * stride + (j + s.hor_int);
@@ -66,19 +73,19 @@ TK_DEV int luma_sample(const PIX* ref, int stride, int i, int j, const SubPel& s
   }
   if (s.hor_frac == 0) {
     int sum = 0;
-    for (int m = 0; m < 6; m++) sum += luma_tap(bipred, s.ver_frac, m) * p[(m - 2) * stride];
+    for (int m = 0; m < 6; m++) sum += s.tv[m] * p[(m - 2) * stride];
     return sat_pix((sum * 64 + 2048) >> 12, bitdepth);
   }
   if (s.ver_frac == 0) {
     int sum = 0;
-    for (int m = 0; m < 6; m++) sum += luma_tap(bipred, s.hor_frac, m) * p[m - 2];
+    for (int m = 0; m < 6; m++) sum += s.th[m] * p[m - 2];
     return sat_pix((sum * 64 + 2048) >> 12, bitdepth);
   }
   int sum = 0;
   for (int n = 0; n < 6; n++) {
     int col = 0;
-    for (int m = 0; m < 6; m++) col += luma_tap(bipred, s.ver_frac, m) * p[(m - 2) * stride + (n - 2)];
-    sum += luma_tap(bipred, s.hor_frac, n) * col;
+    for (int m = 0; m < 6; m++) col += s.tv[m] * p[(m - 2) * stride + (n - 2)];
+    sum += s.th[n] * col;
   }
   return sat_pix((sum + 2048) >> 12, bitdepth);
 }
@@ -87,9 +94,10 @@ TK_DEV int luma_sample(const PIX* ref, int stride, int i, int j, const SubPel& s
 template <typename PIX>
 TK_DEV void pred_luma(const Team& t, PIX* dst, int dstride, const PIX* ref, int rstride, int width, int height, mv_t mv,
                       int sign, int bipred, int pic_w, int pic_h, int xpos, int ypos, int bitdepth) {
-  SubPel s = luma_setup(mv, sign, width, height, pic_w, pic_h, xpos, ypos);
+  SubPel s = luma_setup(mv, sign, width, height, pic_w, pic_h, xpos, ypos, bipred);
   for (int k = t.rank; k < width * height; k += t.size) {
-    int i = k / width, j = k - i * width;
+    int i, j;
+    split2(mk_div(width), k, i, j);
     dst[i * dstride + j] = (PIX)luma_sample(ref, rstride, i, j, s, bipred, bitdepth);
   }
 }
@@ -105,7 +113,8 @@ TK_DEV void pred_chroma(const Team& t, PIX* dst, int dstride, const PIX* ref, in
   hi = tmin(hi, pic_w2 - xpos);
   hi = tmax(hi, -xpos - width);
   for (int k = t.rank; k < width * height; k += t.size) {
-    int i = k / width, j = k - i * width;
+    int i, j;
+    split2(mk_div(width), k, i, j);
     const PIX* p = ref + (i + vi) * rstride + (j + hi);
     int v;
     if (vf == 0 && hf == 0) {
@@ -157,12 +166,16 @@ template <typename PIX>
 TK_DEV void average_yuv(const Team& t, PIX* dy, PIX* du, PIX* dv, const PIX* ay, const PIX* au, const PIX* av,
                         const PIX* by, const PIX* bu, const PIX* bv, int size, int bw, int bh) {
   for (int k = t.rank; k < bw * bh; k += t.size) {
-    int i = k / bw, j = k - i * bw, o = i * size + j;
+    int i, j;
+    split2(mk_div(bw), k, i, j);
+    int o = i * size + j;
     dy[o] = (PIX)(((int)ay[o] + (int)by[o]) >> 1);
   }
   int cw = bw >> 1, ch = bh >> 1, cs = size >> 1;
   for (int k = t.rank; k < cw * ch; k += t.size) {
-    int i = k / cw, j = k - i * cw, o = i * cs + j;
+    int i, j;
+    split2(mk_div(cw), k, i, j);
+    int o = i * cs + j;
     du[o] = (PIX)(((int)au[o] + (int)bu[o]) >> 1);
     dv[o] = (PIX)(((int)av[o] + (int)bv[o]) >> 1);
   }
@@ -259,7 +272,8 @@ TK_DEV void pred_intra(const Team& t, const IntraEdge<PIX>* e, int ypos, int xpo
     tlF = (PIX)((2 * tl + left[0] + top[0] + 2) >> 2);
   }
   for (int k = t.rank; k < size * size; k += t.size) {
-    int i = k / size, j = k - i * size;
+    int i, j;
+    split2(mk_div(size), k, i, j);
     int v;
     switch (mode) {
       case 1:  // planar

@@ -20,31 +20,25 @@
 namespace tk {
 
 struct XformWs {
-  int16_t in[32 * 32];    // (down-scaled) residual fed to the core transform, TRANSPOSED: in[col*size1 + row]
+  // `in`: (down-scaled) residual fed to the core transform, TRANSPOSED: in[col*size1 + row].  It is dead
+  // after forward stage 1, so the inverse transform's stage-1 buffer (itmp, [coef col i][sample j],
+  // 16*32 entries) lives in the same storage.
+  int16_t in[32 * 32];
   int16_t tmp[16 * 32];   // stage-1 output, [row j][coef i] (stride qsize)
-  int16_t coef[16 * 16];  // forward coefficients, compact
-  int16_t rcoef[16 * 16]; // de-quantised coefficients, compact
-  int16_t itmp[16 * 32];  // inverse stage-1, [coef col i][sample j]
+  int16_t coef[16 * 16];  // forward coefficients, compact; reused for the de-quantised ones (rcoef)
   int flag;               // team-shared scalar result
   long long* prof;        // cycle counters (THOR_PROF builds)
-  // team-local copies of the constant tables (LDS on the GPU): DCT bases, scans
-  int16_t dct[16 + 64 + 256 + 1024];
-  int16_t izz[16 + 64 + 256];
+  // team-local copy of the 32-point DCT basis (LDS on the GPU); the N-point basis is its rows
+  // 0, 32/N, 2*32/N, ... restricted to the first N columns (HEVC nesting property).
+  int16_t dct32[1024];
 };
 
-TK_DEV int dct_off(int n) { return n == 4 ? 0 : n == 8 ? 16 : n == 16 ? 80 : 336; }
-TK_DEV const int16_t* dct_matrix(const XformWs* ws, int n) { return ws->dct + dct_off(n); }
-TK_DEV const int16_t* izz_table(const XformWs* ws, int qsize) { return ws->izz + (qsize == 4 ? 0 : qsize == 8 ? 16 : 80); }
-// Fill the team-local tables (call once per team before any transform).
+// entry (i, q) of the N-point basis, log2(32/N) = rs
+TK_DEV int dct_at(const XformWs* ws, int rs, int i, int q) { return ws->dct32[((i << rs) << 5) + q]; }
+TK_DEV const int16_t* izz_table(const XformWs*, int qsize) { return qsize == 4 ? TK_TAB.izz4 : (qsize == 8 ? TK_TAB.izz8 : TK_TAB.izz16); }
+// Fill the team-local table (call once per team before any transform).
 TK_DEV void xform_tables_init(const Team& t, XformWs* ws) {
-  for (int n = 4; n <= 32; n *= 2) {
-    const int16_t* M = n == 4 ? TK_TAB.dct4 : n == 8 ? TK_TAB.dct8 : n == 16 ? TK_TAB.dct16 : TK_TAB.dct32;
-    int16_t* d = ws->dct + dct_off(n);
-    for (int k = t.rank; k < n * n; k += t.size) d[k] = M[k];
-  }
-  for (int k = t.rank; k < 16; k += t.size) ws->izz[k] = TK_TAB.izz4[k];
-  for (int k = t.rank; k < 64; k += t.size) ws->izz[16 + k] = TK_TAB.izz8[k];
-  for (int k = t.rank; k < 256; k += t.size) ws->izz[80 + k] = TK_TAB.izz16[k];
+  for (int k = t.rank; k < 1024; k += t.size) ws->dct32[k] = TK_TAB.dct32[k];
   t.sync();
 }
 
@@ -62,7 +56,8 @@ TK_DEV void fwd_transform(const Team& t, XformWs* ws, const PIX* org, int ostrid
   }
   // residual (+ optional saturating box sum, transform.c:262-277)
   for (int k = t.rank; k < size1 * size1; k += t.size) {
-    int i = k / size1, j = k - i * size1;
+    int i, j;
+    split2(mk_div(size1), k, i, j);
     int sum = 0;
     if (scale == 1) {
       sum = (int16_t)((int)org[i * ostride + j] - (int)pred[i * pstride + j]);
@@ -85,21 +80,23 @@ TK_DEV void fwd_transform(const Team& t, XformWs* ws, const PIX* org, int ostrid
 // Stage 2 (cols):   coef[i][j] = (sum_q M[i][q] * tmp[q][j] + add2) >> shift2
 // Lane mappings are chosen so that every LDS access is either consecutive across lanes or a broadcast.
 TK_DEV void fwd_core(const Team& t, XformWs* ws, int size1, int qsize, int shift_1) {
-  const int16_t* M = dct_matrix(ws, size1);
+  const int rs = 5 - ilog2((unsigned)size1);
   const int add_1 = 1 << (shift_1 - 1);
   const int shift_2 = ilog2(size1) + 5;
   const int add_2 = 1 << (shift_2 - 1);
   for (int k = t.rank; k < qsize * size1; k += t.size) {
-    int i = k / size1, j = k - i * size1;  // row j fastest: M[i][q] is a broadcast, in[q][j] consecutive
+    int i, j;
+    split2(mk_div(size1), k, i, j);  // row j fastest: M[i][q] is a broadcast, in[q][j] consecutive
     int sum = 0;
-    for (int q = 0; q < size1; q++) sum += M[i * size1 + q] * ws->in[q * size1 + j];
+    for (int q = 0; q < size1; q++) sum += dct_at(ws, rs, i, q) * ws->in[q * size1 + j];
     ws->tmp[j * qsize + i] = (int16_t)((sum + add_1) >> shift_1);
   }
   t.sync();
   for (int k = t.rank; k < qsize * qsize; k += t.size) {
-    int i = k / qsize, j = k - i * qsize;
+    int i, j;
+    split2(mk_div(qsize), k, i, j);
     int sum = 0;
-    for (int q = 0; q < size1; q++) sum += M[i * size1 + q] * ws->tmp[q * qsize + j];
+    for (int q = 0; q < size1; q++) sum += dct_at(ws, rs, i, q) * ws->tmp[q * qsize + j];
     ws->coef[i * qsize + j] = (int16_t)((sum + add_2) >> shift_2);
   }
   t.sync();
@@ -211,7 +208,7 @@ TK_DEV void dequantize(const Team& t, XformWs* ws, const int16_t* coefq, int qp,
     int16_t r;
     if (lshift >= rshift) r = (int16_t)((c * scale) << (lshift - rshift));
     else r = (int16_t)((c * scale + ((int64_t)1 << (rshift - lshift - 1))) >> (rshift - lshift));
-    ws->rcoef[k] = r;
+    ws->coef[k] = r;  // rcoef aliases coef (the forward coefficients are dead after quantisation)
   }
   t.sync();
 }
@@ -223,20 +220,23 @@ TK_DEV void inv_transform_recon(const Team& t, XformWs* ws, const PIX* pred, int
   const int n = size < 32 ? size : 32;
   const int scale = size / n;
   const int qsize = n < kMaxQuant ? n : kMaxQuant;
-  const int16_t* M = dct_matrix(ws, n);
+  const int rs = 5 - ilog2((unsigned)n);
+  int16_t* itmp = ws->in;  // aliases `in`
   const int shift_2 = 20 - bitdepth, add_2 = 1 << (shift_2 - 1);
   // stage 1: itmp[i*n + j] = clip((sum_k M[k][j]*rcoef[k][i] + 64) >> 7)   i < qsize, j < n
   for (int k = t.rank; k < qsize * n; k += t.size) {
-    int i = k / n, j = k - i * n;
+    int i, j;
+    split2(mk_div(n), k, i, j);
     int sum = 0;
-    for (int q = 0; q < qsize; q++) sum += M[q * n + j] * ws->rcoef[q * qsize + i];
-    ws->itmp[i * n + j] = (int16_t)clampi((sum + 64) >> 7, -32768, 32767);
+    for (int q = 0; q < qsize; q++) sum += dct_at(ws, rs, q, j) * ws->coef[q * qsize + i];
+    itmp[i * n + j] = (int16_t)clampi((sum + 64) >> 7, -32768, 32767);
   }
   t.sync();
   for (int k = t.rank; k < n * n; k += t.size) {
-    int i = k / n, j = k - i * n;
+    int i, j;
+    split2(mk_div(n), k, i, j);
     int sum = 0;
-    for (int q = 0; q < qsize; q++) sum += M[q * n + j] * ws->itmp[q * n + i];
+    for (int q = 0; q < qsize; q++) sum += dct_at(ws, rs, q, j) * itmp[q * n + i];
     int r = clampi((sum + add_2) >> shift_2, -32768, 32767);
     for (int m = 0; m < scale; m++)
       for (int x = 0; x < scale; x++) {
@@ -250,7 +250,8 @@ TK_DEV void inv_transform_recon(const Team& t, XformWs* ws, const PIX* pred, int
 template <typename PIX>
 TK_DEV void copy_block(const Team& t, PIX* dst, int dstride, const PIX* src, int sstride, int w, int h) {
   for (int k = t.rank; k < w * h; k += t.size) {
-    int i = k / w, j = k - i * w;
+    int i, j;
+    split2(mk_div(w), k, i, j);
     dst[i * dstride + j] = src[i * sstride + j];
   }
 }
