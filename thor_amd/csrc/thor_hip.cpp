@@ -33,7 +33,7 @@ __device__ Tables g_tab;
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-template <typename PIX> __global__ __launch_bounds__(64, 4) void k_superblocks(const FrameJob<PIX>* jobs, int tdiag) {
+template <typename PIX> __global__ __launch_bounds__(64, 3) void k_superblocks(const FrameJob<PIX>* jobs, int tdiag) {
   __shared__ FrameJob<PIX> sJ;
   {
     const uint32_t* src = (const uint32_t*)&jobs[blockIdx.y];
