@@ -100,7 +100,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--streams', type=int, default=int(os.environ.get('THOR_BENCH_STREAMS', '128')), help='streams PER GPU')
+    ap.add_argument('--streams', type=int, default=int(os.environ.get('THOR_BENCH_STREAMS', '512')), help='streams PER GPU')
     ap.add_argument('--width', type=int, default=1920)
     ap.add_argument('--height', type=int, default=1080)
     ap.add_argument('--qp', type=int, default=32)

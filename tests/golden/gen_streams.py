@@ -13,6 +13,9 @@ CASES = {
     '192x128_n3_q32_skip3': ('clip_192x128_6.yuv.gz', 192, 128, 3, 32, ['-skip', '3']),
     '208x120_n4_q32': ('clip_208x120_4.yuv.gz', 208, 120, 4, 32, []),
     '208x120_n4_q36_nocdef': ('clip_208x120_4.yuv.gz', 208, 120, 4, 36, ['-cdef', '0']),
+    # 10-bit samples (uint16 LE), the reference's _hbd code path
+    '192x128_n4_q32_10bit': ('clip10_192x128_5.yuv.gz', 192, 128, 4, 32, ['-bitdepth', '10', '-input_bitdepth', '10']),
+    '192x128_n3_q40_10bit_nocdef': ('clip10_192x128_5.yuv.gz', 192, 128, 3, 40, ['-bitdepth', '10', '-input_bitdepth', '10', '-cdef', '0']),
 }
 out = {}
 with tempfile.TemporaryDirectory() as d:

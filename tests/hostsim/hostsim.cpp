@@ -85,14 +85,19 @@ template <typename PIX> void run_cdef(const CdefJob<PIX>* cj, const CdefJob<PIX>
   }
 }
 template void run_cdef<uint8_t>(const CdefJob<uint8_t>*, const CdefJob<uint8_t>*, int);
+template void run_cdef<uint16_t>(const CdefJob<uint16_t>*, const CdefJob<uint16_t>*, int);
 template void run_superblocks<uint8_t>(const FrameJob<uint8_t>*, const FrameJob<uint8_t>*, int);
+template void run_superblocks<uint16_t>(const FrameJob<uint16_t>*, const FrameJob<uint16_t>*, int);
 template void run_deblock<uint8_t>(const FrameJob<uint8_t>*, const FrameJob<uint8_t>*, int);
+template void run_deblock<uint16_t>(const FrameJob<uint16_t>*, const FrameJob<uint16_t>*, int);
 template void run_make_ref<uint8_t>(const FrameJob<uint8_t>*, const Plane3<uint8_t>*, int);
+template void run_make_ref<uint16_t>(const FrameJob<uint16_t>*, const Plane3<uint16_t>*, int);
 }  // namespace backend
 }  // namespace tk
 
 int main(int argc, char** argv) {
   tk::init_tables(&tk::g_tab);
   tk::CliArgs a = tk::cli_parse(argc, argv);
-  return tk::cli_run<uint8_t>(a);
+  if (a.sp.bitdepth != a.sp.input_bitdepth) { fprintf(stderr, "bitdepth != input_bitdepth is not supported\n"); return 2; }
+  return a.sp.bitdepth > 8 ? tk::cli_run<uint16_t>(a) : tk::cli_run<uint8_t>(a);
 }

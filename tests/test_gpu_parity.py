@@ -15,7 +15,7 @@ G = golden_streams()
 def encode_gpu(clip, w, h, n, qp, streams=1, skip=0, **over):
     import thor_amd
     p = thor_amd.load_config(CFG, width=w, height=h, qp=qp, f=30, **over)
-    fsz = w * h * 3 // 2
+    fsz = w * h * 3 // 2 * (2 if int(over.get('bitdepth', 8)) > 8 else 1)
     a = np.frombuffer(clip, dtype=np.uint8)
     with thor_amd.Encoder(p, streams) as enc:
         recs = [b''] * streams

@@ -23,7 +23,7 @@ def test_reference_reproduces_golden_and_roundtrips(name):
         assert decode(bits) == rec
 
 
-@pytest.mark.parametrize('name', ['192x128_n3_q32', '208x120_n4_q32', '192x128_n3_q32_skip3', '192x128_n4_q44'])
+@pytest.mark.parametrize('name', ['192x128_n3_q32', '208x120_n4_q32', '192x128_n3_q32_skip3', '192x128_n4_q44', '192x128_n4_q32_10bit'])
 def test_engine_host_simulation_matches_golden(name):
     c = G[name]
     bits, rec = run_encoder(build_hostsim(), golden_clip(c['clip']), c['w'], c['h'], c['n'], c['qp'], c['extra'])

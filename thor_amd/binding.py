@@ -87,7 +87,8 @@ class Encoder:
         self.h = lib().thor_hip_open(C.byref(params), num_streams, device)
         if not self.h:
             raise RuntimeError('thor_hip_open failed (unsupported parameters?)')
-        self.frame_bytes = params.width * params.height * 3 // 2
+        self.sample_bytes = 2 if params.bitdepth > 8 else 1
+        self.frame_bytes = params.width * params.height * 3 // 2 * self.sample_bytes
 
     def close(self):
         if self.h:
@@ -95,7 +96,7 @@ class Encoder:
             self.h = None
 
     def stage(self, stream, slot, frame):
-        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        frame = np.ascontiguousarray(frame).view(np.uint8)
         assert frame.size == self.frame_bytes
         rc = lib().thor_hip_stage_frame(self.h, stream, slot, frame.ctypes.data_as(C.c_void_p))
         if rc:

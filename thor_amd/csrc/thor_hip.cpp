@@ -260,6 +260,10 @@ template void run_superblocks<uint8_t>(const FrameJob<uint8_t>*, const FrameJob<
 template void run_deblock<uint8_t>(const FrameJob<uint8_t>*, const FrameJob<uint8_t>*, int);
 template void run_make_ref<uint8_t>(const FrameJob<uint8_t>*, const Plane3<uint8_t>*, int);
 template void run_cdef<uint8_t>(const CdefJob<uint8_t>*, const CdefJob<uint8_t>*, int);
+template void run_superblocks<uint16_t>(const FrameJob<uint16_t>*, const FrameJob<uint16_t>*, int);
+template void run_deblock<uint16_t>(const FrameJob<uint16_t>*, const FrameJob<uint16_t>*, int);
+template void run_make_ref<uint16_t>(const FrameJob<uint16_t>*, const Plane3<uint16_t>*, int);
+template void run_cdef<uint16_t>(const CdefJob<uint16_t>*, const CdefJob<uint16_t>*, int);
 }  // namespace backend
 }  // namespace tk
 
@@ -268,13 +272,22 @@ template void run_cdef<uint8_t>(const CdefJob<uint8_t>*, const CdefJob<uint8_t>*
 // ---------------------------------------------------------------------------------------------
 using namespace tk;
 
+template <typename PIX> struct EncT {
+  Engine<PIX> eng;
+  std::vector<std::vector<DevFrame<PIX>>> staged;  // [stream][slot]
+};
 struct thor_hip_encoder {
-  Engine<uint8_t> eng;
   SeqParams sp;
   int S = 0;
-  std::vector<std::vector<DevFrame<uint8_t>>> staged;  // [stream][slot]
-  std::vector<uint8_t> rec_host;
+  bool hbd = false;          // samples are uint16_t (bitdepth > 8)
+  EncT<uint8_t>* e8 = nullptr;
+  EncT<uint16_t>* e16 = nullptr;
 };
+#define ENC_DISPATCH(e, body)                                   \
+  do {                                                          \
+    if ((e)->hbd) { auto& E = *(e)->e16; typedef uint16_t PIXT; body; } \
+    else { auto& E = *(e)->e8; typedef uint8_t PIXT; body; }            \
+  } while (0)
 
 static SeqParams to_seq(const thor_hip_params& p) {
   SeqParams s;
@@ -300,7 +313,8 @@ static void from_seq(thor_hip_params* p, const SeqParams& s) {
 static int unsupported(const SeqParams& s) {
   // This path implements the high-efficiency low-delay operating point family; reject the rest
   // loudly rather than silently producing a different stream.
-  if (s.bitdepth != 8 || s.input_bitdepth != 8) return fprintf(stderr, "thor_hip: only 8-bit is implemented in this round\n"), 1;
+  if (s.bitdepth != s.input_bitdepth || (s.bitdepth != 8 && s.bitdepth != 10 && s.bitdepth != 12))
+    return fprintf(stderr, "thor_hip: need bitdepth == input_bitdepth in {8, 10, 12}\n"), 1;
   if (s.num_reorder_pics != 0 || s.interp_ref != 0) return fprintf(stderr, "thor_hip: B frames / interpolated refs not implemented in this round\n"), 1;
   if (s.encoder_speed != 0) return fprintf(stderr, "thor_hip: encoder_speed > 0 not implemented\n"), 1;
   if (s.clpf != 0) return fprintf(stderr, "thor_hip: CLPF not implemented\n"), 1;
@@ -346,63 +360,78 @@ thor_hip_encoder* thor_hip_open(const thor_hip_params* p, int num_streams, int d
   thor_hip_encoder* e = new thor_hip_encoder;
   e->sp = s;
   e->S = num_streams;
-  e->eng.open(s, num_streams);
-  e->staged.resize(num_streams);
+  e->hbd = s.bitdepth > 8;
+  if (e->hbd) e->e16 = new EncT<uint16_t>; else e->e8 = new EncT<uint8_t>;
+  ENC_DISPATCH(e, { E.eng.open(s, num_streams); E.staged.resize(num_streams); });
   return e;
 }
 
 void thor_hip_close(thor_hip_encoder* e) {
   if (!e) return;
-  for (auto& v : e->staged)
-    for (auto& f : v)
-      if (f.base_y) f.release();
-  e->eng.close();
+  ENC_DISPATCH(e, {
+    for (auto& v : E.staged)
+      for (auto& f : v)
+        if (f.base_y) f.release();
+    E.eng.close();
+  });
+  delete e->e8;
+  delete e->e16;
   delete e;
 }
 
 int thor_hip_stage_frame(thor_hip_encoder* e, int stream, int slot, const void* yuv) {
   if (!e || stream < 0 || stream >= e->S || slot < 0 || !yuv) return 1;
-  auto& v = e->staged[stream];
-  if ((int)v.size() <= slot) v.resize(slot + 1);
-  if (!v[slot].base_y) v[slot].alloc(e->sp.width, e->sp.height, 0);
-  DevFrame<uint8_t> keep = e->eng.st[stream].orig;
-  e->eng.st[stream].orig = v[slot];
-  e->eng.upload_orig(stream, (const uint8_t*)yuv);
-  e->eng.st[stream].orig = keep;
+  ENC_DISPATCH(e, {
+    auto& v = E.staged[stream];
+    if ((int)v.size() <= slot) v.resize(slot + 1);
+    if (!v[slot].base_y) v[slot].alloc(e->sp.width, e->sp.height, 0);
+    DevFrame<PIXT> keep = E.eng.st[stream].orig;
+    E.eng.st[stream].orig = v[slot];
+    E.eng.upload_orig(stream, (const PIXT*)yuv);
+    E.eng.st[stream].orig = keep;
+  });
   return 0;
 }
 
 int thor_hip_encode_staged(thor_hip_encoder* e, const int* slots) {
   if (!e || !slots) return 1;
-  std::vector<DevFrame<uint8_t>> keep(e->S);
-  std::vector<FrameParams> fp(e->S);
-  for (int s = 0; s < e->S; s++) {
-    if (slots[s] < 0 || slots[s] >= (int)e->staged[s].size() || !e->staged[s][slots[s]].base_y) return 2;
-    keep[s] = e->eng.st[s].orig;
-    e->eng.st[s].orig = e->staged[s][slots[s]];
-    fp[s] = e->eng.next_frame_params(s);
-  }
-  e->eng.encode_frames(fp);
-  for (int s = 0; s < e->S; s++) e->eng.st[s].orig = keep[s];
-  return 0;
+  int rc = 0;
+  ENC_DISPATCH(e, {
+    std::vector<DevFrame<PIXT>> keep(e->S);
+    std::vector<FrameParams> fp(e->S);
+    for (int s = 0; s < e->S && !rc; s++)
+      if (slots[s] < 0 || slots[s] >= (int)E.staged[s].size() || !E.staged[s][slots[s]].base_y) rc = 2;
+    if (!rc) {
+      for (int s = 0; s < e->S; s++) {
+        keep[s] = E.eng.st[s].orig;
+        E.eng.st[s].orig = E.staged[s][slots[s]];
+        fp[s] = E.eng.next_frame_params(s);
+      }
+      E.eng.encode_frames(fp);
+      for (int s = 0; s < e->S; s++) E.eng.st[s].orig = keep[s];
+    }
+  });
+  return rc;
 }
 
 int thor_hip_encode_frame(thor_hip_encoder* e, const void* const* yuv) {
   if (!e || !yuv) return 1;
-  std::vector<FrameParams> fp(e->S);
-  for (int s = 0; s < e->S; s++) {
-    e->eng.upload_orig(s, (const uint8_t*)yuv[s]);
-    fp[s] = e->eng.next_frame_params(s);
-  }
-  e->eng.encode_frames(fp);
+  ENC_DISPATCH(e, {
+    std::vector<FrameParams> fp(e->S);
+    for (int s = 0; s < e->S; s++) {
+      E.eng.upload_orig(s, (const PIXT*)yuv[s]);
+      fp[s] = E.eng.next_frame_params(s);
+    }
+    E.eng.encode_frames(fp);
+  });
   return 0;
 }
 
-size_t thor_hip_stream_bytes(const thor_hip_encoder* e, int stream) { return e->eng.st[stream].out.size(); }
-const uint8_t* thor_hip_stream_data(const thor_hip_encoder* e, int stream) { return e->eng.st[stream].out.data(); }
+size_t thor_hip_stream_bytes(const thor_hip_encoder* e, int stream) { return e->hbd ? e->e16->eng.st[stream].out.size() : e->e8->eng.st[stream].out.size(); }
+const uint8_t* thor_hip_stream_data(const thor_hip_encoder* e, int stream) { return e->hbd ? e->e16->eng.st[stream].out.data() : e->e8->eng.st[stream].out.data(); }
 int thor_hip_get_recon(thor_hip_encoder* e, int stream, void* yuv_out) {
   if (!e || stream < 0 || stream >= e->S || !yuv_out) return 1;
-  e->eng.download_rec(stream, (uint8_t*)yuv_out);
+  ENC_DISPATCH(e, { E.eng.download_rec(stream, (PIXT*)yuv_out); });
   return 0;
 }
 void thor_hip_kernel_time(thor_hip_encoder*, double* sb_ms, long* sb_launches, double* filter_ms) {
@@ -410,7 +439,7 @@ void thor_hip_kernel_time(thor_hip_encoder*, double* sb_ms, long* sb_launches, d
   if (sb_launches) *sb_launches = g_clk.sb_launches;
   if (filter_ms) *filter_ms = g_clk.filt_ms;
 }
-void thor_hip_read_prof(thor_hip_encoder* e, long long out[16]) { backend::d2h(out, e->eng.d_prof, 16 * sizeof(long long)); }
+void thor_hip_read_prof(thor_hip_encoder* e, long long out[16]) { ENC_DISPATCH(e, { backend::d2h(out, E.eng.d_prof, 16 * sizeof(long long)); }); }
 void thor_hip_kernel_time_reset(thor_hip_encoder*) { g_clk.sb_ms = g_clk.filt_ms = 0; g_clk.sb_launches = 0; }
 
 }  // extern "C"
@@ -437,16 +466,20 @@ static void stream_put1(thor_stream* s, unsigned bit) {  // putbits(1, bit) of e
   s->bitrest -= 1;
 }
 
-struct SeamState {
-  Engine<uint8_t> eng;
+template <typename PIX> struct SeamState {
+  Engine<PIX> eng;
 };
-static std::map<const void*, SeamState*> g_seams;
+template <typename PIX> static std::map<const void*, SeamState<PIX>*>& seams() {
+  static std::map<const void*, SeamState<PIX>*> m;
+  return m;
+}
 
-extern "C" void encode_frame_lbd(struct thor_encoder_info* ei) {
-  if (!ei || !ei->params || !ei->orig || !ei->rec || !ei->stream) seam_fatal("encode_frame_lbd: null encoder_info member");
+template <typename PIX> static void encode_frame_impl(struct thor_encoder_info* ei) {
+  if (!ei || !ei->params || !ei->orig || !ei->rec || !ei->stream) seam_fatal("encode_frame: null encoder_info member");
+  if ((ei->params->bitdepth > 8) != (sizeof(PIX) == 2)) seam_fatal("thor_hip: frame sample size does not match params->bitdepth");
   const thor_enc_params& ep = *ei->params;
   thor_frame_info& fi = ei->frame_info;
-  SeamState*& st = g_seams[ei];
+  SeamState<PIX>*& st = seams<PIX>()[ei];
   if (!st) {
     SeqParams s;
     s.width = ei->width; s.height = ei->height; s.qp = (int)ep.qp; s.bitdepth = ep.bitdepth; s.input_bitdepth = ep.input_bitdepth;
@@ -461,11 +494,11 @@ extern "C" void encode_frame_lbd(struct thor_encoder_info* ei) {
       seam_fatal("thor_hip: unsupported encoder parameters (need 4:2:0, 128x128 SB, no qmtx / delta-QP / rate control / sync)");
     if (unsupported(s)) seam_fatal("thor_hip: unsupported encoder parameters");
     ensure_init(0);
-    st = new SeamState;
+    st = new SeamState<PIX>;
     st->eng.raw_frames = true;
     st->eng.open(s, 1);
   }
-  Engine<uint8_t>& eng = st->eng;
+  Engine<PIX>& eng = st->eng;
   if (fi.frame_type == F_B || fi.interp_ref) seam_fatal("thor_hip: B frames / interpolated references are not implemented in this round");
   FrameParams f;
   f.frame_type = fi.frame_type; f.qp = fi.qp; f.num_ref = fi.num_ref; f.frame_num = fi.frame_num; f.interp_ref = 0;
@@ -479,7 +512,7 @@ extern "C" void encode_frame_lbd(struct thor_encoder_info* ei) {
   fi.lambda = f.lambda_coeff * kSquaredLambdaQP[f.qp];
   fi.prev_qp = fi.qp;
   const thor_yuv_frame& o = *ei->orig;
-  eng.upload_planes(0, (const uint8_t*)o.y, o.stride_y, (const uint8_t*)o.u, (const uint8_t*)o.v, o.stride_c);
+  eng.upload_planes(0, (const PIX*)o.y, o.stride_y, (const PIX*)o.u, (const PIX*)o.v, o.stride_c);
   eng.st[0].num_encoded = fi.frame_num;  // only used for bookkeeping
   std::vector<FrameParams> fp(1, f);
   eng.encode_frames(fp);
@@ -490,14 +523,14 @@ extern "C" void encode_frame_lbd(struct thor_encoder_info* ei) {
   // reconstruction -> caller's rec frame
   {
     thor_yuv_frame& r = *ei->rec;
-    std::vector<uint8_t> tmp((size_t)ei->width * ei->height * 3 / 2);
+    std::vector<PIX> tmp((size_t)ei->width * ei->height * 3 / 2);
     eng.download_rec(0, tmp.data());
     const int w = ei->width, h = ei->height;
-    for (int i = 0; i < h; i++) memcpy((uint8_t*)r.y + (size_t)i * r.stride_y, &tmp[(size_t)i * w], w);
-    const uint8_t* cu = &tmp[(size_t)w * h]; const uint8_t* cv = cu + (size_t)(w / 2) * (h / 2);
+    for (int i = 0; i < h; i++) memcpy((PIX*)r.y + (size_t)i * r.stride_y, &tmp[(size_t)i * w], w * sizeof(PIX));
+    const PIX* cu = &tmp[(size_t)w * h]; const PIX* cv = cu + (size_t)(w / 2) * (h / 2);
     for (int i = 0; i < h / 2; i++) {
-      memcpy((uint8_t*)r.u + (size_t)i * r.stride_c, cu + (size_t)i * (w / 2), w / 2);
-      memcpy((uint8_t*)r.v + (size_t)i * r.stride_c, cv + (size_t)i * (w / 2), w / 2);
+      memcpy((PIX*)r.u + (size_t)i * r.stride_c, cu + (size_t)i * (w / 2), (w / 2) * sizeof(PIX));
+      memcpy((PIX*)r.v + (size_t)i * r.stride_c, cv + (size_t)i * (w / 2), (w / 2) * sizeof(PIX));
     }
   }
   // sliding window of the caller's reference pointers + padded copy (enc/encode_frame.c:826-835)
@@ -506,26 +539,24 @@ extern "C" void encode_frame_lbd(struct thor_encoder_info* ei) {
     memmove(ei->ref + 1, ei->ref, sizeof(thor_yuv_frame*) * (THOR_MAX_REF_FRAMES - 1));
     ei->ref[0] = last;
     thor_yuv_frame& d = *ei->ref[0];
-    const DevFrame<uint8_t>& g = eng.st[0].ring[0];
+    const DevFrame<PIX>& g = eng.st[0].ring[0];
     d.frame_num = ei->rec->frame_num;
     const int ph = d.pad_ver_y, pw = d.pad_hor_y, pch = d.pad_ver_c, pcw = d.pad_hor_c;
-    std::vector<uint8_t> row;
-    auto pull = [&](uint8_t* hp, int hs, const uint8_t* dp, int ds, int w, int h, int padw, int padh) {
-      std::vector<uint8_t> buf((size_t)(h + 2 * padh) * ds);
-      backend::d2h(buf.data(), dp - (size_t)padh * ds - padw, buf.size() - (size_t)(ds - (w + 2 * padw)));
+    auto pull = [&](PIX* hp, int hs, const PIX* dp, int ds, int w, int h, int padw, int padh) {
+      std::vector<PIX> buf((size_t)(h + 2 * padh) * ds);
+      backend::d2h(buf.data(), dp - (size_t)padh * ds - padw, (buf.size() - (size_t)(ds - (w + 2 * padw))) * sizeof(PIX));
       for (int i = -padh; i < h + padh; i++)
-        memcpy(hp + (ptrdiff_t)i * hs - padw, &buf[(size_t)(i + padh) * ds], w + 2 * padw);
+        memcpy(hp + (ptrdiff_t)i * hs - padw, &buf[(size_t)(i + padh) * ds], (w + 2 * padw) * sizeof(PIX));
     };
-    pull((uint8_t*)d.y, d.stride_y, g.p.y, g.p.sy, ei->width, ei->height, pw < kPadY ? pw : kPadY, ph < kPadY ? ph : kPadY);
-    pull((uint8_t*)d.u, d.stride_c, g.p.u, g.p.sc, ei->width / 2, ei->height / 2, pcw < kPadY / 2 ? pcw : kPadY / 2, pch < kPadY / 2 ? pch : kPadY / 2);
-    pull((uint8_t*)d.v, d.stride_c, g.p.v, g.p.sc, ei->width / 2, ei->height / 2, pcw < kPadY / 2 ? pcw : kPadY / 2, pch < kPadY / 2 ? pch : kPadY / 2);
+    pull((PIX*)d.y, d.stride_y, g.p.y, g.p.sy, ei->width, ei->height, pw < kPadY ? pw : kPadY, ph < kPadY ? ph : kPadY);
+    pull((PIX*)d.u, d.stride_c, g.p.u, g.p.sc, ei->width / 2, ei->height / 2, pcw < kPadY / 2 ? pcw : kPadY / 2, pch < kPadY / 2 ? pch : kPadY / 2);
+    pull((PIX*)d.v, d.stride_c, g.p.v, g.p.sc, ei->width / 2, ei->height / 2, pcw < kPadY / 2 ? pcw : kPadY / 2, pch < kPadY / 2 ? pch : kPadY / 2);
   }
   ei->cdef_damping = 5;
 }
 
-extern "C" void encode_frame_hbd(struct thor_encoder_info*) {
-  seam_fatal("thor_hip: encode_frame_hbd (16-bit sample frames) is not implemented in this round");
-}
+extern "C" void encode_frame_lbd(struct thor_encoder_info* ei) { encode_frame_impl<uint8_t>(ei); }
+extern "C" void encode_frame_hbd(struct thor_encoder_info* ei) { encode_frame_impl<uint16_t>(ei); }
 
 // ---------------------------------------------------------------------------------------------
 // C ABI - kernel-level batch entry points (known-answer tests)

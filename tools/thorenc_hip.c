@@ -40,7 +40,7 @@ int main(int argc, char** argv) {
   if (!inf) { fprintf(stderr, "usage: %s -cf cfg -if in.yuv -width W -height H -qp Q -n N ...\n", argv[0]); return 2; }
   FILE* fi = fopen(inf, "rb");
   if (!fi) { fprintf(stderr, "cannot open %s\n", inf); return 2; }
-  size_t fsz = (size_t)p.width * p.height * 3 / 2;
+  size_t fsz = (size_t)p.width * p.height * 3 / 2 * (p.bitdepth > 8 ? 2 : 1);
   unsigned char* frame = (unsigned char*)malloc(fsz);
   thor_hip_encoder* e = thor_hip_open(&p, S, 0);
   if (!e) { fprintf(stderr, "thor_hip_open failed\n"); return 3; }
