@@ -405,7 +405,8 @@ int thor_hip_encode_staged(thor_hip_encoder* e, const int* slots) {
       for (int s = 0; s < e->S; s++) {
         keep[s] = E.eng.st[s].orig;
         E.eng.st[s].orig = E.staged[s][slots[s]];
-        fp[s] = E.eng.next_frame_params(s);
+        E.eng.schedule(s);
+        fp[s] = E.eng.st[s].cur;
       }
       E.eng.encode_frames(fp);
       for (int s = 0; s < e->S; s++) E.eng.st[s].orig = keep[s];
@@ -420,7 +421,8 @@ int thor_hip_encode_frame(thor_hip_encoder* e, const void* const* yuv) {
     std::vector<FrameParams> fp(e->S);
     for (int s = 0; s < e->S; s++) {
       E.eng.upload_orig(s, (const PIXT*)yuv[s]);
-      fp[s] = E.eng.next_frame_params(s);
+      E.eng.schedule(s);
+      fp[s] = E.eng.st[s].cur;
     }
     E.eng.encode_frames(fp);
   });

@@ -671,7 +671,26 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
           unsigned cost = rdo_trial(t, J, ws, nd, p, lambda, tb > 0);
           if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
         }
-        // TODO(B frames): motion_estimate_bi joint search (encode_block.c:2052-2068)
+        if (J.frame_type == F_B && c.encoder_speed == 0) {
+          // joint +mv / -mv search (search_bipred_prediction_params me_mode 1, encode_block.c:1708-1737, 2052-2068)
+          const int ri0 = J.interp_ref ? 1 : 0, ri1 = J.interp_ref ? 2 : 1;
+          const Plane3<PIX>& f0 = J.ref[ri0];
+          const Plane3<PIX>& f1 = J.ref[ri1];
+          MeArgs a;
+          a.cb_size = size; a.ostride = J.orig.sy; a.width = size; a.height = size; a.rstride = f0.sy; a.sign = 0;
+          a.fwidth = c.width; a.fheight = c.height; a.xpos = nd.xpos; a.ypos = nd.ypos; a.enable_bipred = 1;
+          a.bitdepth = c.bitdepth; a.lam = J.sqrt_lambda;
+          mv_t mvb;
+          motion_estimate_bi(t, ws->mep, oy, f0.y + nd.ypos * f0.sy + nd.xpos, f1.y + nd.ypos * f1.sy + nd.xpos, a, mv_center[ri0],
+                             mvp, ri0, &mvb);
+          p.mode = M_BIPRED;
+          p.pb_part = P_NONE;
+          p.ref0 = (int8_t)ri0; p.ref1 = (int8_t)ri1;
+          for (int i = 0; i < 4; i++) { p.mv0[i] = mvb; p.mv1[i] = mvb; }
+          p.tb_param = 0;
+          unsigned cost = rdo_trial(t, J, ws, nd, p, lambda);
+          if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
+        }
       }
     }
     // intra (encode_block.c:2070-2114).  The reference re-encodes the winning mode for both

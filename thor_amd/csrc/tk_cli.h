@@ -60,6 +60,22 @@ static inline void cli_apply(CliArgs& a, const std::vector<std::string>& t) {
     else if (k == "-num_reorder_pics") p.num_reorder_pics = I();
     else if (k == "-interp_ref") p.interp_ref = I();
     else if (k == "-dqpP") p.dqpP = I();
+    else if (k == "-dqpB") p.dqpB = I();
+    else if (k == "-dqpB0") p.dqpB0 = I();
+    else if (k == "-dqpB1") p.dqpB1 = I();
+    else if (k == "-dqpB2") p.dqpB2 = I();
+    else if (k == "-dqpB3") p.dqpB3 = I();
+    else if (k == "-mqpB") p.mqpB = F();
+    else if (k == "-mqpB0") p.mqpB0 = F();
+    else if (k == "-mqpB1") p.mqpB1 = F();
+    else if (k == "-mqpB2") p.mqpB2 = F();
+    else if (k == "-mqpB3") p.mqpB3 = F();
+    else if (k == "-lambda_coeffB") p.lambda_coeffB = F();
+    else if (k == "-lambda_coeffB0") p.lambda_coeffB0 = F();
+    else if (k == "-lambda_coeffB1") p.lambda_coeffB1 = F();
+    else if (k == "-lambda_coeffB2") p.lambda_coeffB2 = F();
+    else if (k == "-lambda_coeffB3") p.lambda_coeffB3 = F();
+    else if (k == "-dyadic_coding") p.dyadic_coding = I();
     else if (k == "-dqpI") p.dqpI = I();
     else if (k == "-mqpP") p.mqpP = F();
     else if (k == "-intra_period") p.intra_period = I();
@@ -108,21 +124,40 @@ template <typename PIX> int cli_run(const CliArgs& a) {
   auto name = [&](const std::string& base, int s) { return a.streams == 1 ? base : base + "." + std::to_string(s); };
   for (int s = 0; s < a.streams; s++)
     if (!a.recfile.empty()) fr[s] = fopen(name(a.recfile, s).c_str(), "wb");
-  for (int n = 0; n < a.num_frames; n++) {
+  // all streams run in lock step through their (identical) coding-order schedules
+  fseek(fi, 0, SEEK_END);
+  const int file_frames = (int)(ftell(fi) / (long)(fsz * sizeof(PIX)));
+  for (int s = 0; s < a.streams; s++) eng.begin_sequence(s, a.skip + s * a.num_frames, a.num_frames, file_frames);
+  std::vector<std::vector<PIX>> recs((size_t)a.streams * a.num_frames);  // recon in display order
+  for (;;) {
     std::vector<FrameParams> fp(a.streams);
+    int active = 0;
     for (int s = 0; s < a.streams; s++) {
-      size_t idx = (size_t)a.skip + (size_t)s * a.num_frames + n;
+      if (!eng.schedule(s)) continue;
+      active++;
+      size_t idx = (size_t)eng.st[s].cur_abs;
       if (fseek(fi, (long)(idx * fsz * sizeof(PIX)), SEEK_SET) || fread(frame.data(), sizeof(PIX), fsz, fi) != fsz) {
         fprintf(stderr, "short read at frame %zu\n", idx);
         return 3;
       }
       eng.upload_orig(s, frame.data());
-      fp[s] = eng.next_frame_params(s);
+      fp[s] = eng.st[s].cur;
     }
+    if (!active) break;
+    if (active != a.streams) { fprintf(stderr, "streams out of step\n"); return 4; }
     eng.encode_frames(fp);
     for (int s = 0; s < a.streams; s++)
-      if (fr[s]) { eng.download_rec(s, rec.data()); fwrite(rec.data(), sizeof(PIX), fsz, fr[s]); }
+      if (fr[s]) {
+        eng.download_rec(s, rec.data());
+        recs[(size_t)s * a.num_frames + fp[s].frame_num] = rec;
+      }
   }
+  for (int s = 0; s < a.streams; s++)
+    if (fr[s])
+      for (int n = 0; n < a.num_frames; n++) {
+        const std::vector<PIX>& r = recs[(size_t)s * a.num_frames + n];
+        if (!r.empty()) fwrite(r.data(), sizeof(PIX), fsz, fr[s]);
+      }
   for (int s = 0; s < a.streams; s++) {
     if (fr[s]) fclose(fr[s]);
     if (!a.outfile.empty()) {

@@ -43,12 +43,12 @@ struct SeqParams {  // the enc_params fields this path honours (enc/mainenc.h:35
   int width = 0, height = 0, qp = 32;
   int bitdepth = 8, input_bitdepth = 8;
   float frame_rate = 30.f;
-  float lambda_coeffI = 1.f, lambda_coeffP = 1.f;
+  float lambda_coeffI = 1.f, lambda_coeffP = 1.f, lambda_coeffB = 1.f, lambda_coeffB0 = 1.f, lambda_coeffB1 = 1.f, lambda_coeffB2 = 1.f, lambda_coeffB3 = 1.f;
   float early_skip_thr = 0.f;
   int enable_tb_split = 0, enable_pb_split = 0, max_num_ref = 1, HQperiod = 1;
   int num_reorder_pics = 0, dyadic_coding = 1, interp_ref = 0;
-  int dqpP = 0, dqpI = 0;
-  float mqpP = 1.f;
+  int dqpP = 0, dqpI = 0, dqpB = 0, dqpB0 = 0, dqpB1 = 0, dqpB2 = 0, dqpB3 = 0;
+  float mqpP = 1.f, mqpB = 1.f, mqpB0 = 1.f, mqpB1 = 1.f, mqpB2 = 1.f, mqpB3 = 1.f;
   int intra_period = 0, intra_rdo = 0, encoder_speed = 0;
   int deblocking = 1, cdef = 2, clpf = 0, use_block_contexts = 0, enable_bipred = 0;
   int cfl_intra = 1, cfl_inter = 0;
@@ -57,8 +57,160 @@ struct SeqParams {  // the enc_params fields this path honours (enc/mainenc.h:35
 
 struct FrameParams {
   int frame_type = F_I, qp = 32, num_ref = 0, frame_num = 0, interp_ref = 0, num_intra_modes = 10;
-  int ref_array[kMaxRefs] = {0, 0, 0, 0};  // indices into the sliding window (0 = most recent)
+  int ref_array[kMaxRefs] = {0, 0, 0, 0};  // indices into the sliding window (0 = most recent); -1 = interpolated frame
   double lambda_coeff = 1.0;
+  int b_level = 0;
+};
+
+// Coding-order schedule of one stream: a resumable restatement of the frame loop of enc/mainenc.c:246-625
+// (frame types, QPs, b_level, reference lists for low-delay and dyadic hierarchical-B GOPs, the fall-back
+// to PPP coding for a tail that does not fill a sub-GOP, duplicate / pre-intra reference removal).
+// frame numbers are relative to `skip` like encoder_info.frame_info.frame_num.
+struct GopScheduler {
+  SeqParams sp;             // HQperiod / num_reorder_pics mutate at the tail exactly like the reference's params
+  int skip = 0, num_frames = 0, file_frames = 0;
+  int frame_num0 = 0, k = 0, sub_gop = 1, num_encoded = 0, last_intra = 0, last_PorI = -1, min_interp_depth = 0;
+  bool started = false;
+  static int ilog2i(unsigned v) { int n = 0; while (v >>= 1) n++; return n; }
+  static int code_to_display(int sub, int idx) {
+    static const int cd1[1] = {0}, cd2[2] = {1, 0}, cd4[4] = {3, 1, 0, 2}, cd8[8] = {7, 3, 1, 5, 0, 2, 4, 6},
+                     cd16[16] = {15, 7, 3, 11, 1, 5, 9, 13, 0, 2, 4, 6, 8, 10, 12, 14};
+    const int* t[5] = {cd1, cd2, cd4, cd8, cd16};
+    return t[ilog2i(sub)][idx];
+  }
+  static int display_to_code(int sub, int idx) {
+    static const int dc1[2] = {-1, 0}, dc2[3] = {-2, 1, 0}, dc4[5] = {-4, 2, 1, 3, 0}, dc8[9] = {-8, 4, 2, 5, 1, 6, 3, 7, 0},
+                     dc16[17] = {-16, 8, 4, 9, 2, 10, 5, 11, 1, 12, 6, 13, 3, 14, 7, 15, 0};
+    const int* t[5] = {dc1, dc2, dc4, dc8, dc16};
+    return t[ilog2i(sub)][idx];
+  }
+  void init(const SeqParams& p, int skip_, int nframes, int file_frames_) {
+    sp = p; skip = skip_; num_frames = nframes; file_frames = file_frames_;
+    sub_gop = p.num_reorder_pics + 1 > 1 ? p.num_reorder_pics + 1 : 1;
+    min_interp_depth = ilog2i((unsigned)(p.num_reorder_pics + 1)) - 3;
+    if (p.frame_rate > 30) min_interp_depth--;
+    frame_num0 = skip; k = 0; num_encoded = 0; last_intra = 0; last_PorI = -1; started = true;
+  }
+  // ring_frame_num(idx): frame_num of the reconstruction currently at sliding-window position idx.
+  // Returns false when the sequence is finished; otherwise fills f and the absolute input frame index.
+  template <class RingF> bool next(FrameParams& f, int& abs_frame, RingF ring_frame_num) {
+    for (;;) {
+      if (!(frame_num0 < skip + num_frames && frame_num0 + 1 <= file_frames)) return false;
+      if (k >= sub_gop) {
+        // end of a sub-GOP: tail fall-back (mainenc.c:615-623)
+        if ((frame_num0 + sub_gop + 1 > file_frames || frame_num0 + sub_gop >= skip + num_frames) && sub_gop >= 2) {
+          sp.HQperiod = sub_gop; sub_gop = 1; sp.num_reorder_pics = 0;
+        }
+        frame_num0 += sub_gop;  // the for-increment runs after the fall-back, i.e. with the NEW sub_gop
+        k = 0;
+        continue;
+      }
+      const int dyadic = sp.dyadic_coding;
+      int frame_offset;
+      if (dyadic && sub_gop > 1) frame_offset = code_to_display(sub_gop, k) - sub_gop + 1;
+      else frame_offset = k == 0 ? 0 : k - sub_gop;
+      const int frame_num_abs = frame_num0 + frame_offset;
+      k++;
+      if (frame_num_abs < skip) continue;
+      f = FrameParams();
+      f.frame_num = frame_num_abs - skip;
+      abs_frame = frame_num_abs;
+      if (sp.num_reorder_pics == 0) {
+        if (sp.intra_period > 0) f.frame_type = (num_encoded % sp.intra_period) == 0 ? F_I : F_P;
+        else f.frame_type = num_encoded == 0 ? F_I : F_P;
+      } else {
+        if (sp.intra_period > 0) f.frame_type = (f.frame_num % sp.intra_period) == 0 ? F_I : ((f.frame_num % sub_gop) == 0 ? F_P : F_B);
+        else f.frame_type = f.frame_num == 0 ? F_I : ((f.frame_num % sub_gop) == 0 ? F_P : F_B);
+      }
+      const int coded_phase = (num_encoded + sub_gop - 2) % sub_gop + 1;
+      const int b_level = ilog2i((unsigned)coded_phase);
+      f.b_level = b_level;
+      if (f.frame_type == F_I) { f.qp = sp.qp + sp.dqpI; last_intra = f.frame_num; }
+      else if (sp.num_reorder_pics == 0) {
+        if (num_encoded % sp.HQperiod) f.qp = (int)(sp.mqpP * (float)sp.qp) + sp.dqpP; else f.qp = sp.qp;
+      } else {
+        if (f.frame_num % sub_gop) {
+          if (dyadic) {
+            if (b_level == 0) f.qp = (int)(sp.mqpB0 * (float)sp.qp) + sp.dqpB0;
+            else if (b_level == 1) f.qp = (int)(sp.mqpB1 * (float)sp.qp) + sp.dqpB1;
+            else if (b_level == 2) f.qp = (int)(sp.mqpB2 * (float)sp.qp) + sp.dqpB2;
+            else if (b_level == 3) f.qp = (int)(sp.mqpB3 * (float)sp.qp) + sp.dqpB3;
+            else f.qp = (int)(sp.mqpB * (float)sp.qp) + sp.dqpB;
+          } else f.qp = (int)(sp.mqpB * (float)sp.qp) + sp.dqpB;
+        } else {
+          if (f.frame_num % sp.HQperiod) f.qp = (int)(sp.mqpP * (float)sp.qp) + sp.dqpP; else f.qp = sp.qp;
+        }
+      }
+      f.qp = f.qp < 0 ? 0 : (f.qp > 51 ? 51 : f.qp);
+      f.num_ref = f.frame_type == F_I ? 0 : (num_encoded < sp.max_num_ref ? num_encoded : sp.max_num_ref);
+      f.interp_ref = 0;
+      int ra[kMaxRefs + 2] = {0, 0, 0, 0, 0, 0};
+      auto imin = [](int a, int b) { return a < b ? a : b; };
+      if (f.num_ref > 0) {
+        if (sp.num_reorder_pics > 0) {
+          if (dyadic) {
+            if ((num_encoded - 1) % sub_gop == 0) {  // P frame: previous anchors
+              ra[0] = num_encoded == 1 ? 0 : sub_gop - 1;
+              if (f.num_ref > 1) ra[1] = imin(32, imin(num_encoded - 1, 2 * sub_gop - 1));
+              for (int r = 2; r < f.num_ref; r++) ra[r] = r - 2;
+            } else {
+              const int display_phase = (f.frame_num - 1) % sub_gop;
+              const int ref_offset = sub_gop >> (b_level + 1);
+              if (b_level >= min_interp_depth && sp.interp_ref == 1) {
+                if (f.num_ref == 2) f.num_ref++;
+                f.interp_ref = sp.interp_ref;
+                ra[1] = imin(num_encoded - 1, coded_phase - display_to_code(sub_gop, display_phase - ref_offset + 1) - 1);
+                ra[2] = imin(num_encoded - 1, coded_phase - display_to_code(sub_gop, display_phase + ref_offset + 1) - 1);
+                ra[0] = -1;
+                for (int r = 3; r < f.num_ref; r++) ra[r] = r - 3;
+              } else {
+                ra[0] = imin(num_encoded - 1, coded_phase - display_to_code(sub_gop, display_phase - ref_offset + 1) - 1);
+                ra[1] = imin(num_encoded - 1, coded_phase - display_to_code(sub_gop, display_phase + ref_offset + 1) - 1);
+                for (int r = 2; r < f.num_ref; r++) ra[r] = r - 2;
+              }
+            }
+          } else {
+            fprintf(stderr, "thor_hip: non-dyadic reordering is not implemented\n");
+            abort();
+          }
+        } else {
+          ra[0] = last_PorI;
+          const int r1 = ((num_encoded + sp.HQperiod - 2) % sp.HQperiod) + 1;
+          const int r2 = r1 == 1 ? 2 : 1;
+          int r3 = r2 + 1;
+          if (r3 == r1) r3 += 1;
+          if (f.num_ref == 2) ra[1] = r1;
+          else if (f.num_ref == 3) { ra[1] = r1; ra[2] = r2; }
+          else if (f.num_ref == 4) { ra[1] = r1; ra[2] = r2; ra[3] = r3; }
+        }
+      }
+      for (int r = f.num_ref - 1; r > 0; --r)
+        for (int q = r - 1; q >= 0; --q)
+          if (ra[q] == ra[r]) {
+            for (int s2 = r; s2 < f.num_ref - 1; ++s2) ra[s2] = ra[s2 + 1];
+            f.num_ref--;
+            break;
+          }
+      if (f.frame_num > last_intra)
+        for (int r = f.num_ref - 1; r >= 0; --r)
+          if (ra[r] >= 0 && ring_frame_num(ra[r]) < last_intra) {
+            for (int s2 = r; s2 < f.num_ref - 1; ++s2) ra[s2] = ra[s2 + 1];
+            f.num_ref--;
+          }
+      for (int r = 0; r < kMaxRefs; r++) f.ref_array[r] = ra[r];
+      f.num_intra_modes = (sp.intra_rdo == 0 || (f.frame_type != F_I && sp.encoder_speed > 0)) ? 4 : 10;
+      if (f.frame_type == F_I) f.lambda_coeff = sp.lambda_coeffI;
+      else if (f.frame_type == F_P) f.lambda_coeff = sp.lambda_coeffP;
+      else f.lambda_coeff = b_level == 0 ? sp.lambda_coeffB0 : b_level == 1 ? sp.lambda_coeffB1 : b_level == 2 ? sp.lambda_coeffB2
+                                                                              : b_level == 3 ? sp.lambda_coeffB3 : sp.lambda_coeffB;
+      return true;
+    }
+  }
+  // call after the frame returned by next() has been encoded (mainenc.c:552, 611)
+  void advance(const FrameParams& f) {
+    num_encoded++;
+    last_PorI = f.frame_type != F_B ? 0 : last_PorI + 1;
+  }
 };
 
 // ---- host bit writer (MSB first) ---------------------------------------------------------
@@ -160,6 +312,9 @@ template <typename PIX> struct Stream {
   int8_t* cdef_dir = nullptr; int* cdef_var = nullptr; int* cdef_fbc = nullptr; unsigned long long* cdef_mse = nullptr;
   int* cdef_sel = nullptr; int* cdef_fbsel = nullptr; CdefResult* cdef_res = nullptr; unsigned long long* cdef_tot = nullptr;
   int num_encoded = 0;
+  GopScheduler gop;          // coding-order schedule (initialised by begin_sequence or lazily as open-ended low delay)
+  FrameParams cur;           // frame returned by the last schedule()
+  int cur_abs = 0;           // its absolute input frame index
   HostBits bits;             // bits of the frame being assembled (sequence header rides on frame 0)
   std::vector<uint8_t> out;  // finished stream bytes (4-byte big-endian length + payload per frame)
 };
@@ -193,6 +348,8 @@ template <typename PIX> class Engine {
     }
     nfb_h = (p.width + 63) >> 6; nfb_v = (p.height + 63) >> 6;
     ring_size = (p.HQperiod > p.max_num_ref ? p.HQperiod : p.max_num_ref) + 1;
+    if (p.num_reorder_pics > 0) ring_size = 2 * (p.num_reorder_pics + 1) + 1 > ring_size ? 2 * (p.num_reorder_pics + 1) + 1 : ring_size;
+    if (ring_size > 33) ring_size = 33;
     ws_bytes = (backend::team_ws_bytes((int)sizeof(PIX)) + 255) & ~(size_t)255;
     st.resize(S);
     d_nbits_all = (int*)backend::dev_alloc((size_t)S * nsb * sizeof(int));
@@ -287,49 +444,14 @@ template <typename PIX> class Engine {
     for (int i = 0; i < h / 2; i++) memcpy(cv + (size_t)i * (w / 2), &tmp[(size_t)i * f.p.sc], (w / 2) * sizeof(PIX));
   }
 
-  // Low-delay GOP decisions for the next frame of stream s (enc/mainenc.c:261-523, num_reorder_pics == 0).
-  FrameParams next_frame_params(int s) const {
-    const Stream<PIX>& q = st[s];
-    const int n = q.num_encoded;
-    FrameParams f;
-    f.frame_num = n;
-    if (sp.intra_period > 0) f.frame_type = (n % sp.intra_period) == 0 ? F_I : F_P;
-    else f.frame_type = n == 0 ? F_I : F_P;
-    if (f.frame_type == F_I) f.qp = sp.qp + sp.dqpI;
-    else if (n % sp.HQperiod) f.qp = (int)(sp.mqpP * (float)sp.qp) + sp.dqpP;
-    else f.qp = sp.qp;
-    f.qp = f.qp < 0 ? 0 : (f.qp > 51 ? 51 : f.qp);
-    f.num_ref = f.frame_type == F_I ? 0 : (n < sp.max_num_ref ? n : sp.max_num_ref);
-    if (f.num_ref >= 1) f.ref_array[0] = 0;
-    if (f.num_ref >= 2) {
-      int r1 = ((n + sp.HQperiod - 2) % sp.HQperiod) + 1;
-      f.ref_array[1] = r1;
-      if (f.num_ref >= 3) {
-        int r2 = r1 == 1 ? 2 : 1;
-        f.ref_array[2] = r2;
-        if (f.num_ref == 4) { int r3 = r2 + 1; if (r3 == r1) r3 += 1; f.ref_array[3] = r3; }
-      }
-    }
-    for (int r = f.num_ref - 1; r > 0; --r)
-      for (int k = r - 1; k >= 0; --k)
-        if (f.ref_array[k] == f.ref_array[r]) {
-          for (int t = r; t < f.num_ref - 1; ++t) f.ref_array[t] = f.ref_array[t + 1];
-          f.num_ref--;
-          break;
-        }
-    // references older than the last intra frame are dropped (mainenc.c:506-518)
-    if (sp.intra_period > 0) {
-      int last_intra = (n / sp.intra_period) * sp.intra_period;
-      if (n > last_intra)
-        for (int r = f.num_ref - 1; r >= 0; --r)
-          if (q.ring[f.ref_array[r]].frame_num < last_intra) {
-            for (int t = r; t < f.num_ref - 1; ++t) f.ref_array[t] = f.ref_array[t + 1];
-            f.num_ref--;
-          }
-    }
-    f.num_intra_modes = (sp.intra_rdo == 0 || (f.frame_type != F_I && sp.encoder_speed > 0)) ? 4 : 10;
-    f.lambda_coeff = f.frame_type == F_I ? sp.lambda_coeffI : sp.lambda_coeffP;
-    return f;
+  // Coding-order schedule.  begin_sequence fixes the chunk [skip, skip+num_frames) of an input holding
+  // file_frames frames (needed for the reference's end-of-sequence behaviour with reordered GOPs).
+  void begin_sequence(int s, int skip, int num_frames, int file_frames) { st[s].gop.init(sp, skip, num_frames, file_frames); }
+  // Next frame to code for stream s: fills st[s].cur / st[s].cur_abs; false when the chunk is finished.
+  bool schedule(int s) {
+    Stream<PIX>& q = st[s];
+    if (!q.gop.started) q.gop.init(sp, 0, 1 << 28, 1 << 28);
+    return q.gop.next(q.cur, q.cur_abs, [&](int idx) { return q.ring[idx].frame_num; });
   }
 
   // Encode one frame per stream (origs already uploaded). Appends to st[s].out.
@@ -462,6 +584,7 @@ template <typename PIX> class Engine {
         write_cdef_params(b, cdef_pos, 1, ch);
       }
       q.num_encoded++;
+      if (q.gop.started) q.gop.advance(f);
       if (raw_frames) continue;
       // flush_all_bits framing (putbits.c:45-83)
       uint32_t nbytes = (uint32_t)b.num_bytes();

@@ -402,4 +402,87 @@ TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const 
   return cmin < min_sad ? cmin : min_sad;
 }
 
+
+// motion_estimate_bi (enc/encode_block.c:798-914): joint search of ONE vector used as +mv on ref0 and
+// -mv on ref1 (B frames, encoder_speed 0).  3x3 telescope from 8 px down to 1/4 px around the rounded
+// centre, then six "extra" candidates read from the per-SB candidate list of r_idx0 - including the
+// reference's side effect on that list (slots [num..3] zero-filled, slots 4 and 5 overwritten with mvp
+// and (0,0) without touching the count) and its use of the list's full-pel entries
+// as quarter-pel vectors.  The vector is clipped for ref0's sign and then AGAIN for ref1's sign; ref0 is
+// predicted with the once-clipped vector, ref1 and the cost use the twice-clipped one.
+template <typename PIX>
+TK_DEVNI unsigned motion_estimate_bi(const Team& t, MeWs* w, const PIX* org, const PIX* ref0, const PIX* ref1, const MeArgs& a,
+                                    mv_t mvc, mv_t mvp, int r_idx0, mv_t* mv_out) {
+  const int sh = a.bitdepth - 8;
+  const int size = a.cb_size;
+  unsigned min_sad = kCostInit;
+  mv_t mv_opt = mk_mv(0, 0);
+  mv_t mv_ref = mk_mv(((mvc.x + 2) >> 2) << 2, ((mvc.y + 2) >> 2) << 2);
+  struct BI { mv_t mv; SubPel s0, s1; };
+  auto mk_bi = [&](mv_t mv) -> BI {
+    BI x;
+    mv_t m0 = clip_mv(mv, a.ypos, a.xpos, a.fwidth, a.fheight, size, size, a.sign);
+    mv_t m1 = clip_mv(m0, a.ypos, a.xpos, a.fwidth, a.fheight, size, size, 1 - a.sign);
+    x.mv = m1;
+    x.s0 = luma_setup(m0, a.sign, size, size, a.fwidth, a.fheight, a.xpos, a.ypos, a.enable_bipred);
+    x.s1 = luma_setup(m1, 1 - a.sign, size, size, a.fwidth, a.fheight, a.xpos, a.ypos, a.enable_bipred);
+    return x;
+  };
+  const Div2 dw = mk_div(size);
+  auto bi_item = [&](const BI& x, int r) -> int {
+    int i, j;
+    split2(dw, r, i, j);
+    int p0 = luma_sample(ref0, a.rstride, i, j, x.s0, a.enable_bipred, a.bitdepth);
+    int p1 = luma_sample(ref1, a.rstride, i, j, x.s1, a.enable_bipred, a.bitdepth);
+    return iabs((int)org[i * a.ostride + j] - ((p0 + p1) >> 1));
+  };
+  auto bi_cost = [&](int, const BI& x, int sad) -> unsigned {
+    return ((unsigned)sad >> sh) + mv_cost(a.lam, (int16_t)(x.mv.y - mvp.y), (int16_t)(x.mv.x - mvp.x));
+  };
+  for (int step = 32; step > 0; step >>= 1) {
+    // candidate list of this step in the reference's (k outer = y, l inner = x) order
+    int ox[9], oy[9], n = 0;
+    const int vf = mv_ref.y & 3, hf = mv_ref.x & 3;
+    for (int k = -step; k <= step; k += step)
+      for (int l = -step; l <= step; l += step) {
+        if (step < 32 && k == 0 && l == 0) continue;
+        if (step == 1) {
+          int skip;
+          if (vf == 0 && hf == 0) skip = iabs(k) != iabs(l);
+          else if (vf == 2 && hf == 2) skip = 1;
+          else skip = iabs(k) == iabs(l);
+          if (skip) continue;
+        }
+        ox[n] = l; oy[n] = k; n++;
+      }
+    if (n > 0) {
+      const mv_t centre = mv_ref;
+      auto cand = [&](int c) -> BI {
+        int x = 0, y = 0;
+        for (int q = 0; q < 9; q++) if (q == c) { x = ox[q]; y = oy[q]; }
+        return mk_bi(mk_mv(centre.x + x, centre.y + y));
+      };
+      unsigned long long k = eval_min(t, n, size * size, cand, bi_item, bi_cost);
+      if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = cand((int)(unsigned)k).mv; }
+    }
+    mv_ref = mv_opt;
+  }
+  // extra candidates (+ side effect on the shared list)
+  t.sync();
+  if (t.rank == 0) {
+    for (int idx = w->mvcand_num[r_idx0]; idx < 4; idx++) w->mvcand[r_idx0][idx] = mk_mv(0, 0);
+    w->mvcand[r_idx0][4] = mvp;
+    w->mvcand[r_idx0][5] = mk_mv(0, 0);
+  }
+  t.sync();
+  {
+    auto cand = [&](int c) -> BI { return mk_bi(w->mvcand[r_idx0][c]); };
+    unsigned long long k = eval_min(t, 6, size * size, cand, bi_item, bi_cost);
+    if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = cand((int)(unsigned)k).mv; }
+  }
+  t.sync();
+  *mv_out = mv_opt;
+  return min_sad;
+}
+
 }  // namespace tk
