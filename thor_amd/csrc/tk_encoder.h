@@ -15,6 +15,7 @@
 #include "tk_common.h"
 #include "tk_tables.h"
 #include "tk_cdef.h"
+#include "tk_interp.h"
 
 namespace tk {
 
@@ -58,6 +59,7 @@ struct SeqParams {  // the enc_params fields this path honours (enc/mainenc.h:35
 struct FrameParams {
   int frame_type = F_I, qp = 32, num_ref = 0, frame_num = 0, interp_ref = 0, num_intra_modes = 10;
   int ref_array[kMaxRefs] = {0, 0, 0, 0};  // indices into the sliding window (0 = most recent); -1 = interpolated frame
+  int interp_src[2] = {0, 0};              // window indices the interpolated frame is built from (before pruning)
   double lambda_coeff = 1.0;
   int b_level = 0;
 };
@@ -162,6 +164,7 @@ struct GopScheduler {
                 ra[1] = imin(num_encoded - 1, coded_phase - display_to_code(sub_gop, display_phase - ref_offset + 1) - 1);
                 ra[2] = imin(num_encoded - 1, coded_phase - display_to_code(sub_gop, display_phase + ref_offset + 1) - 1);
                 ra[0] = -1;
+                f.interp_src[0] = ra[1]; f.interp_src[1] = ra[2];
                 for (int r = 3; r < f.num_ref; r++) ra[r] = r - 3;
               } else {
                 ra[0] = imin(num_encoded - 1, coded_phase - display_to_code(sub_gop, display_phase - ref_offset + 1) - 1);
@@ -301,7 +304,7 @@ template <typename PIX> struct DevFrame {
 };
 
 template <typename PIX> struct Stream {
-  DevFrame<PIX> orig, rec, tmp;
+  DevFrame<PIX> orig, rec, tmp, interp;
   std::vector<DevFrame<PIX>> ring;  // sliding window, ring[0] = most recent reconstruction
   DbCell* cells = nullptr;
   uint32_t* sb_bits = nullptr;
@@ -363,6 +366,7 @@ template <typename PIX> class Engine {
       s.tmp.alloc(p.width, p.height, 0);
       s.ring.resize(ring_size);
       for (auto& r : s.ring) r.alloc(p.width, p.height, kPadY);
+      if (p.interp_ref) s.interp.alloc(p.width, p.height, kPadY);
       s.cells = (DbCell*)backend::dev_alloc((size_t)cw * chh * sizeof(DbCell));
       backend::dev_memset(s.cells, 0, (size_t)cw * chh * sizeof(DbCell));
       s.sb_bits = (uint32_t*)backend::dev_alloc((size_t)nsb * kSbWords * 4);
@@ -386,7 +390,7 @@ template <typename PIX> class Engine {
   }
   void close() {
     for (auto& s : st) {
-      s.orig.release(); s.rec.release(); s.tmp.release();
+      s.orig.release(); s.rec.release(); s.tmp.release(); s.interp.release();
       backend::dev_free(s.cdef_dir); backend::dev_free(s.cdef_var); backend::dev_free(s.cdef_fbc); backend::dev_free(s.cdef_mse);
       backend::dev_free(s.cdef_sel); backend::dev_free(s.cdef_fbsel); backend::dev_free(s.cdef_res); backend::dev_free(s.cdef_tot);
       for (auto& r : s.ring) r.release();
@@ -454,6 +458,24 @@ template <typename PIX> class Engine {
     return q.gop.next(q.cur, q.cur_abs, [&](int idx) { return q.ring[idx].frame_num; });
   }
 
+  // Temporally interpolated reference (enc/mainenc.c:350-355): normative CPU-side step between frames in the
+  // reference too; the two padded window frames are read back, interpolated on the host (tk_interp.h), padded
+  // and uploaded as the stream's `interp` frame.
+  void make_interp_frame(Stream<PIX>& q, const FrameParams& f) {
+    const int w = sp.width, h = sp.height;
+    interp::HFrame<PIX> a, b, o;
+    a.alloc(w, h, kPadY); b.alloc(w, h, kPadY); o.alloc(w, h, kPadY);
+    const DevFrame<PIX>& ra = q.ring[f.interp_src[0]];
+    const DevFrame<PIX>& rb = q.ring[f.interp_src[1]];
+    backend::d2h(a.by.data(), ra.base_y, a.by.size() * sizeof(PIX)); backend::d2h(a.bc.data(), ra.base_c, a.bc.size() * sizeof(PIX));
+    backend::d2h(b.by.data(), rb.base_y, b.by.size() * sizeof(PIX)); backend::d2h(b.bc.data(), rb.base_c, b.bc.size() * sizeof(PIX));
+    interp::interpolate_frames(o, a, b, 2, 1);
+    o.pad_all();
+    backend::h2d(q.interp.base_y, o.by.data(), o.by.size() * sizeof(PIX));
+    backend::h2d(q.interp.base_c, o.bc.data(), o.bc.size() * sizeof(PIX));
+    q.interp.frame_num = f.frame_num;
+  }
+
   // Encode one frame per stream (origs already uploaded). Appends to st[s].out.
   void encode_frames(const std::vector<FrameParams>& fp) {
     for (int s = 0; s < S; s++) {
@@ -472,8 +494,9 @@ template <typename PIX> class Engine {
       J.lambda = f.lambda_coeff * kSquaredLambdaQP[f.qp];
       J.sqrt_lambda = sqrt(J.lambda);
       J.orig = q.orig.p; J.rec = q.rec.p;
+      if (f.interp_ref) make_interp_frame(q, f);
       for (int r = 0; r < f.num_ref; r++) {
-        const DevFrame<PIX>& rf = q.ring[f.ref_array[r]];
+        const DevFrame<PIX>& rf = f.ref_array[r] < 0 ? q.interp : q.ring[f.ref_array[r]];
         J.ref[r] = rf.p;
         J.sign[r] = rf.frame_num > f.frame_num;
         J.sign_ge[r] = rf.frame_num >= f.frame_num;
