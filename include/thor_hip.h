@@ -49,6 +49,11 @@ typedef struct thor_hip_params { /* the enc_params fields this path honours (enc
   int intra_period, intra_rdo, encoder_speed;
   int deblocking, cdef, clpf, use_block_contexts, enable_bipred;
   int cfl_intra, cfl_inter;
+  /* hierarchical-B coding (num_reorder_pics > 0; enc/mainenc.c:270-345) */
+  int dyadic_coding;
+  float lambda_coeffB, lambda_coeffB0, lambda_coeffB1, lambda_coeffB2, lambda_coeffB3;
+  int dqpB, dqpB0, dqpB1, dqpB2, dqpB3;
+  float mqpB, mqpB0, mqpB1, mqpB2, mqpB3;
 } thor_hip_params;
 
 typedef struct thor_hip_encoder thor_hip_encoder;
@@ -64,6 +69,15 @@ int thor_hip_device_count(void);
 thor_hip_encoder* thor_hip_open(const thor_hip_params* p, int num_streams, int device);
 void thor_hip_close(thor_hip_encoder* e);
 
+/* Coding-order schedule (the frame loop of enc/mainenc.c:246-625).  thor_hip_begin_sequence fixes the
+ * chunk [skip, skip + num_frames) of an input holding file_frames frames for one stream; without it a
+ * stream is an open-ended low-delay sequence starting at frame 0.  thor_hip_next_frame returns 1 and the
+ * chunk-relative DISPLAY index of the next frame to code (B frames are coded out of display order), or 0
+ * when the chunk is finished; the following encode call must be given exactly that frame.  Calling it is
+ * optional for low-delay streams (coding order == display order). */
+int thor_hip_begin_sequence(thor_hip_encoder* e, int stream, int skip, int num_frames, int file_frames);
+int thor_hip_next_frame(thor_hip_encoder* e, int stream, int* display_index);
+
 /* Copy one planar 4:2:0 frame (bitdepth 8: bytes; >8: little-endian uint16) of stream `stream`
  * into HBM staging slot `slot` (slots are allocated on demand). */
 int thor_hip_stage_frame(thor_hip_encoder* e, int stream, int slot, const void* yuv);
@@ -77,7 +91,8 @@ int thor_hip_encode_frame(thor_hip_encoder* e, const void* const* yuv_per_stream
  * the reference writes with -of). The pointer stays valid until the next encode call. */
 size_t thor_hip_stream_bytes(const thor_hip_encoder* e, int stream);
 const uint8_t* thor_hip_stream_data(const thor_hip_encoder* e, int stream);
-/* Reconstruction of the most recent frame of a stream (what the reference writes with -rf). */
+/* Reconstruction of the most recently CODED frame of a stream (the reference writes these with -rf in
+ * display order). */
 int thor_hip_get_recon(thor_hip_encoder* e, int stream, void* yuv_out);
 
 /* HIP-event time (ms) and launch count of the superblock kernel accumulated since the last

@@ -16,18 +16,26 @@ CASES = {
     # 10-bit samples (uint16 LE), the reference's _hbd code path
     '192x128_n4_q32_10bit': ('clip10_192x128_5.yuv.gz', 192, 128, 4, 32, ['-bitdepth', '10', '-input_bitdepth', '10']),
     '192x128_n3_q40_10bit_nocdef': ('clip10_192x128_5.yuv.gz', 192, 128, 3, 40, ['-bitdepth', '10', '-input_bitdepth', '10', '-cdef', '0']),
+    # hierarchical-B with temporally interpolated references (RA / HDB16 operating points)
+    '128x96_n9_q32_ra': ('clip_128x96_9.yuv.gz', 128, 96, 9, 32, [], 'ra_high_efficiency.cfg'),
+    '192x128_n6_q30_ra_gop4': ('clip_192x128_6.yuv.gz', 192, 128, 6, 30, ['-num_reorder_pics', '3'], 'ra_high_efficiency.cfg'),
+    '192x128_n6_q36_ra_gop4_nointerp': ('clip_192x128_6.yuv.gz', 192, 128, 6, 36, ['-num_reorder_pics', '3', '-interp_ref', '0'], 'ra_high_efficiency.cfg'),
+    '192x128_n5_q32_hdb16_gop4_10bit': ('clip10_192x128_5.yuv.gz', 192, 128, 5, 32,
+                                        ['-num_reorder_pics', '3', '-bitdepth', '10', '-input_bitdepth', '10'], 'hdb16_high_efficiency.cfg'),
 }
 out = {}
 with tempfile.TemporaryDirectory() as d:
-    for name, (clip, w, h, n, qp, extra) in CASES.items():
+    for name, case in CASES.items():
+        clip, w, h, n, qp, extra = case[:6]
+        cfg = case[6] if len(case) > 6 else 'ldb_high_efficiency.cfg'
         raw = gzip.open(os.path.join(G, clip)).read()
         open(os.path.join(d, 'in.yuv'), 'wb').write(raw)
-        log = subprocess.run([os.path.join(ROOT, 'oracle/_ref/Thorenc'), '-cf', os.path.join(ROOT, 'configs/ldb_high_efficiency.cfg'),
+        log = subprocess.run([os.path.join(ROOT, 'oracle/_ref/Thorenc'), '-cf', os.path.join(ROOT, 'configs', cfg),
                               '-if', os.path.join(d, 'in.yuv'), '-width', str(w), '-height', str(h), '-qp', str(qp), '-n', str(n),
                               '-f', '30', '-of', os.path.join(d, 'o.bit'), '-rf', os.path.join(d, 'o.yuv')] + extra,
                              check=True, capture_output=True, text=True).stdout
         frames = [l.split()[:4] for l in log.splitlines() if len(l.split()) > 4 and l.split()[1] in 'IPB']
-        out[name] = {'clip': clip, 'w': w, 'h': h, 'n': n, 'qp': qp, 'extra': extra,
+        out[name] = {'clip': clip, 'cfg': cfg, 'w': w, 'h': h, 'n': n, 'qp': qp, 'extra': extra,
                      'bit_md5': hashlib.md5(open(os.path.join(d, 'o.bit'), 'rb').read()).hexdigest(),
                      'rec_md5': hashlib.md5(open(os.path.join(d, 'o.yuv'), 'rb').read()).hexdigest(),
                      'bit_bytes': os.path.getsize(os.path.join(d, 'o.bit')), 'frames': frames}

@@ -12,22 +12,15 @@ pytestmark = pytest.mark.gpu
 G = golden_streams()
 
 
-def encode_gpu(clip, w, h, n, qp, streams=1, skip=0, **over):
+def encode_gpu(clip, w, h, n, qp, streams=1, skip=0, cfg=None, **over):
     import thor_amd
-    p = thor_amd.load_config(CFG, width=w, height=h, qp=qp, f=30, **over)
+    p = thor_amd.load_config(os.path.join(ROOT, 'configs', cfg) if cfg else CFG, width=w, height=h, qp=qp, f=30, **over)
     fsz = w * h * 3 // 2 * (2 if int(over.get('bitdepth', 8)) > 8 else 1)
     a = np.frombuffer(clip, dtype=np.uint8)
     with thor_amd.Encoder(p, streams) as enc:
-        recs = [b''] * streams
-        for s in range(streams):
-            for f in range(n):
-                i = skip + s * n + f
-                enc.stage(s, f, a[i * fsz:(i + 1) * fsz])
-        for f in range(n):
-            enc.encode_staged([f] * streams)
-            for s in range(streams):
-                recs[s] += enc.recon(s).tobytes()
-        return [enc.bitstream(s) for s in range(streams)], recs
+        clips = [[a[(skip + s * n + f) * fsz:(skip + s * n + f + 1) * fsz] for f in range(n)] for s in range(streams)]
+        bits, recs = enc.encode_clips(clips, skips=[skip + s * n for s in range(streams)], file_frames=len(a) // fsz)
+        return bits, [b''.join(r.tobytes() for r in rs if r is not None) for rs in recs]
 
 
 @pytest.mark.parametrize('name', sorted(G))
@@ -42,7 +35,7 @@ def test_gpu_matches_reference_golden(name):
             skip = int(v)
         else:
             over[k[1:]] = v
-    bits, rec = encode_gpu(golden_clip(c['clip']), c['w'], c['h'], c['n'], c['qp'], skip=skip, **over)
+    bits, rec = encode_gpu(golden_clip(c['clip']), c['w'], c['h'], c['n'], c['qp'], skip=skip, cfg=c.get('cfg'), **over)
     assert len(bits[0]) == c['bit_bytes']
     assert md5(bits[0]) == c['bit_md5'], 'bitstream differs from the reference'
     assert md5(rec[0]) == c['rec_md5'], 'reconstruction differs from the reference'
@@ -88,3 +81,25 @@ def test_dropin_reference_front_end_on_our_library():
     c = G['192x128_n6_q32']
     bits, rec = run_encoder(REF_HIPENC, clip, 192, 128, 6, 32)
     assert md5(bits) == c['bit_md5'] and md5(rec) == c['rec_md5']
+
+
+@pytest.mark.skipif(not os.path.exists(REF_HIPENC), reason='oracle/_ref/Thorenc_hip not in the snapshot')
+@pytest.mark.parametrize('name', ['128x96_n9_q32_ra', '192x128_n5_q32_hdb16_gop4_10bit'])
+def test_dropin_front_end_hierarchical_b(name):
+    """Same seam with the reference's GOP loop driving B frames: the caller interpolates the reference frame
+    on the CPU (enc/mainenc.c:353) and hands it over in encoder_info.interp_frames[0]; 10-bit goes through
+    encode_frame_hbd."""
+    c = G[name]
+    bits, rec = run_encoder(REF_HIPENC, golden_clip(c['clip']), c['w'], c['h'], c['n'], c['qp'], c['extra'], cfg=c['cfg'])
+    assert md5(bits) == c['bit_md5'] and md5(rec) == c['rec_md5']
+
+
+@pytest.mark.skipif(not os.path.exists(REF_ENC), reason='oracle/_ref/Thorenc not in the snapshot')
+def test_live_reference_random_access_17_frames():
+    """RA operating point (sub-GOP 8, interpolated refs) over two sub-GOPs + tail, 416x240, through the CLI tool."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import gen_clip
+    clip = b''.join(p.tobytes() for fr in gen_clip.make_clip(416, 240, 19, 7, 2.0) for p in fr)
+    rb, rr = run_encoder(REF_ENC, clip, 416, 240, 19, 30, cfg='ra_high_efficiency.cfg')
+    bits, rec = run_encoder(os.path.join(ROOT, 'tools', 'thorenc_hip'), clip, 416, 240, 19, 30, cfg='ra_high_efficiency.cfg')
+    assert bits == rb and rec == rr

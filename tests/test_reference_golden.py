@@ -13,7 +13,7 @@ needs_ref = pytest.mark.skipif(not os.path.exists(REF_ENC), reason='oracle/_ref 
 @pytest.mark.parametrize('name', sorted(G))
 def test_reference_reproduces_golden_and_roundtrips(name):
     c = G[name]
-    bits, rec = run_encoder(REF_ENC, golden_clip(c['clip']), c['w'], c['h'], c['n'], c['qp'], c['extra'])
+    bits, rec = run_encoder(REF_ENC, golden_clip(c['clip']), c['w'], c['h'], c['n'], c['qp'], c['extra'], cfg=c.get('cfg'))
     assert md5(bits) == c['bit_md5'] and md5(rec) == c['rec_md5']
     # the reference's own check.sh property (check.sh:54-75).  NB: with CDEF on, the reference encoder
     # can shrink cdef_bits when it back-patches the frame header (encode_frame.c:776-782) without moving
@@ -23,9 +23,11 @@ def test_reference_reproduces_golden_and_roundtrips(name):
         assert decode(bits) == rec
 
 
-@pytest.mark.parametrize('name', ['192x128_n3_q32', '208x120_n4_q32', '192x128_n3_q32_skip3', '192x128_n4_q44', '192x128_n4_q32_10bit'])
+@pytest.mark.parametrize('name', ['192x128_n3_q32', '208x120_n4_q32', '192x128_n3_q32_skip3', '192x128_n4_q44', '192x128_n4_q32_10bit',
+                                  '128x96_n9_q32_ra', '192x128_n6_q30_ra_gop4', '192x128_n6_q36_ra_gop4_nointerp',
+                                  '192x128_n5_q32_hdb16_gop4_10bit'])
 def test_engine_host_simulation_matches_golden(name):
     c = G[name]
-    bits, rec = run_encoder(build_hostsim(), golden_clip(c['clip']), c['w'], c['h'], c['n'], c['qp'], c['extra'])
+    bits, rec = run_encoder(build_hostsim(), golden_clip(c['clip']), c['w'], c['h'], c['n'], c['qp'], c['extra'], cfg=c.get('cfg'))
     assert md5(bits) == c['bit_md5'], 'stream differs from the reference'
     assert md5(rec) == c['rec_md5'], 'reconstruction differs from the reference'

@@ -49,11 +49,11 @@ def build_hostsim():
     return out
 
 
-def run_encoder(binary, clip_bytes, w, h, n, qp, extra=(), env=None):
+def run_encoder(binary, clip_bytes, w, h, n, qp, extra=(), env=None, cfg=None):
     """Run a Thorenc-compatible CLI (reference, hostsim, thorenc_hip, Thorenc_hip); returns (bits, recon)."""
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, 'in.yuv'), 'wb').write(clip_bytes)
-        cmd = [binary, '-cf', CFG, '-if', os.path.join(d, 'in.yuv'), '-width', str(w), '-height', str(h), '-qp', str(qp),
+        cmd = [binary, '-cf', os.path.join(ROOT, 'configs', cfg) if cfg else CFG, '-if', os.path.join(d, 'in.yuv'), '-width', str(w), '-height', str(h), '-qp', str(qp),
                '-n', str(n), '-f', '30', '-of', os.path.join(d, 'o.bit'), '-rf', os.path.join(d, 'o.yuv')] + list(extra)
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, env=env)
         return open(os.path.join(d, 'o.bit'), 'rb').read(), open(os.path.join(d, 'o.yuv'), 'rb').read()

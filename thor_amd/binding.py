@@ -39,7 +39,11 @@ class ThorParams(C.Structure):
                 ('max_num_ref', C.c_int), ('HQperiod', C.c_int), ('num_reorder_pics', C.c_int), ('interp_ref', C.c_int),
                 ('dqpP', C.c_int), ('dqpI', C.c_int), ('mqpP', C.c_float), ('intra_period', C.c_int), ('intra_rdo', C.c_int),
                 ('encoder_speed', C.c_int), ('deblocking', C.c_int), ('cdef', C.c_int), ('clpf', C.c_int),
-                ('use_block_contexts', C.c_int), ('enable_bipred', C.c_int), ('cfl_intra', C.c_int), ('cfl_inter', C.c_int)]
+                ('use_block_contexts', C.c_int), ('enable_bipred', C.c_int), ('cfl_intra', C.c_int), ('cfl_inter', C.c_int),
+                ('dyadic_coding', C.c_int), ('lambda_coeffB', C.c_float), ('lambda_coeffB0', C.c_float), ('lambda_coeffB1', C.c_float),
+                ('lambda_coeffB2', C.c_float), ('lambda_coeffB3', C.c_float), ('dqpB', C.c_int), ('dqpB0', C.c_int), ('dqpB1', C.c_int),
+                ('dqpB2', C.c_int), ('dqpB3', C.c_int), ('mqpB', C.c_float), ('mqpB0', C.c_float), ('mqpB1', C.c_float),
+                ('mqpB2', C.c_float), ('mqpB3', C.c_float)]
 
 
 def lib():
@@ -53,6 +57,8 @@ def lib():
         L.thor_hip_open.restype = C.c_void_p
         L.thor_hip_open.argtypes = [C.POINTER(ThorParams), C.c_int, C.c_int]
         L.thor_hip_close.argtypes = [C.c_void_p]
+        L.thor_hip_begin_sequence.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.thor_hip_next_frame.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.thor_hip_stage_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.thor_hip_encode_staged.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.thor_hip_encode_frame.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
@@ -101,6 +107,38 @@ class Encoder:
         rc = lib().thor_hip_stage_frame(self.h, stream, slot, frame.ctypes.data_as(C.c_void_p))
         if rc:
             raise RuntimeError(f'thor_hip_stage_frame rc={rc}')
+
+    def begin_sequence(self, stream, skip, num_frames, file_frames):
+        """Fix the chunk [skip, skip+num_frames) of a file_frames-long input (thor_hip_begin_sequence)."""
+        rc = lib().thor_hip_begin_sequence(self.h, stream, skip, num_frames, file_frames)
+        if rc:
+            raise RuntimeError(f'thor_hip_begin_sequence rc={rc}')
+
+    def next_frame(self, stream):
+        """Chunk-relative display index of the next frame to code, or None when the chunk is finished."""
+        d = C.c_int()
+        return d.value if lib().thor_hip_next_frame(self.h, stream, C.byref(d)) else None
+
+    def encode_clips(self, clips, want_recon=True, skips=None, file_frames=None):
+        """Encode clips[s] (equal-length lists of frames in display order) as closed streams in lock step,
+        following the coding-order schedule.  Stream s stands for frames [skips[s], skips[s]+n) of an input
+        file holding file_frames frames (defaults: 0 and n).  Returns (bitstreams, recon[s][display index])."""
+        n = len(clips[0])
+        for s in range(self.S):
+            for f in range(n):
+                self.stage(s, f, clips[s][f])
+            sk = skips[s] if skips else 0
+            self.begin_sequence(s, sk, n, file_frames if file_frames else sk + n)
+        recs = [[None] * n for _ in range(self.S)]
+        while True:
+            idx = [self.next_frame(s) for s in range(self.S)]
+            if idx[0] is None:
+                break
+            self.encode_staged(idx)
+            if want_recon:
+                for s in range(self.S):
+                    recs[s][idx[s]] = self.recon(s)
+        return [self.bitstream(s) for s in range(self.S)], recs
 
     def encode_staged(self, slots):
         arr = (C.c_int * self.S)(*slots)

@@ -274,6 +274,7 @@ using namespace tk;
 
 template <typename PIX> struct EncT {
   Engine<PIX> eng;
+  std::vector<char> pending;  // thor_hip_next_frame already scheduled the stream's next frame
   std::vector<std::vector<DevFrame<PIX>>> staged;  // [stream][slot]
 };
 struct thor_hip_encoder {
@@ -298,6 +299,11 @@ static SeqParams to_seq(const thor_hip_params& p) {
   s.dqpP = p.dqpP; s.dqpI = p.dqpI; s.mqpP = p.mqpP; s.intra_period = p.intra_period; s.intra_rdo = p.intra_rdo;
   s.encoder_speed = p.encoder_speed; s.deblocking = p.deblocking; s.cdef = p.cdef; s.clpf = p.clpf;
   s.use_block_contexts = p.use_block_contexts; s.enable_bipred = p.enable_bipred; s.cfl_intra = p.cfl_intra; s.cfl_inter = p.cfl_inter;
+  s.dyadic_coding = p.dyadic_coding;
+  s.lambda_coeffB = p.lambda_coeffB; s.lambda_coeffB0 = p.lambda_coeffB0; s.lambda_coeffB1 = p.lambda_coeffB1;
+  s.lambda_coeffB2 = p.lambda_coeffB2; s.lambda_coeffB3 = p.lambda_coeffB3;
+  s.dqpB = p.dqpB; s.dqpB0 = p.dqpB0; s.dqpB1 = p.dqpB1; s.dqpB2 = p.dqpB2; s.dqpB3 = p.dqpB3;
+  s.mqpB = p.mqpB; s.mqpB0 = p.mqpB0; s.mqpB1 = p.mqpB1; s.mqpB2 = p.mqpB2; s.mqpB3 = p.mqpB3;
   return s;
 }
 static void from_seq(thor_hip_params* p, const SeqParams& s) {
@@ -308,6 +314,11 @@ static void from_seq(thor_hip_params* p, const SeqParams& s) {
   p->dqpP = s.dqpP; p->dqpI = s.dqpI; p->mqpP = s.mqpP; p->intra_period = s.intra_period; p->intra_rdo = s.intra_rdo;
   p->encoder_speed = s.encoder_speed; p->deblocking = s.deblocking; p->cdef = s.cdef; p->clpf = s.clpf;
   p->use_block_contexts = s.use_block_contexts; p->enable_bipred = s.enable_bipred; p->cfl_intra = s.cfl_intra; p->cfl_inter = s.cfl_inter;
+  p->dyadic_coding = s.dyadic_coding;
+  p->lambda_coeffB = s.lambda_coeffB; p->lambda_coeffB0 = s.lambda_coeffB0; p->lambda_coeffB1 = s.lambda_coeffB1;
+  p->lambda_coeffB2 = s.lambda_coeffB2; p->lambda_coeffB3 = s.lambda_coeffB3;
+  p->dqpB = s.dqpB; p->dqpB0 = s.dqpB0; p->dqpB1 = s.dqpB1; p->dqpB2 = s.dqpB2; p->dqpB3 = s.dqpB3;
+  p->mqpB = s.mqpB; p->mqpB0 = s.mqpB0; p->mqpB1 = s.mqpB1; p->mqpB2 = s.mqpB2; p->mqpB3 = s.mqpB3;
 }
 
 static int unsupported(const SeqParams& s) {
@@ -315,7 +326,10 @@ static int unsupported(const SeqParams& s) {
   // loudly rather than silently producing a different stream.
   if (s.bitdepth != s.input_bitdepth || (s.bitdepth != 8 && s.bitdepth != 10 && s.bitdepth != 12))
     return fprintf(stderr, "thor_hip: need bitdepth == input_bitdepth in {8, 10, 12}\n"), 1;
-  if (s.num_reorder_pics != 0 || s.interp_ref != 0) return fprintf(stderr, "thor_hip: B frames / interpolated refs not implemented in this round\n"), 1;
+  if (s.num_reorder_pics != 0 && !s.dyadic_coding) return fprintf(stderr, "thor_hip: non-dyadic frame reordering is not implemented\n"), 1;
+  if (s.num_reorder_pics < 0 || s.num_reorder_pics > 15 || (s.num_reorder_pics & (s.num_reorder_pics + 1)))
+    return fprintf(stderr, "thor_hip: num_reorder_pics must be 0, 1, 3, 7 or 15\n"), 1;
+  if (s.interp_ref != 0 && s.interp_ref != 1) return fprintf(stderr, "thor_hip: interp_ref must be 0 or 1\n"), 1;
   if (s.encoder_speed != 0) return fprintf(stderr, "thor_hip: encoder_speed > 0 not implemented\n"), 1;
   if (s.clpf != 0) return fprintf(stderr, "thor_hip: CLPF not implemented\n"), 1;
   if (s.width % 8 || s.height % 8 || s.width < 16 || s.height < 16) return fprintf(stderr, "thor_hip: bad geometry\n"), 1;
@@ -362,7 +376,7 @@ thor_hip_encoder* thor_hip_open(const thor_hip_params* p, int num_streams, int d
   e->S = num_streams;
   e->hbd = s.bitdepth > 8;
   if (e->hbd) e->e16 = new EncT<uint16_t>; else e->e8 = new EncT<uint8_t>;
-  ENC_DISPATCH(e, { E.eng.open(s, num_streams); E.staged.resize(num_streams); });
+  ENC_DISPATCH(e, { E.eng.open(s, num_streams); E.staged.resize(num_streams); E.pending.assign(num_streams, 0); });
   return e;
 }
 
@@ -377,6 +391,24 @@ void thor_hip_close(thor_hip_encoder* e) {
   delete e->e8;
   delete e->e16;
   delete e;
+}
+
+int thor_hip_begin_sequence(thor_hip_encoder* e, int stream, int skip, int num_frames, int file_frames) {
+  if (!e || stream < 0 || stream >= e->S || skip < 0 || num_frames < 1 || file_frames < skip + num_frames) return 1;
+  ENC_DISPATCH(e, { E.eng.begin_sequence(stream, skip, num_frames, file_frames); E.pending[stream] = 0; });
+  return 0;
+}
+
+int thor_hip_next_frame(thor_hip_encoder* e, int stream, int* display_index) {
+  if (!e || stream < 0 || stream >= e->S) return 0;
+  int ok = 0;
+  ENC_DISPATCH(e, {
+    if (E.pending[stream]) ok = 1;
+    else ok = E.eng.schedule(stream) ? 1 : 0;
+    E.pending[stream] = (char)ok;
+    if (ok && display_index) *display_index = E.eng.st[stream].cur.frame_num;
+  });
+  return ok;
 }
 
 int thor_hip_stage_frame(thor_hip_encoder* e, int stream, int slot, const void* yuv) {
@@ -405,7 +437,8 @@ int thor_hip_encode_staged(thor_hip_encoder* e, const int* slots) {
       for (int s = 0; s < e->S; s++) {
         keep[s] = E.eng.st[s].orig;
         E.eng.st[s].orig = E.staged[s][slots[s]];
-        E.eng.schedule(s);
+        if (!E.pending[s] && !E.eng.schedule(s)) { fprintf(stderr, "thor_hip: stream %d has no frame left to code\n", s); abort(); }
+        E.pending[s] = 0;
         fp[s] = E.eng.st[s].cur;
       }
       E.eng.encode_frames(fp);
@@ -421,7 +454,8 @@ int thor_hip_encode_frame(thor_hip_encoder* e, const void* const* yuv) {
     std::vector<FrameParams> fp(e->S);
     for (int s = 0; s < e->S; s++) {
       E.eng.upload_orig(s, (const PIXT*)yuv[s]);
-      E.eng.schedule(s);
+      if (!E.pending[s] && !E.eng.schedule(s)) { fprintf(stderr, "thor_hip: stream %d has no frame left to code\n", s); abort(); }
+      E.pending[s] = 0;
       fp[s] = E.eng.st[s].cur;
     }
     E.eng.encode_frames(fp);
@@ -492,24 +526,46 @@ template <typename PIX> static void encode_frame_impl(struct thor_encoder_info* 
     s.intra_period = ep.intra_period; s.intra_rdo = ep.intra_rdo; s.encoder_speed = ep.encoder_speed; s.deblocking = ep.deblocking;
     s.cdef = ep.cdef; s.clpf = ep.clpf; s.use_block_contexts = ep.use_block_contexts; s.enable_bipred = ep.enable_bipred;
     s.cfl_intra = ep.cfl_intra; s.cfl_inter = ep.cfl_inter; s.log2_sb_size = ep.log2_sb_size;
+    s.dyadic_coding = 1;  // the caller owns the GOP structure; only the window size matters here
     if (ep.subsample != 420 || ep.log2_sb_size != 7 || ep.qmtx || ep.max_delta_qp || ep.bitrate || ep.sync)
       seam_fatal("thor_hip: unsupported encoder parameters (need 4:2:0, 128x128 SB, no qmtx / delta-QP / rate control / sync)");
     if (unsupported(s)) seam_fatal("thor_hip: unsupported encoder parameters");
     ensure_init(0);
     st = new SeamState<PIX>;
     st->eng.raw_frames = true;
+    st->eng.external_interp = true;  // the caller interpolates (enc/mainenc.c:353) and hands the frame over
     st->eng.open(s, 1);
   }
   Engine<PIX>& eng = st->eng;
-  if (fi.frame_type == F_B || fi.interp_ref) seam_fatal("thor_hip: B frames / interpolated references are not implemented in this round");
+  if (fi.interp_ref > 1) seam_fatal("thor_hip: interp_ref > 1 is not implemented");
+  if (fi.num_ref > kMaxRefs) seam_fatal("thor_hip: more than 4 references");
   FrameParams f;
-  f.frame_type = fi.frame_type; f.qp = fi.qp; f.num_ref = fi.num_ref; f.frame_num = fi.frame_num; f.interp_ref = 0;
-  f.num_intra_modes = fi.num_intra_modes;
-  for (int r = 0; r < fi.num_ref && r < kMaxRefs; r++) {
-    if (fi.ref_array[r] < 0 || fi.ref_array[r] >= eng.ring_size) seam_fatal("thor_hip: reference index outside the device window");
+  f.frame_type = fi.frame_type; f.qp = fi.qp; f.num_ref = fi.num_ref; f.frame_num = fi.frame_num; f.interp_ref = fi.interp_ref;
+  f.num_intra_modes = fi.num_intra_modes; f.b_level = fi.b_level;
+  for (int r = 0; r < fi.num_ref; r++) {
+    if (fi.ref_array[r] < -1 || fi.ref_array[r] >= eng.ring_size) seam_fatal("thor_hip: reference index outside the device window");
     f.ref_array[r] = fi.ref_array[r];
+    if (fi.ref_array[r] == -1) {  // interpolated frame built by the caller
+      if (!ei->interp_frames[0] || !ep.interp_ref) seam_fatal("thor_hip: ref_array -1 without an interpolated frame");
+      const thor_yuv_frame& q = *ei->interp_frames[0];
+      DevFrame<PIX>& g = eng.st[0].interp;
+      auto push = [&](const PIX* hp, int hs, PIX* dp, int ds, int w, int h, int padw, int padh) {
+        std::vector<PIX> buf((size_t)(h + 2 * padh) * ds);
+        for (int i = -padh; i < h + padh; i++) memcpy(&buf[(size_t)(i + padh) * ds], hp + (ptrdiff_t)i * hs - padw, (w + 2 * padw) * sizeof(PIX));
+        backend::h2d(dp - (size_t)padh * ds - padw, buf.data(), (buf.size() - (size_t)(ds - (w + 2 * padw))) * sizeof(PIX));
+      };
+      if (q.pad_hor_y < kPadY || q.pad_ver_y < kPadY) seam_fatal("thor_hip: interpolated frame padding too small");
+      push((const PIX*)q.y, q.stride_y, g.p.y, g.p.sy, ei->width, ei->height, kPadY, kPadY);
+      push((const PIX*)q.u, q.stride_c, g.p.u, g.p.sc, ei->width / 2, ei->height / 2, kPadY / 2, kPadY / 2);
+      push((const PIX*)q.v, q.stride_c, g.p.v, g.p.sc, ei->width / 2, ei->height / 2, kPadY / 2, kPadY / 2);
+      g.frame_num = q.frame_num;
+    }
   }
-  f.lambda_coeff = fi.frame_type == F_I ? ep.lambda_coeffI : ep.lambda_coeffP;
+  // lambda_coeff by frame type / B level (enc/encode_frame.c:655-672)
+  if (fi.frame_type == F_I) f.lambda_coeff = ep.lambda_coeffI;
+  else if (fi.frame_type == F_P) f.lambda_coeff = ep.lambda_coeffP;
+  else f.lambda_coeff = fi.b_level == 0 ? ep.lambda_coeffB0 : fi.b_level == 1 ? ep.lambda_coeffB1 : fi.b_level == 2 ? ep.lambda_coeffB2
+                                          : fi.b_level == 3 ? ep.lambda_coeffB3 : ep.lambda_coeffB;
   fi.lambda_coeff = f.lambda_coeff;
   fi.lambda = f.lambda_coeff * kSquaredLambdaQP[f.qp];
   fi.prev_qp = fi.qp;

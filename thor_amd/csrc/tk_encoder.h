@@ -337,6 +337,7 @@ template <typename PIX> class Engine {
   int* d_nbits_all = nullptr; int* d_status_all = nullptr;   // [S][nsb]
   uint32_t* d_payload = nullptr; size_t payload_words = 0;   // compacted SB bits of all streams
   backend::GatherItem* d_items = nullptr;
+  bool external_interp = false;  // drop-in mode: the caller uploads st[s].interp itself
   bool raw_frames = false;  // drop-in mode: no sequence header / framing; caller consumes st[s].bits
   long long* d_prof = nullptr;  // 16 cycle counters summed over all superblocks (THOR_PROF builds)
 
@@ -494,7 +495,7 @@ template <typename PIX> class Engine {
       J.lambda = f.lambda_coeff * kSquaredLambdaQP[f.qp];
       J.sqrt_lambda = sqrt(J.lambda);
       J.orig = q.orig.p; J.rec = q.rec.p;
-      if (f.interp_ref) make_interp_frame(q, f);
+      if (f.interp_ref && !external_interp) make_interp_frame(q, f);
       for (int r = 0; r < f.num_ref; r++) {
         const DevFrame<PIX>& rf = f.ref_array[r] < 0 ? q.interp : q.ring[f.ref_array[r]];
         J.ref[r] = rf.p;

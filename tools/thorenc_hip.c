@@ -58,15 +58,35 @@ int main(int argc, char** argv) {
     fr[s] = fopen(name, "wb");
   }
   int* slots = (int*)malloc(S * sizeof(int));
+  /* coding-order schedule (B frames are coded out of display order); recon is written in display order */
+  fseek(fi, 0, SEEK_END);
+  long file_frames = wrap > 0 ? (long)skip + (long)S * n : (long)(ftell(fi) / (long)fsz);
+  for (int s = 0; s < S; s++)
+    if (thor_hip_begin_sequence(e, s, skip + s * n, n, (int)file_frames)) { fprintf(stderr, "bad sequence bounds\n"); return 5; }
+  unsigned char** recs = (unsigned char**)calloc((size_t)S * n, sizeof(unsigned char*));
   double t0 = now_s(), tenc = 0;
-  for (int f = 0; f < n; f++) {
-    for (int s = 0; s < S; s++) slots[s] = f;
+  int coded = 0;
+  for (;;) {
+    int active = 0;
+    for (int s = 0; s < S; s++) active += thor_hip_next_frame(e, s, &slots[s]);
+    if (!active) break;
+    if (active != S) { fprintf(stderr, "streams out of step\n"); return 5; }
     double a = now_s();
     if (thor_hip_encode_staged(e, slots)) { fprintf(stderr, "encode failed\n"); return 5; }
     tenc += now_s() - a;
+    coded++;
     for (int s = 0; s < S; s++)
-      if (fr[s]) { thor_hip_get_recon(e, s, frame); fwrite(frame, 1, fsz, fr[s]); }
+      if (fr[s]) {
+        unsigned char* r = (unsigned char*)malloc(fsz);
+        thor_hip_get_recon(e, s, r);
+        recs[(size_t)s * n + slots[s]] = r;
+      }
   }
+  for (int s = 0; s < S; s++)
+    if (fr[s])
+      for (int f = 0; f < n; f++)
+        if (recs[(size_t)s * n + f]) fwrite(recs[(size_t)s * n + f], 1, fsz, fr[s]);
+  n = coded;
   double sb_ms = 0, filt_ms = 0; long launches = 0;
   thor_hip_kernel_time(e, &sb_ms, &launches, &filt_ms);
   double mpx = (double)p.width * p.height * n * S / 1e6;
