@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <map>
 #include <vector>
 
 #include "tk_block.h"
@@ -33,43 +34,114 @@ __device__ Tables g_tab;
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-template <typename PIX> __global__ __launch_bounds__(64, 3) void k_superblocks(const FrameJob<PIX>* jobs, int tdiag) {
-  __shared__ FrameJob<PIX> sJ;
-  {
-    const uint32_t* src = (const uint32_t*)&jobs[blockIdx.y];
-    uint32_t* dst = (uint32_t*)&sJ;
-    for (int i = threadIdx.x; i < (int)(sizeof(FrameJob<PIX>) / 4); i += 64) dst[i] = src[i];
+// Dependency-driven persistent superblock kernel.  A task is (stream, superblock).  SB(k,l) needs its left
+// neighbour (k,l-1) and its up-right neighbour (k-1,l+1) ((k-1,l) in the last column) - SURVEY.md Appendix A.
+// Ready tasks live in a single-use FIFO in global memory (one slot per task of the frame, so no wrap-around):
+// a finishing task bumps the dependency counters of its successors and pushes those that became ready;
+// idle workgroups take a pop ticket and wait for that slot to be filled.  Every task is pushed exactly once
+// and running tasks never wait, so every pop ticket below the task count is eventually served: no deadlock
+// whatever the dispatch order or residency, and no workgroup ever holds a task that is not ready.
+// Publication uses agent-scope release/acquire, which also orders the data across the 8 XCD L2s.
+struct DfCtl {
+  unsigned head, tail, error, pad;
+};
+struct DfArgs {
+  DfCtl* ctl;
+  unsigned* queue;             // [S*nsb] task ids (stream*nsb + sb), 0xffffffff = not filled yet
+  unsigned* cnt;               // [S*nsb] finished-dependency counters
+  uint8_t* pool;               // one BigWs scratch slot per workgroup
+  size_t slot_bytes;
+  unsigned long long* times;   // optional [S*nsb][3] pop/start/end wall clock (100 MHz)
+  int S, nsb, cols, rows;
+  unsigned long long spin_limit;  // wall-clock ticks a workgroup may wait for a queue slot
+};
+static const unsigned kDfEmpty = 0xffffffffu;
+
+// Poll with RELAXED agent-scope loads: an acquire load in the loop would issue a buffer_inv (a whole-L2
+// invalidate on this XCD) per poll and starve every working wavefront.  The single acquire fence executed
+// after the wait orders the dependent reads.
+__device__ inline unsigned df_pop(const DfArgs& A, unsigned slot) {
+  const unsigned long long t0 = wall_clock64();
+  unsigned n = 0, v;
+  while ((v = __hip_atomic_load(&A.queue[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kDfEmpty) {
+    for (int i = 0; i < 4; i++) __builtin_amdgcn_s_sleep(127);  // ~14 us between polls
+    if ((++n & 63u) == 0) {
+      if (__hip_atomic_load(&A.ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return kDfEmpty;
+      if (wall_clock64() - t0 > A.spin_limit) { atomicExch(&A.ctl->error, 1u); return kDfEmpty; }
+    }
   }
-  __syncthreads();
-  const FrameJob<PIX>& J = sJ;
-  int kmin = tdiag - (J.sb_cols - 1);
-  kmin = kmin <= 0 ? 0 : (kmin + 1) / 2;
-  const int k = kmin + (int)blockIdx.x, l = tdiag - 2 * k;
-  if (k >= J.sb_rows || l < 0 || l >= J.sb_cols) return;
-  const int sbi = k * J.sb_cols + l;
+  return v;
+}
+__device__ inline void df_done_dep(const DfArgs& A, unsigned base, int k, int l) {  // a dependency of (k,l) finished
+  const unsigned id = base + (unsigned)(k * A.cols + l);
+  const unsigned need = (l > 0 ? 1u : 0u) + (k > 0 ? 1u : 0u);
+  const unsigned old = __hip_atomic_fetch_add(&A.cnt[id], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (old + 1 == need) {
+    const unsigned p = __hip_atomic_fetch_add(&A.ctl->tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&A.queue[p], id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <typename PIX> __global__ __launch_bounds__(64, 3) void k_superblocks(const FrameJob<PIX>* jobs, DfArgs A) {
+  __shared__ FrameJob<PIX> sJ;
   __shared__ SmallWs<PIX> sws;
-  TeamWs<PIX> wsv = make_ws(&sws, (BigWs<PIX>*)(J.scratch + (size_t)blockIdx.x * J.scratch_bytes));
+  __shared__ unsigned s_task;
+  const FrameJob<PIX>& J = sJ;
+  const unsigned total = (unsigned)A.S * (unsigned)A.nsb;
+  TeamWs<PIX> wsv = make_ws(&sws, (BigWs<PIX>*)(A.pool + (size_t)blockIdx.x * A.slot_bytes));
   TeamWs<PIX>* ws = &wsv;
   Team t{(int)threadIdx.x, 64};
+  for (;;) {
+    __syncthreads();
+    unsigned long long tpop = 0;
+    if (threadIdx.x == 0) {
+      const unsigned slot = atomicAdd(&A.ctl->head, 1u);
+      if (A.times) tpop = wall_clock64();
+      s_task = slot < total ? df_pop(A, slot) : kDfEmpty;
+    }
+    __syncthreads();
+    const unsigned task = (unsigned)__builtin_amdgcn_readfirstlane((int)s_task);
+    if (task == kDfEmpty) break;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int sidx = (int)(task / (unsigned)A.nsb), sb = (int)(task % (unsigned)A.nsb);
+    const int k = sb / A.cols, l = sb % A.cols;
+    {
+      const uint32_t* src = (const uint32_t*)&jobs[sidx];
+      uint32_t* dst = (uint32_t*)&sJ;
+      for (int i = threadIdx.x; i < (int)(sizeof(FrameJob<PIX>) / 4); i += 64) dst[i] = src[i];
+    }
 #ifdef THOR_PROF
-  if (threadIdx.x < kProfSlots) sws.prof[threadIdx.x] = 0;
+    if (threadIdx.x < kProfSlots) sws.prof[threadIdx.x] = 0;
 #endif
-  __syncthreads();
-  BitSink out;
-  out.buf = J.sb_bits + (size_t)sbi * J.sb_words;
-  out.pos = 0;
-  out.cap = J.sb_words * 32;
-  out.emit = 1;
-  out.ovf = 0;
-  process_sb(t, J, ws, k * kMaxSb, l * kMaxSb, out);
-  if (threadIdx.x == 0) {
-    J.sb_nbits[sbi] = out.pos;
-    J.sb_status[sbi] = out.ovf;
+    __syncthreads();
+    if (A.times && threadIdx.x == 0) { A.times[3 * (size_t)task] = tpop; A.times[3 * (size_t)task + 1] = wall_clock64(); }
+    BitSink out;
+    out.buf = J.sb_bits + (size_t)sb * J.sb_words;
+    out.pos = 0;
+    out.cap = J.sb_words * 32;
+    out.emit = 1;
+    out.ovf = 0;
+    process_sb(t, J, ws, k * kMaxSb, l * kMaxSb, out);
+    if (threadIdx.x == 0) {
+      J.sb_nbits[sb] = out.pos;
+      J.sb_status[sb] = out.ovf;
+    }
+#ifdef THOR_PROF
+    __syncthreads();
+    if (J.prof && threadIdx.x < kProfSlots) atomicAdd((unsigned long long*)&J.prof[threadIdx.x], (unsigned long long)sws.prof[threadIdx.x]);
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (A.times) A.times[3 * (size_t)task + 2] = wall_clock64();
+      const unsigned base = (unsigned)sidx * (unsigned)A.nsb;
+      if (l + 1 < A.cols) df_done_dep(A, base, k, l + 1);               // right neighbour: its left dependency
+      if (k + 1 < A.rows) {
+        if (l >= 1) df_done_dep(A, base, k + 1, l - 1);                 // down-left: its up-right dependency
+        if (l == A.cols - 1) df_done_dep(A, base, k + 1, l);            // last column: the SB below uses (k,l) as "up-right"
+      }
+    }
   }
-#ifdef THOR_PROF
-  __syncthreads();
-  if (J.prof && threadIdx.x < kProfSlots) atomicAdd((unsigned long long*)&J.prof[threadIdx.x], (unsigned long long)sws.prof[threadIdx.x]);
-#endif
 }
 
 template <typename PIX> __global__ void k_deblock(const FrameJob<PIX>* jobs, int pass) {
@@ -199,19 +271,78 @@ static std::pair<hipEvent_t, hipEvent_t> ev_begin() {
   return p;
 }
 
+struct DfState {  // per engine (keyed by its device job array)
+  DfCtl* ctl = nullptr;
+  unsigned* queue = nullptr;
+  unsigned* cnt = nullptr;
+  uint8_t* pool = nullptr;
+  unsigned long long* times = nullptr;
+  int S = 0, nsb = 0, wgs = 0;
+  int frame = 0;
+};
+static std::map<const void*, DfState> g_df;
+
 template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S) {
-  const int cols = hjobs[0].sb_cols, rows = hjobs[0].sb_rows;
-  auto ev = ev_begin();
-  for (int t = 0; t <= (cols - 1) + 2 * (rows - 1); t++) {
-    int n = 0;
-    for (int k = 0; k < rows; k++) { int l = t - 2 * k; if (l >= 0 && l < cols) n++; }
-    if (!n) continue;
-    hipLaunchKernelGGL(k_superblocks<PIX>, dim3(n, S), dim3(64), 0, g_stream, jobs, t);
-    g_clk.sb_launches++;
+  const int cols = hjobs[0].sb_cols, rows = hjobs[0].sb_rows, nsb = cols * rows;
+  const size_t total = (size_t)S * nsb;
+  DfState& D = g_df[jobs];
+  const size_t slot = (sizeof(BigWs<PIX>) + 255) & ~(size_t)255;
+  if (D.S != S || D.nsb != nsb) {
+    if (D.ctl) { HIPCHECK(hipFree(D.ctl)); HIPCHECK(hipFree(D.queue)); HIPCHECK(hipFree(D.cnt)); HIPCHECK(hipFree(D.pool)); if (D.times) HIPCHECK(hipFree(D.times)); }
+    D = DfState();
+    D.S = S; D.nsb = nsb;
+    int per_cu = 0;
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_superblocks<PIX>, 64, 0));
+    hipDeviceProp_t prop;
+    int dev = 0;
+    HIPCHECK(hipGetDevice(&dev));
+    HIPCHECK(hipGetDeviceProperties(&prop, dev));
+    long cap = (long)(per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
+    if (const char* e = getenv("THOR_HIP_WGS")) cap = atol(e);
+    D.wgs = (int)(cap < (long)total ? cap : (long)total);
+    HIPCHECK(hipMalloc(&D.ctl, sizeof(DfCtl)));
+    HIPCHECK(hipMalloc(&D.queue, sizeof(unsigned) * total));
+    HIPCHECK(hipMalloc(&D.cnt, sizeof(unsigned) * total));
+    HIPCHECK(hipMalloc(&D.pool, slot * (size_t)D.wgs));
+    if (getenv("THOR_SBTIMES")) { HIPCHECK(hipMalloc(&D.times, sizeof(unsigned long long) * 3 * total)); }
   }
+  // frame start: only SB(0,0) of every stream is ready
+  {
+    std::vector<unsigned> q0(S);
+    for (int s2 = 0; s2 < S; s2++) q0[s2] = (unsigned)s2 * (unsigned)nsb;
+    DfCtl hc0 = {0u, (unsigned)S, 0u, 0u};
+    HIPCHECK(hipMemsetAsync(D.queue, 0xff, sizeof(unsigned) * total, g_stream));
+    HIPCHECK(hipMemsetAsync(D.cnt, 0, sizeof(unsigned) * total, g_stream));
+    HIPCHECK(hipMemcpyAsync(D.queue, q0.data(), sizeof(unsigned) * S, hipMemcpyHostToDevice, g_stream));
+    HIPCHECK(hipMemcpyAsync(D.ctl, &hc0, sizeof(hc0), hipMemcpyHostToDevice, g_stream));
+    HIPCHECK(hipStreamSynchronize(g_stream));
+  }
+  DfArgs A;
+  A.ctl = D.ctl; A.queue = D.queue; A.cnt = D.cnt; A.pool = D.pool; A.slot_bytes = slot; A.times = D.times;
+  A.S = S; A.nsb = nsb; A.cols = cols; A.rows = rows;
+  double lim_s = 300.0;
+  if (const char* e = getenv("THOR_HIP_SPIN_TIMEOUT_S")) lim_s = atof(e);
+  A.spin_limit = (unsigned long long)(lim_s * 1e8);
+  auto ev = ev_begin();
+  hipLaunchKernelGGL(k_superblocks<PIX>, dim3(D.wgs), dim3(64), 0, g_stream, jobs, A);
+  g_clk.sb_launches++;
   HIPCHECK(hipEventRecord(ev.second, g_stream));
   g_sb_events.push_back(ev);
   HIPCHECK(hipGetLastError());
+  DfCtl hc;
+  HIPCHECK(hipMemcpyAsync(&hc, D.ctl, sizeof(hc), hipMemcpyDeviceToHost, g_stream));
+  HIPCHECK(hipStreamSynchronize(g_stream));
+  if (hc.error || hc.tail != (unsigned)total) {
+    fprintf(stderr, "Run-time error...\nthor_hip: superblock scheduler failed (error %u, %u of %zu tasks released)\n...now exiting to system...\n", hc.error, hc.tail, total);
+    abort();
+  }
+  if (D.times) {
+    std::vector<unsigned long long> h(3 * total);
+    HIPCHECK(hipMemcpy(h.data(), D.times, h.size() * 8, hipMemcpyDeviceToHost));
+    FILE* f = fopen(getenv("THOR_SBTIMES"), D.frame == 0 ? "wb" : "ab");
+    if (f) { int hdr[4] = {D.frame, S, nsb, cols}; fwrite(hdr, 4, 4, f); fwrite(h.data(), 8, h.size(), f); fclose(f); }
+  }
+  D.frame++;
 }
 template <typename PIX> void run_deblock(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S) {
   const int items = (hjobs[0].cfg.width / 8) * (hjobs[0].cfg.height / 8);
