@@ -19,6 +19,8 @@ namespace tk {
 struct Node {
   int size, ypos, xpos, bw, bh;
   int stage, child;
+  int md_done;          // top-down flow (encoder_speed > 0): mode decision already made, cost in cost_this
+  unsigned cost_this;
   unsigned cost_small;
   int bitpos0;
   int encode_this_size, encode_rect;
@@ -499,7 +501,7 @@ TK_DEV unsigned search_inter(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>*
   MeArgs a;
   a.cb_size = size; a.rstride = ref.sy; a.sign = sign; a.fwidth = J.cfg.width; a.fheight = J.cfg.height;
   a.xpos = xpos; a.ypos = ypos; a.enable_bipred = J.cfg.enable_bipred; a.bitdepth = J.cfg.bitdepth;
-  a.lam = J.sqrt_lambda; a.ostride = ostride;
+  a.lam = J.sqrt_lambda; a.ostride = ostride; a.speed = J.cfg.encoder_speed;
   unsigned sad = 0;
   mv_t mv, mvp2 = mvp;
   if (part == P_NONE) {
@@ -590,6 +592,40 @@ TK_DEVNI void search_bipred(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* 
   for (int i = 0; i < 4; i++) { mv_arr0[i] = min0[i]; mv_arr1[i] = min1[i]; }
 }
 
+// search_intra_prediction_params (encode_block.c:928-1031): intra mode by luma SAD against the frame-edge
+// prediction; evaluation order DC, HOR, VER, PLANAR (stop here when num_intra_modes == 4), then the six
+// angular modes; first minimum wins.  DC is always built from (left, top) here (sic: `xposY >= 0` :953).
+template <typename PIX>
+TK_DEVNI unsigned intra_sad_search(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int num_modes, int* mode_out) {
+  const EncCfg& c = J.cfg;
+  const int size = nd.size, bd = c.bitdepth;
+  const int ur = upright_avail(nd.ypos, nd.xpos, size, size, c.width, kMaxSb);
+  const int dl = downleft_avail(nd.ypos, nd.xpos, size, size, c.height, kMaxSb);
+  const PIX* fy = J.rec.y + nd.ypos * J.rec.sy + nd.xpos;
+  const PIX* oy = J.orig.y + nd.ypos * J.orig.sy + nd.xpos;
+  make_edges(t, ws->edgep, fy, J.rec.sy, (const PIX*)nullptr, 0, 0, 0, nd.ypos, nd.xpos, size, ur, dl, 0, bd);
+  t.sync();
+  unsigned min_sad = 1u << 30;
+  int best = 0;
+  const int n = num_modes == 4 ? 4 : 10;
+  for (int e = 0; e < n; e++) {
+    const int m = e == 0 ? 0 : e == 1 ? 2 : e == 2 ? 3 : e == 3 ? 1 : e;  // evaluation order -> intra_mode_t
+    pred_intra(t, ws->edgep, 1, 1, size, ws->pred_y, size, m, bd);
+    t.sync();
+    int local = 0;
+    for (int k = t.rank; k < size * size; k += t.size) {
+      int i, j;
+      split2(mk_div(size), k, i, j);
+      local += iabs((int)oy[i * J.orig.sy + j] - (int)ws->pred_y[k]);
+    }
+    const unsigned sad = (unsigned)team_sum(t, local) >> (bd - 8);
+    t.sync();
+    if (sad < min_sad) { min_sad = sad; best = m; }
+  }
+  *mode_out = best;
+  return min_sad;
+}
+
 // ---------------------------------------------------------------------------------
 // mode_decision_rdo (encode_block.c:1835-2121).  Result in nd.best; returns min cost.
 // ---------------------------------------------------------------------------------
@@ -602,6 +638,7 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
   const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
   const int max_pb = c.enable_pb_split ? 4 : 1;
   unsigned min_cost = kCostInit;
+  int do_inter = 1, do_intra = 1;
   BlkParam p;
   // deterministic stand-in for the reference's uninitialised tmp_block_param
   p.mode = M_SKIP; p.intra_mode = 0; p.skip_idx = 0; p.pb_part = P_NONE; p.ref0 = p.ref1 = 0; p.dir = 0;
@@ -627,23 +664,44 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
           if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
         }
       }
+      // encoder_speed > 0: intra-vs-inter pre-decision by SAD (encode_block.c:1943-1947, 1990-1993)
+      const int intra_inter_sad = c.encoder_speed > 0;
+      unsigned sad_intra = 0xffffffffu;
+      if (intra_inter_sad) {
+        int im;
+        sad_intra = intra_sad_search(t, J, ws, nd, J.num_intra_modes, &im);
+        sad_intra += (unsigned)(int)mul_add_nofma(J.sqrt_lambda, 2.0, 0.5);
+      }
       // uni-prediction per reference
       mv_t mv_center[kMaxRefs];
       mv_t mv_all[4][4];
       mv_t mvp = mk_mv(0, 0);
       const PIX* oy = J.orig.y + nd.ypos * J.orig.sy + nd.xpos;
-      const int min_idx = (J.frame_type == F_B && J.interp_ref > 2) ? 1 : 0;
-      for (int r = min_idx; r < J.num_ref; r++) {
+      int min_idx = 0, max_idx = J.num_ref - 1;
+      {
+        const int br = ws->mep->best_ref;
+        if (!(br < 0 || c.encoder_speed < 2 || c.enable_bipred)) min_idx = max_idx = br;
+      }
+      if (J.frame_type == F_B && J.interp_ref > 2) min_idx = 1;
+      unsigned worst_cost = 0, best_cost = 0xffffffffu;
+      for (int r = min_idx; r <= max_idx; r++) {
         mvp = get_mv_pred(J.cells, J.cell_stride, nd.ypos, nd.xpos, c.width, c.height, size, kMaxSb);
         if (t.rank == 0) add_mvcand(ws->mep, r, mvp);
         t.sync();
         nd.syn.mvp = mvp;
         mv_center[r] = mvp;
+        unsigned sad_inter = 0xffffffffu;
         for (int part = 0; part < max_pb; part++) {
-          search_inter(t, J, ws, nd.ypos, nd.xpos, size, oy, J.orig.sy, r, mv_center[r], mvp, mv_all[part], part, J.sign[r]);
+          unsigned sad = search_inter(t, J, ws, nd.ypos, nd.xpos, size, oy, J.orig.sy, r, mv_center[r], mvp, mv_all[part], part, J.sign[r]);
           add_cands4(t, ws, r, mv_all[part]);
           mv_center[r] = mv_all[0][0];
+          sad_inter = sad < sad_inter ? sad : sad_inter;
         }
+        if (intra_inter_sad) {
+          do_inter = sad_inter < sad_intra;
+          if (sad_inter < sad_intra) do_intra = 0;
+        }
+        if (!do_inter) continue;
         p.mode = M_INTER;
         p.ref0 = p.ref1 = (int8_t)r;
         for (int part = 0; part < max_pb; part++) {
@@ -653,12 +711,21 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
           for (int tb = min_tb; tb <= max_tb - 1; tb++) {
             p.tb_param = (int8_t)tb;
             unsigned cost = rdo_trial(t, J, ws, nd, p, lambda, tb > min_tb);
+            worst_cost = cost > worst_cost ? cost : worst_cost;
+            best_cost = cost < best_cost ? cost : best_cost;
             if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
           }
         }
       }
+      // "one reference convincingly better": remember reference 0 for the rest of the SB (sic: best_ref_idx
+      // is never updated in the reference, encode_block.c:1868/2018-2019); uint32 wrap-around as in C.
+      if (worst_cost && worst_cost * 3u > best_cost * 4u) {
+        t.sync();
+        if (t.rank == 0) ws->mep->best_ref = 0;
+        t.sync();
+      }
       // bi-prediction
-      if (J.num_ref > 1 && c.enable_bipred) {
+      if (J.num_ref > 1 && c.enable_bipred && do_inter) {
         int r0, r1;
         mv_t a0[4], a1[4];
         search_bipred(t, J, ws, nd, 0, mv_center, mvp, &r0, &r1, a0, a1);
@@ -679,7 +746,7 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
           MeArgs a;
           a.cb_size = size; a.ostride = J.orig.sy; a.width = size; a.height = size; a.rstride = f0.sy; a.sign = 0;
           a.fwidth = c.width; a.fheight = c.height; a.xpos = nd.xpos; a.ypos = nd.ypos; a.enable_bipred = 1;
-          a.bitdepth = c.bitdepth; a.lam = J.sqrt_lambda;
+          a.bitdepth = c.bitdepth; a.lam = J.sqrt_lambda; a.speed = c.encoder_speed;
           mv_t mvb;
           motion_estimate_bi(t, ws->mep, oy, f0.y + nd.ypos * f0.sy + nd.xpos, f1.y + nd.ypos * f1.sy + nd.xpos, a, mv_center[ri0],
                              mvp, ri0, &mvb);
@@ -699,7 +766,8 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
     p.mode = M_INTRA;
     int intra_mode = 0;
     unsigned best_tb_cost[2] = {kCostInit, kCostInit};
-    if (c.intra_rdo) {
+    if (!do_intra) {
+    } else if (c.intra_rdo) {
       unsigned min_intra = kCostInit;
       for (int m = 0; m < J.num_intra_modes; m++) {
         p.intra_mode = (int8_t)m;
@@ -720,6 +788,7 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
         if (cost < min_cost) { min_cost = cost; p.cbp_y = p.cbp_u = p.cbp_v = 0; if (t.rank == 0) keep_best(nd, p); }
       }
     } else {
+      intra_sad_search(t, J, ws, nd, J.num_intra_modes, &intra_mode);
       p.intra_mode = (int8_t)intra_mode;
       for (int tb = 0; tb <= max_tb - 1; tb++) {
         p.tb_param = (int8_t)tb;
@@ -807,7 +876,8 @@ TK_DEVNI int check_early_skip(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>
   const EncCfg& c = J.cfg;
   const int size = nd.size, size0 = size < 32 ? size : 32;
   const int qpY = J.qp, qpC = TK_TAB.chroma_qp[qpY];
-  const float thr = c.early_skip_thr;
+  float thr = c.early_skip_thr;
+  if (c.encoder_speed > 1 && nd.size == kMaxSb) thr += thr / 4;  // encode_block.c:2256-2257
   const int size0c = size0 >> 1;
   int significant = 0;
   for (int i = 0; i < size && !significant; i += size0)
@@ -896,7 +966,7 @@ TK_DEV void process_sb(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, i
   const EncCfg& c = J.cfg;
   const int fw = c.width, fh = c.height;
   if (t.rank == 0)
-    for (int r = 0; r < kMaxRefs; r++) { ws->mep->mvcand_num[r] = 0; ws->mep->mvcand_mask[r] = 0; }
+  { for (int r = 0; r < kMaxRefs; r++) { ws->mep->mvcand_num[r] = 0; ws->mep->mvcand_mask[r] = 0; } ws->mep->best_ref = -1; }
   xform_tables_init(t, ws->xfp);
   int sp = 0;
   unsigned ret = 0;  // value "returned" by the node that was just popped
@@ -921,6 +991,8 @@ TK_DEV void process_sb(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, i
         nd.cost_small = 1u << 28;
         nd.bitpos0 = out.pos;
         nd.child = 0;
+        nd.md_done = 0;
+        nd.cost_this = 1u << 28;
         SynCtx& s = nd.syn;
         s.frame_type = J.frame_type; s.num_ref = J.num_ref; s.enable_bipred = c.enable_bipred; s.interp_ref = J.interp_ref;
         s.max_pb_part = c.enable_pb_split ? 4 : 1; s.max_tb_part = c.enable_tb_split == 1 ? 2 : 1;
@@ -962,8 +1034,9 @@ TK_DEV void process_sb(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, i
           continue;
         }
       }
-      // ---- split signalling + children
-      if (size > kMinBlk) {
+      // ---- split signalling + children (bottom-up), unless this is a top-down 16x16 (encode_block.c:2418)
+      const int top_down = size == 2 * kMinBlk && nd.encode_this_size && J.frame_type != F_I && c.encoder_speed > 0;
+      if (size > kMinBlk && !top_down) {
         if (t.rank == 0) {
           BitSink w = out;
           bs_super_mode(w, nd.syn, 0, 0, 1);
@@ -1015,11 +1088,37 @@ TK_DEV void process_sb(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, i
     {
       unsigned cost = 1u << 28;
       if (nd.encode_this_size || nd.encode_rect) {
-        cost = mode_decision(t, J, ws, nd);
-        t.sync();
+        if (!nd.md_done) {
+          cost = mode_decision(t, J, ws, nd);
+          t.sync();
 #if TK_HOST
-        if (getenv("THOR_DBG")) fprintf(stderr, "F %d y %d x %d s %d RDO mode %d cost %u small %u ref %d part %d tb %d mv %d %d\n", J.frame_num, nd.ypos, nd.xpos, nd.size, nd.best.mode, cost, nd.cost_small, nd.best.ref0, nd.best.pb_part, nd.best.tb_param, nd.best.mv0[0].x, nd.best.mv0[0].y);
+          if (getenv("THOR_DBG")) fprintf(stderr, "F %d y %d x %d s %d RDO mode %d cost %u small %u ref %d part %d tb %d mv %d %d\n", J.frame_num, nd.ypos, nd.xpos, nd.size, nd.best.mode, cost, nd.cost_small, nd.best.ref0, nd.best.pb_part, nd.best.tb_param, nd.best.mv0[0].x, nd.best.mv0[0].y);
 #endif
+          // top-down 16x16 (encoder_speed > 0, encode_block.c:2418-2419, 2528-2537): the children are only
+          // tried when this size costs more than size^2 * iq_8x8[qp] / 8
+          const int top_down = nd.size == 2 * kMinBlk && nd.encode_this_size && J.frame_type != F_I && c.encoder_speed > 0;
+          if (top_down && cost > (unsigned)(nd.size * nd.size * TK_TAB.iq_8x8[J.qp] / 8)) {
+            out.pos = nd.bitpos0;
+            if (t.rank == 0) {
+              BitSink w = out;
+              bs_super_mode(w, nd.syn, 0, 0, 1);
+              out.ovf |= w.ovf;
+              nd.cost_small = 0;
+              nd.md_done = 1;
+              nd.cost_this = cost;
+              nd.stage = 1;
+            }
+            {
+              BitSink cnt = out;
+              cnt.emit = 0;
+              bs_super_mode(cnt, nd.syn, 0, 0, 1);
+              out.pos = cnt.pos;
+            }
+            t.sync();
+            have_ret = 0;
+            continue;
+          }
+        } else cost = nd.cost_this;
         if (cost <= nd.cost_small) {
           out.pos = nd.bitpos0;
           final_encode(t, J, ws, nd, out);

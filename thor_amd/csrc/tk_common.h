@@ -223,6 +223,7 @@ struct Tables {
   uint8_t chroma_qp[52];
   uint8_t beta[52];
   uint8_t tc[56];
+  uint16_t iq_8x8[52];                       // top-down split threshold scale (encode_block.c:2394-2398)
 };
 
 #if TK_HOST

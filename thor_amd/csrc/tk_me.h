@@ -21,6 +21,7 @@ struct MeWs {
   mv_t mvcand[kMaxRefs][64];
   int mvcand_num[kMaxRefs];
   unsigned long long mvcand_mask[kMaxRefs];
+  int best_ref;  // frame_info.best_ref (enc/mainenc.h:143): per-SB state of the encoder_speed 2 reference shortcut
   long long* prof;
 };
 
@@ -229,8 +230,102 @@ struct MeArgs {
   int rstride;
   int sign, fwidth, fheight, xpos, ypos;  // CB position (Appendix B.16)
   int enable_bipred, bitdepth;
+  int speed;             // encoder_speed (0 slow .. 2 fast)
   double lam;            // sqrt(lambda)
 };
+
+
+// Bilinear sub-pel approximations of encoder_speed > 0 (sad_calc_fasthalf enc/encode_block.c:174-283 ==
+// sad_calc_fasthalf_simd enc_kernels.c:330, sad_calc_fastquarter :286-415): the SADs of the 8 half-
+// (quarter-) pel neighbours of the centre built from rounding (avg) and truncating (rdavg) byte averages;
+// returns the smallest of them and its offset.  Lanes split the samples, 8 shuffle reductions.
+template <typename PIX> TK_DEV unsigned fast_halfpel(const Team& t, const PIX* a, const PIX* b, int as, int bs, int width, int height, int* bx, int* by) {
+  int tl = 0, tr = 0, br = 0, bl = 0, top = 0, right = 0, down = 0, left = 0;
+  const Div2 dw = mk_div(width);
+  for (int r = t.rank; r < width * height; r += t.size) {
+    int i, j;
+    split2(dw, r, i, j);
+    const PIX* c = b + i * bs + j;
+    auto B = [&](int dy, int dx) -> int { return (int)c[dy * bs + dx]; };
+    auto av = [](int x, int y) { return (x + y + 1) >> 1; };
+    auto rd = [](int x, int y) { return (x + y) >> 1; };
+    const int o = (int)a[i * as + j];
+    const int h_l = av(B(0, -1), B(0, 0)), h_r = av(B(0, 0), B(0, 1));
+    const int v4 = av(B(-2, 0), B(1, 0));          // column j,   rows -2 / +1
+    const int v4b = av(B(-1, 0), B(2, 0));         // column j,   rows -1 / +2
+    const int t6 = av(B(0, -2), B(0, 1));          // row 0, cols -2 / +1
+    const int t7 = av(B(0, -1), B(0, 2));          // row 0, cols -1 / +2
+    const int ptl = rd(rd(rd(av(B(-2, -1), B(1, -1)), v4), rd(av(B(-1, -2), B(-1, 1)), t6)), rd(av(B(-1, -1), B(-1, 0)), h_l));
+    const int ptr = rd(rd(rd(v4, av(B(-2, 1), B(1, 1))), rd(t7, av(B(-1, -1), B(-1, 2)))), rd(av(B(-1, 0), B(-1, 1)), h_r));
+    const int pbl = rd(rd(rd(v4b, av(B(-1, -1), B(2, -1))), rd(t6, av(B(1, -2), B(1, 1)))), rd(av(B(1, -1), B(1, 0)), h_l));
+    const int pbr = rd(rd(rd(v4b, av(B(-1, 1), B(2, 1))), rd(t7, av(B(1, -1), B(1, 2)))), rd(h_r, av(B(1, 0), B(1, 1))));
+    left += iabs(o - h_l); right += iabs(o - h_r);
+    down += iabs(o - av(B(0, 0), B(1, 0))); top += iabs(o - av(B(0, 0), B(-1, 0)));
+    tl += iabs(o - ptl); tr += iabs(o - ptr); br += iabs(o - pbr); bl += iabs(o - pbl);
+  }
+  unsigned utop = (unsigned)team_sum(t, top), uright = (unsigned)team_sum(t, right), udown = (unsigned)team_sum(t, down), uleft = (unsigned)team_sum(t, left);
+  unsigned utl = (unsigned)team_sum(t, tl), utr = (unsigned)team_sum(t, tr), ubr = (unsigned)team_sum(t, br), ubl = (unsigned)team_sum(t, bl);
+  int x = 0, y = -2;
+  if (udown < utop) { y = 2; utop = udown; }
+  if (uright < utop) { x = 2; y = 0; utop = uright; }
+  if (uleft < utop) { x = -2; y = 0; utop = uleft; }
+  if (utl < utop) { x = -2; y = -2; utop = utl; }
+  if (utr < utop) { x = 2; y = -2; utop = utr; }
+  if (ubr < utop) { x = 2; y = 2; utop = ubr; }
+  if (ubl < utop) { x = -2; y = 2; utop = ubl; }
+  *bx = x; *by = y;
+  return utop;
+}
+
+template <typename PIX> TK_DEV unsigned fast_quarterpel(const Team& t, const PIX* o_, const PIX* r_, int os, int rs, int width, int height, int* bx, int* by) {
+  int tl = 0, tr = 0, br = 0, bl = 0, top = 0, right = 0, down = 0, left = 0;
+  const int hx = *bx, hy = *by;  // half-pel offset chosen before (0 or +-2): selects the interpolation pattern
+  const Div2 dw = mk_div(width);
+  for (int q = t.rank; q < width * height; q += t.size) {
+    int i, j;
+    split2(dw, q, i, j);
+    const PIX* c = r_ + i * rs + j;
+    auto av = [](int x, int y) { return (x + y + 1) >> 1; };
+    const int o = (int)o_[i * os + j];
+    const int a = c[0], d = c[1], f = c[rs];
+    int p_tl, p_top, p_tr, p_left, p_right, p_bl, p_down, p_br;
+    if (hx & hy) {
+      const int e = c[rs + 1];
+      const int ad = av(a, d), de = av(d, e), af = av(a, f), fe = av(f, e);
+      p_tl = (ad + af) >> 1; p_top = (de + a) >> 1; p_tr = (ad + de) >> 1; p_left = (ad + f) >> 1; p_right = (ad + e) >> 1;
+      p_bl = (af + fe) >> 1; p_down = (de + f) >> 1; p_br = (de + fe) >> 1;
+    } else if (hx) {
+      const int b = c[-rs], cc = c[-rs + 1], e = c[rs + 1];
+      const int ad = av(a, d), de = av(d, e), dc = av(d, cc), af = av(a, f), ab = av(a, b);
+      p_tl = (ad + ab) >> 1; p_top = (dc + a) >> 1; p_tr = (ad + dc) >> 1; p_left = (ad + a) >> 1; p_right = (ad + d) >> 1;
+      p_bl = (ad + af) >> 1; p_down = (af + d) >> 1; p_br = (ad + de) >> 1;
+    } else if (hy) {
+      const int e = c[rs + 1], g = c[rs - 1], h = c[-1];
+      const int ad = av(a, d), af = av(a, f), fe = av(f, e), ah = av(a, h), gf = av(g, f);
+      p_tl = (ah + af) >> 1; p_top = (af + a) >> 1; p_tr = (ad + af) >> 1; p_left = (gf + a) >> 1; p_right = (ad + f) >> 1;
+      p_bl = (af + gf) >> 1; p_down = (af + f) >> 1; p_br = (af + fe) >> 1;
+    } else {
+      const int b = c[-rs], h = c[-1];
+      const int ad = av(a, d), af = av(a, f), ah = av(a, h), ab = av(a, b);
+      p_tl = (ah + ab) >> 1; p_top = (ab + a) >> 1; p_tr = (ad + ab) >> 1; p_left = (ah + a) >> 1; p_right = (ad + a) >> 1;
+      p_bl = (ah + af) >> 1; p_down = (af + a) >> 1; p_br = (af + ad) >> 1;
+    }
+    tl += iabs(o - p_tl); top += iabs(o - p_top); tr += iabs(o - p_tr); left += iabs(o - p_left); right += iabs(o - p_right);
+    bl += iabs(o - p_bl); down += iabs(o - p_down); br += iabs(o - p_br);
+  }
+  unsigned utop = (unsigned)team_sum(t, top), uright = (unsigned)team_sum(t, right), udown = (unsigned)team_sum(t, down), uleft = (unsigned)team_sum(t, left);
+  unsigned utl = (unsigned)team_sum(t, tl), utr = (unsigned)team_sum(t, tr), ubr = (unsigned)team_sum(t, br), ubl = (unsigned)team_sum(t, bl);
+  int x = 0, y = -1;
+  if (utl < utop) { x = -1; utop = utl; }
+  if (utr < utop) { x = 1; utop = utr; }
+  if (uleft < utop) { x = -1; y = 0; utop = uleft; }
+  if (uright < utop) { x = 1; y = 0; utop = uright; }
+  if (ubl < utop) { x = -1; y = 1; utop = ubl; }
+  if (udown < utop) { x = 0; y = 1; utop = udown; }
+  if (ubr < utop) { x = 1; y = 1; utop = ubr; }
+  *bx = x; *by = y;
+  return utop;
+}
 
 template <typename PIX>
 TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const PIX* ref, const MeArgs& a, mv_t mvc,
@@ -260,7 +355,43 @@ TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const 
   long long pq_ = (long long)__builtin_readcyclecounter();
   if (t.rank == 0) w->prof[11] += 1;
 #endif
-  // --- telescope (encode_block.c:529-561)
+  // 5-offset "widesad" evaluation of the clipped candidates w->cmv[0..n) (encode_block.c:430-453): per
+  // candidate the offset with the smallest SAD (ties -> leftmost), then the usual cost with the adjusted
+  // mv (written back to w->cmv).  Returns the best (cost << 32 | index).
+  auto eval_wide = [&](int n) -> unsigned long long {
+    unsigned long long bestk = ~0ull;
+    for (int base = 0; base < n; base += kMeWideChunk) {
+      const int m = n - base < kMeWideChunk ? n - base : kMeWideChunk;
+      auto widepel = [&](int c5) -> const PIX* {
+        int c = c5 / 5, o = c5 - c * 5;
+        int off = o == 0 ? -3 : o == 1 ? -1 : o == 2 ? 0 : o == 3 ? 1 : 3;
+        mv_t mm = w->cmv[base + c];
+        return ref + (s * (mm.y >> 2)) * a.rstride + s * (mm.x >> 2) + off;
+      };
+      sad_many_ptr(t, w->sad, m * 5, org, a.ostride, a.width, a.height, a.rstride, widepel);
+      unsigned long long k = ~0ull;
+      for (int lc = t.rank; lc < m; lc += t.size) {
+        const int c = base + lc;
+        mv_t mm = w->cmv[c];
+        int x = 0;
+        unsigned best = 1u << 31;
+        for (int o = 0; o < 5; o++) {
+          unsigned v = (unsigned)w->sad[lc * 5 + o];
+          if (v < best) { best = v; x = o == 0 ? -3 : o == 1 ? -1 : o == 2 ? 0 : o == 3 ? 1 : 3; }
+        }
+        mm.x = (int16_t)(mm.x + ((s * x) << 2));
+        w->cmv[c] = mm;  // adjusted mv, looked up again if this candidate wins
+        unsigned long long kk = ((unsigned long long)((best >> sh) + mv_cost(a.lam, mm.y - mvp.y, mm.x - mvp.x)) << 32) | (unsigned)c;
+        k = kk < k ? kk : k;
+      }
+      t.sync();
+      k = team_min64(t, k);
+      bestk = k < bestk ? k : bestk;
+    }
+    return bestk;
+  };
+  // --- telescope (encode_block.c:529-561); encoder_speed > 0 keeps it only for 16x16 CBs with bipred on
+  if ((a.cb_size == 16 && a.enable_bipred) || a.speed == 0)
   for (int step = 32; step >= 4; step >>= 1) {
     const int n = step < 32 ? 24 : 25;
     const mv_t centre = mv_ref;
@@ -269,8 +400,17 @@ TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const 
       int q = idx / 5;
       return mk_fp(mk_mv(centre.x + (idx - q * 5 - 2) * step, centre.y + (q - 2) * step));
     };
-    unsigned long long k = eval_fullpel(t, n, org, a.ostride, a.rstride, a.width, a.height, tele, fp_cost);
-    if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = tele((int)(unsigned)k).mv; }
+    if (step == 32 && a.cb_size == 16 && a.speed == 1) {  // first ring by widesad at encoder_speed 1
+      t.sync();
+      for (int c = t.rank; c < n; c += t.size) w->cmv[c] = tele(c).mv;
+      t.sync();
+      unsigned long long k = eval_wide(n);
+      if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = w->cmv[(int)(unsigned)k]; }
+      t.sync();
+    } else {
+      unsigned long long k = eval_fullpel(t, n, org, a.ostride, a.rstride, a.width, a.height, tele, fp_cost);
+      if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = tele((int)(unsigned)k).mv; }
+    }
     mv_ref = mv_opt;
   }
 
@@ -289,37 +429,7 @@ TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const 
       }
       t.sync();
       if (wide) {
-        // 16x16 CBs: 5-offset "widesad" (encode_block.c:430-453): per candidate the offset with the
-        // smallest SAD (ties -> leftmost), then the usual cost with the adjusted mv.
-        unsigned long long bestk = ~0ull;
-        for (int base = 0; base < n; base += kMeWideChunk) {
-          const int m = n - base < kMeWideChunk ? n - base : kMeWideChunk;
-          auto widepel = [&](int c5) -> const PIX* {
-            int c = c5 / 5, o = c5 - c * 5;
-            int off = o == 0 ? -3 : o == 1 ? -1 : o == 2 ? 0 : o == 3 ? 1 : 3;
-            mv_t mm = w->cmv[base + c];
-            return ref + (s * (mm.y >> 2)) * a.rstride + s * (mm.x >> 2) + off;
-          };
-          sad_many_ptr(t, w->sad, m * 5, org, a.ostride, a.width, a.height, a.rstride, widepel);
-          unsigned long long k = ~0ull;
-          for (int lc = t.rank; lc < m; lc += t.size) {
-            const int c = base + lc;
-            mv_t mm = w->cmv[c];
-            int x = 0;
-            unsigned best = 1u << 31;
-            for (int o = 0; o < 5; o++) {
-              unsigned v = (unsigned)w->sad[lc * 5 + o];
-              if (v < best) { best = v; x = o == 0 ? -3 : o == 1 ? -1 : o == 2 ? 0 : o == 3 ? 1 : 3; }
-            }
-            mm.x = (int16_t)(mm.x + ((s * x) << 2));
-            w->cmv[c] = mm;  // adjusted mv, looked up again if this candidate wins
-            unsigned long long kk = ((unsigned long long)((best >> sh) + mv_cost(a.lam, mm.y - mvp.y, mm.x - mvp.x)) << 32) | (unsigned)c;
-            k = kk < k ? kk : k;
-          }
-          t.sync();
-          k = team_min64(t, k);
-          bestk = k < bestk ? k : bestk;
-        }
+        unsigned long long bestk = eval_wide(n);
         if ((unsigned)(bestk >> 32) < min_sad) { min_sad = (unsigned)(bestk >> 32); mv_opt = w->cmv[(int)(unsigned)bestk]; }
         t.sync();
       } else {
@@ -336,10 +446,11 @@ TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const 
   if (t.rank == 0) w->prof[14] += (long long)__builtin_readcyclecounter() - pq_;
   pq_ = (long long)__builtin_readcyclecounter();
 #endif
-  // --- hexagon refinement (encode_block.c:583-616), encoder_speed 0 => up to 5 rounds
+  // --- hexagon refinement (encode_block.c:583-616): up to 5 rounds; skipped for CBs > 16 at encoder_speed > 0
   {
     int start = 0, end = 5;
-    for (int step = 1; step < 6; step++) {
+    const int maxsteps = (a.cb_size <= 16 || a.speed == 0) ? 6 : 0;
+    for (int step = 1; step < maxsteps; step++) {
       const int n = (end - start + 6) % 6 + 1;  // 6 in the first round, 3 afterwards
       const mv_t centre = mv_ref;
       auto hex = [&](int c) -> FP {
@@ -369,6 +480,7 @@ TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const 
   pt0_ = (long long)__builtin_readcyclecounter();
 #endif
   unsigned cmin = min_sad;
+  if (a.speed == 0)
   for (int pass = 0; pass < 2; pass++) {
     const int d = pass == 0 ? 2 : 1;
     const mv_t base = pass == 0 ? mv_ref : mv_opt;
@@ -396,6 +508,22 @@ TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const 
     if ((unsigned)(k >> 32) < cmin) { cmin = (unsigned)(k >> 32); best = sub_prep((int)(unsigned)k).mv; }
     // mv_opt += delta of the winning position (none => unchanged)
     mv_opt = mk_mv(mv_opt.x + (best.x - base.x), mv_opt.y + (best.y - base.y));
+  }
+  else {
+    // bilinear approximation (encode_block.c:664-707).  NB the reference folds the sign into mv_ref before
+    // pricing the half-pel vector, so for a backward reference the rate term sees the negated vector.
+    mv_t mr = mk_mv(mv_ref.x * s, mv_ref.y * s);
+    int spx = 0, spy = 0, xd_hp = 0, yd_hp = 0, xd_qp = 0, yd_qp = 0;
+    unsigned sad = fast_halfpel(t, org, ref + (mr.y >> 2) * a.rstride + (mr.x >> 2), a.ostride, a.rstride, a.width, a.height, &spx, &spy) >> sh;
+    sad += mv_cost(a.lam, mr.y + s * spy - mvp.y, mr.x + s * spx - mvp.x);
+    if (sad < cmin) { cmin = sad; xd_hp = s * spx; yd_hp = s * spy; }
+    spx = xd_hp; spy = yd_hp;
+    mr = mk_mv(mv_opt.x + s * spx, mv_opt.y + s * spy);
+    mv_opt = mk_mv(mv_opt.x + xd_hp, mv_opt.y + yd_hp);
+    sad = fast_quarterpel(t, org, ref + (s * (mr.y >> 2)) * a.rstride + s * (mr.x >> 2), a.ostride, a.rstride, a.width, a.height, &spx, &spy) >> sh;
+    sad += mv_cost(a.lam, mr.y + s * spy - mvp.y, mr.x + s * spx - mvp.x);
+    if (sad < cmin) { cmin = sad; xd_qp = s * spx; yd_qp = s * spy; }
+    mv_opt = mk_mv(mv_opt.x + xd_qp, mv_opt.y + yd_qp);
   }
   TK_PROF_ADD(w, 3);
   *mv_out = mv_opt;

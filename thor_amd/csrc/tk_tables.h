@@ -67,6 +67,12 @@ static inline void init_tables(Tables* t) {
   // chroma QP mapping (common_tables.c:68-73): identity to 29, then a compressed tail.
   static const uint8_t cq_tail[22] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36,
                                       36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45};
+  {  // 8x8 inverse-quantiser step per qp used by the encoder_speed > 0 top-down split test (encode_block.c:2394)
+    static const uint16_t iq[52] = {6,   7,   8,   8,   10,  11,  12,  13,  15,  17,  19,  21,  24,  27,  30,  34,  38,  43,
+                                    48,  54,  60,  68,  76,  86,  96,  108, 121, 136, 152, 171, 192, 216, 242, 272, 305, 342,
+                                    384, 431, 484, 543, 610, 684, 768, 862, 968, 1086, 1219, 1368, 1536, 1724, 1935, 2172};
+    for (int q = 0; q < 52; q++) t->iq_8x8[q] = iq[q];
+  }
   for (int q = 0; q < 30; q++) t->chroma_qp[q] = (uint8_t)q;
   for (int q = 30; q < 52; q++) t->chroma_qp[q] = cq_tail[q - 30];
   // deblocking thresholds (common_frame.c:37-45)
