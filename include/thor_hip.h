@@ -54,6 +54,7 @@ typedef struct thor_hip_params { /* the enc_params fields this path honours (enc
   float lambda_coeffB, lambda_coeffB0, lambda_coeffB1, lambda_coeffB2, lambda_coeffB3;
   int dqpB, dqpB0, dqpB1, dqpB2, dqpB3;
   float mqpB, mqpB0, mqpB1, mqpB2, mqpB3;
+  int max_clpf_strength; /* CLPF strength cap (enc/strings.c:351) */
 } thor_hip_params;
 
 typedef struct thor_hip_encoder thor_hip_encoder;

@@ -22,13 +22,23 @@ CASES = {
     '192x128_n6_q36_ra_gop4_nointerp': ('clip_192x128_6.yuv.gz', 192, 128, 6, 36, ['-num_reorder_pics', '3', '-interp_ref', '0'], 'ra_high_efficiency.cfg'),
     '192x128_n5_q32_hdb16_gop4_10bit': ('clip10_192x128_5.yuv.gz', 192, 128, 5, 32,
                                         ['-num_reorder_pics', '3', '-bitdepth', '10', '-input_bitdepth', '10'], 'hdb16_high_efficiency.cfg'),
+    # low / medium complexity operating points: encoder_speed 2 / 1, CLPF
+    '192x128_n6_q32_ldb_low': ('clip_192x128_6.yuv.gz', 192, 128, 6, 32, [], 'ldb_low_complexity.cfg'),
+    '208x120_n4_q30_ldb_medium': ('clip_208x120_4.yuv.gz', 208, 120, 4, 30, [], 'ldb_medium_complexity.cfg'),
+    '208x120_n4_q38_ldb_medium_clpf': ('clip_208x120_4.yuv.gz', 208, 120, 4, 38, ['-clpf', '1'], 'ldb_medium_complexity.cfg'),
+    '192x128_n5_q34_ldb_low_10bit': ('clip10_192x128_5.yuv.gz', 192, 128, 5, 34, ['-bitdepth', '10', '-input_bitdepth', '10'], 'ldb_low_complexity.cfg'),
+    # BASELINE config 1 exactly: 352x288, 30 frames, seed 1, LDB_low_complexity, qp 32 (clip generated, not committed)
+    'cfg1_352x288_n30_q32_ldb_low': ('gen:352,288,30,1,2.0', 352, 288, 30, 32, [], 'ldb_low_complexity.cfg'),
 }
 out = {}
 with tempfile.TemporaryDirectory() as d:
     for name, case in CASES.items():
         clip, w, h, n, qp, extra = case[:6]
         cfg = case[6] if len(case) > 6 else 'ldb_high_efficiency.cfg'
-        raw = gzip.open(os.path.join(G, clip)).read()
+        import sys
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        from util import golden_clip
+        raw = golden_clip(clip)
         open(os.path.join(d, 'in.yuv'), 'wb').write(raw)
         log = subprocess.run([os.path.join(ROOT, 'oracle/_ref/Thorenc'), '-cf', os.path.join(ROOT, 'configs', cfg),
                               '-if', os.path.join(d, 'in.yuv'), '-width', str(w), '-height', str(h), '-qp', str(qp), '-n', str(n),

@@ -84,6 +84,24 @@ template <typename PIX> void run_cdef(const CdefJob<PIX>* cj, const CdefJob<PIX>
     cdef_pass_apply(C, 0, 1);
   }
 }
+template <typename PIX> void run_clpf_stats(const ClpfJob<PIX>* lj, const ClpfJob<PIX>*, int S) {
+  for (int s = 0; s < S; s++) clpf_pass_stats(lj[s], 0, 1);
+}
+template <typename PIX> void run_clpf_apply(const ClpfJob<PIX>* lj, const ClpfJob<PIX>*, int S) {
+  for (int s = 0; s < S; s++) {
+    const ClpfJob<PIX>& C = lj[s];
+    for (int i = 0; i < C.height; i++) memcpy(C.src.y + (size_t)i * C.src.sy, C.rec.y + (size_t)i * C.rec.sy, C.width * sizeof(PIX));
+    for (int i = 0; i < C.height / 2; i++) {
+      memcpy(C.src.u + (size_t)i * C.src.sc, C.rec.u + (size_t)i * C.rec.sc, C.width / 2 * sizeof(PIX));
+      memcpy(C.src.v + (size_t)i * C.src.sc, C.rec.v + (size_t)i * C.rec.sc, C.width / 2 * sizeof(PIX));
+    }
+    clpf_pass_apply(C, 0, 1);
+  }
+}
+template void run_clpf_stats<uint8_t>(const ClpfJob<uint8_t>*, const ClpfJob<uint8_t>*, int);
+template void run_clpf_stats<uint16_t>(const ClpfJob<uint16_t>*, const ClpfJob<uint16_t>*, int);
+template void run_clpf_apply<uint8_t>(const ClpfJob<uint8_t>*, const ClpfJob<uint8_t>*, int);
+template void run_clpf_apply<uint16_t>(const ClpfJob<uint16_t>*, const ClpfJob<uint16_t>*, int);
 template void run_cdef<uint8_t>(const CdefJob<uint8_t>*, const CdefJob<uint8_t>*, int);
 template void run_cdef<uint16_t>(const CdefJob<uint16_t>*, const CdefJob<uint16_t>*, int);
 template void run_superblocks<uint8_t>(const FrameJob<uint8_t>*, const FrameJob<uint8_t>*, int);

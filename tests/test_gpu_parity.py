@@ -84,11 +84,11 @@ def test_dropin_reference_front_end_on_our_library():
 
 
 @pytest.mark.skipif(not os.path.exists(REF_HIPENC), reason='oracle/_ref/Thorenc_hip not in the snapshot')
-@pytest.mark.parametrize('name', ['128x96_n9_q32_ra', '192x128_n5_q32_hdb16_gop4_10bit'])
+@pytest.mark.parametrize('name', ['128x96_n9_q32_ra', '192x128_n5_q32_hdb16_gop4_10bit', '192x128_n6_q32_ldb_low'])
 def test_dropin_front_end_hierarchical_b(name):
     """Same seam with the reference's GOP loop driving B frames: the caller interpolates the reference frame
     on the CPU (enc/mainenc.c:353) and hands it over in encoder_info.interp_frames[0]; 10-bit goes through
-    encode_frame_hbd."""
+    encode_frame_hbd; the low-complexity case exercises encoder_speed 2 + CLPF through the seam."""
     c = G[name]
     bits, rec = run_encoder(REF_HIPENC, golden_clip(c['clip']), c['w'], c['h'], c['n'], c['qp'], c['extra'], cfg=c['cfg'])
     assert md5(bits) == c['bit_md5'] and md5(rec) == c['rec_md5']

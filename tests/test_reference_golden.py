@@ -25,7 +25,9 @@ def test_reference_reproduces_golden_and_roundtrips(name):
 
 @pytest.mark.parametrize('name', ['192x128_n3_q32', '208x120_n4_q32', '192x128_n3_q32_skip3', '192x128_n4_q44', '192x128_n4_q32_10bit',
                                   '128x96_n9_q32_ra', '192x128_n6_q30_ra_gop4', '192x128_n6_q36_ra_gop4_nointerp',
-                                  '192x128_n5_q32_hdb16_gop4_10bit'])
+                                  '192x128_n5_q32_hdb16_gop4_10bit',
+                                  '192x128_n6_q32_ldb_low', '208x120_n4_q30_ldb_medium', '208x120_n4_q38_ldb_medium_clpf',
+                                  '192x128_n5_q34_ldb_low_10bit', 'cfg1_352x288_n30_q32_ldb_low'])
 def test_engine_host_simulation_matches_golden(name):
     c = G[name]
     bits, rec = run_encoder(build_hostsim(), golden_clip(c['clip']), c['w'], c['h'], c['n'], c['qp'], c['extra'], cfg=c.get('cfg'))

@@ -4,6 +4,7 @@ import gzip
 import hashlib
 import json
 import os
+import sys
 import subprocess
 import tempfile
 
@@ -27,6 +28,12 @@ def golden_streams():
 
 
 def golden_clip(name):
+    """Committed clip, or 'gen:w,h,frames,seed,sigma' = the seeded synthetic generator (oracle/gen_clip.py)."""
+    if name.startswith('gen:'):
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        import gen_clip
+        w, h, n, seed, sigma = name[4:].split(',')
+        return b''.join(p.tobytes() for fr in gen_clip.make_clip(int(w), int(h), int(n), int(seed), float(sigma)) for p in fr)
     return gzip.open(os.path.join(GOLD, name)).read()
 
 

@@ -43,7 +43,7 @@ class ThorParams(C.Structure):
                 ('dyadic_coding', C.c_int), ('lambda_coeffB', C.c_float), ('lambda_coeffB0', C.c_float), ('lambda_coeffB1', C.c_float),
                 ('lambda_coeffB2', C.c_float), ('lambda_coeffB3', C.c_float), ('dqpB', C.c_int), ('dqpB0', C.c_int), ('dqpB1', C.c_int),
                 ('dqpB2', C.c_int), ('dqpB3', C.c_int), ('mqpB', C.c_float), ('mqpB0', C.c_float), ('mqpB1', C.c_float),
-                ('mqpB2', C.c_float), ('mqpB3', C.c_float)]
+                ('mqpB2', C.c_float), ('mqpB3', C.c_float), ('max_clpf_strength', C.c_int)]
 
 
 def lib():

@@ -14,6 +14,7 @@
 #include "tk_block.h"
 #include "tk_filters.h"
 #include "tk_cdef.h"
+#include "tk_clpf.h"
 #include "tk_encoder.h"
 #include "tk_cli.h"
 #include "../../include/thor_hip.h"
@@ -202,6 +203,23 @@ template <typename PIX> __global__ void k_cdef(const CdefJob<PIX>* cj, int pass)
   else if (pass == 2) { if (C.cdef_bits) cdef_pass_mse(C, gid, gsize); }
   else if (pass == 4) cdef_pass_apply(C, gid, gsize);
 }
+template <typename PIX> __global__ void k_clpf(const ClpfJob<PIX>* lj, int pass) {
+  const ClpfJob<PIX>& L = lj[blockIdx.y];
+  const int gid = (int)(blockIdx.x * blockDim.x + threadIdx.x), gsize = (int)(gridDim.x * blockDim.x);
+  if (pass == 0) clpf_pass_stats(L, gid, gsize);
+  else clpf_pass_apply(L, gid, gsize);
+}
+template <typename PIX> __global__ void k_clpf_copy(const ClpfJob<PIX>* lj) {  // rec -> src (unfiltered copy)
+  const ClpfJob<PIX>& C = lj[blockIdx.y];
+  const int rows = C.height + C.height;
+  for (int it = blockIdx.x; it < rows; it += gridDim.x) {
+    const PIX* s; PIX* d; int w;
+    if (it < C.height) { s = C.rec.y + (size_t)it * C.rec.sy; d = C.src.y + (size_t)it * C.src.sy; w = C.width; }
+    else if (it < C.height + C.height / 2) { int r = it - C.height; s = C.rec.u + (size_t)r * C.rec.sc; d = C.src.u + (size_t)r * C.src.sc; w = C.width / 2; }
+    else { int r = it - C.height - C.height / 2; s = C.rec.v + (size_t)r * C.rec.sc; d = C.src.v + (size_t)r * C.src.sc; w = C.width / 2; }
+    for (int x = threadIdx.x; x < w; x += blockDim.x) d[x] = s[x];
+  }
+}
 template <typename PIX> __global__ __launch_bounds__(1024) void k_cdef_select(const CdefJob<PIX>* cj) {
   Team t{(int)threadIdx.x, (int)blockDim.x};
   cdef_pass_select(t, cj[blockIdx.x]);
@@ -382,6 +400,23 @@ template <typename PIX> void run_cdef(const CdefJob<PIX>* cj, const CdefJob<PIX>
   g_filt_events.push_back(ev);
   HIPCHECK(hipGetLastError());
 }
+template <typename PIX> void run_clpf_stats(const ClpfJob<PIX>* lj, const ClpfJob<PIX>* hlj, int S) {
+  const int nb = (hlj[0].width / 8) * (hlj[0].height / 8) + 2 * (hlj[0].width / 16) * (hlj[0].height / 16);
+  auto ev = ev_begin();
+  hipLaunchKernelGGL(k_clpf<PIX>, dim3((nb + 63) / 64, S), dim3(64), 0, g_stream, lj, 0);
+  HIPCHECK(hipEventRecord(ev.second, g_stream));
+  g_filt_events.push_back(ev);
+  HIPCHECK(hipGetLastError());
+}
+template <typename PIX> void run_clpf_apply(const ClpfJob<PIX>* lj, const ClpfJob<PIX>* hlj, int S) {
+  const int nu = 3 * (hlj[0].width / 8) * (hlj[0].height / 8);
+  auto ev = ev_begin();
+  hipLaunchKernelGGL(k_clpf_copy<PIX>, dim3(hlj[0].height * 2, S), dim3(256), 0, g_stream, lj);
+  hipLaunchKernelGGL(k_clpf<PIX>, dim3((nu + 63) / 64, S), dim3(64), 0, g_stream, lj, 1);
+  HIPCHECK(hipEventRecord(ev.second, g_stream));
+  g_filt_events.push_back(ev);
+  HIPCHECK(hipGetLastError());
+}
 void run_gather(const GatherItem* d_items, int n, uint32_t* dst) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_gather_bits, dim3(n), dim3(64), 0, g_stream, d_items, n, dst);
@@ -392,6 +427,10 @@ template void run_deblock<uint8_t>(const FrameJob<uint8_t>*, const FrameJob<uint
 template void run_make_ref<uint8_t>(const FrameJob<uint8_t>*, const Plane3<uint8_t>*, int);
 template void run_cdef<uint8_t>(const CdefJob<uint8_t>*, const CdefJob<uint8_t>*, int);
 template void run_superblocks<uint16_t>(const FrameJob<uint16_t>*, const FrameJob<uint16_t>*, int);
+template void run_clpf_stats<uint8_t>(const ClpfJob<uint8_t>*, const ClpfJob<uint8_t>*, int);
+template void run_clpf_stats<uint16_t>(const ClpfJob<uint16_t>*, const ClpfJob<uint16_t>*, int);
+template void run_clpf_apply<uint8_t>(const ClpfJob<uint8_t>*, const ClpfJob<uint8_t>*, int);
+template void run_clpf_apply<uint16_t>(const ClpfJob<uint16_t>*, const ClpfJob<uint16_t>*, int);
 template void run_deblock<uint16_t>(const FrameJob<uint16_t>*, const FrameJob<uint16_t>*, int);
 template void run_make_ref<uint16_t>(const FrameJob<uint16_t>*, const Plane3<uint16_t>*, int);
 template void run_cdef<uint16_t>(const CdefJob<uint16_t>*, const CdefJob<uint16_t>*, int);
@@ -430,7 +469,7 @@ static SeqParams to_seq(const thor_hip_params& p) {
   s.dqpP = p.dqpP; s.dqpI = p.dqpI; s.mqpP = p.mqpP; s.intra_period = p.intra_period; s.intra_rdo = p.intra_rdo;
   s.encoder_speed = p.encoder_speed; s.deblocking = p.deblocking; s.cdef = p.cdef; s.clpf = p.clpf;
   s.use_block_contexts = p.use_block_contexts; s.enable_bipred = p.enable_bipred; s.cfl_intra = p.cfl_intra; s.cfl_inter = p.cfl_inter;
-  s.dyadic_coding = p.dyadic_coding;
+  s.dyadic_coding = p.dyadic_coding; s.max_clpf_strength = p.max_clpf_strength;
   s.lambda_coeffB = p.lambda_coeffB; s.lambda_coeffB0 = p.lambda_coeffB0; s.lambda_coeffB1 = p.lambda_coeffB1;
   s.lambda_coeffB2 = p.lambda_coeffB2; s.lambda_coeffB3 = p.lambda_coeffB3;
   s.dqpB = p.dqpB; s.dqpB0 = p.dqpB0; s.dqpB1 = p.dqpB1; s.dqpB2 = p.dqpB2; s.dqpB3 = p.dqpB3;
@@ -445,7 +484,7 @@ static void from_seq(thor_hip_params* p, const SeqParams& s) {
   p->dqpP = s.dqpP; p->dqpI = s.dqpI; p->mqpP = s.mqpP; p->intra_period = s.intra_period; p->intra_rdo = s.intra_rdo;
   p->encoder_speed = s.encoder_speed; p->deblocking = s.deblocking; p->cdef = s.cdef; p->clpf = s.clpf;
   p->use_block_contexts = s.use_block_contexts; p->enable_bipred = s.enable_bipred; p->cfl_intra = s.cfl_intra; p->cfl_inter = s.cfl_inter;
-  p->dyadic_coding = s.dyadic_coding;
+  p->dyadic_coding = s.dyadic_coding; p->max_clpf_strength = s.max_clpf_strength;
   p->lambda_coeffB = s.lambda_coeffB; p->lambda_coeffB0 = s.lambda_coeffB0; p->lambda_coeffB1 = s.lambda_coeffB1;
   p->lambda_coeffB2 = s.lambda_coeffB2; p->lambda_coeffB3 = s.lambda_coeffB3;
   p->dqpB = s.dqpB; p->dqpB0 = s.dqpB0; p->dqpB1 = s.dqpB1; p->dqpB2 = s.dqpB2; p->dqpB3 = s.dqpB3;
@@ -461,8 +500,7 @@ static int unsupported(const SeqParams& s) {
   if (s.num_reorder_pics < 0 || s.num_reorder_pics > 15 || (s.num_reorder_pics & (s.num_reorder_pics + 1)))
     return fprintf(stderr, "thor_hip: num_reorder_pics must be 0, 1, 3, 7 or 15\n"), 1;
   if (s.interp_ref != 0 && s.interp_ref != 1) return fprintf(stderr, "thor_hip: interp_ref must be 0 or 1\n"), 1;
-  if (s.encoder_speed != 0) return fprintf(stderr, "thor_hip: encoder_speed > 0 not implemented\n"), 1;
-  if (s.clpf != 0) return fprintf(stderr, "thor_hip: CLPF not implemented\n"), 1;
+  if (s.encoder_speed < 0 || s.encoder_speed > 2) return fprintf(stderr, "thor_hip: encoder_speed must be 0, 1 or 2\n"), 1;
   if (s.width % 8 || s.height % 8 || s.width < 16 || s.height < 16) return fprintf(stderr, "thor_hip: bad geometry\n"), 1;
   if (s.max_num_ref < 1 || s.max_num_ref > 4) return fprintf(stderr, "thor_hip: max_num_ref out of range\n"), 1;
   return 0;
@@ -657,6 +695,7 @@ template <typename PIX> static void encode_frame_impl(struct thor_encoder_info* 
     s.intra_period = ep.intra_period; s.intra_rdo = ep.intra_rdo; s.encoder_speed = ep.encoder_speed; s.deblocking = ep.deblocking;
     s.cdef = ep.cdef; s.clpf = ep.clpf; s.use_block_contexts = ep.use_block_contexts; s.enable_bipred = ep.enable_bipred;
     s.cfl_intra = ep.cfl_intra; s.cfl_inter = ep.cfl_inter; s.log2_sb_size = ep.log2_sb_size;
+    s.max_clpf_strength = ep.max_clpf_strength;
     s.dyadic_coding = 1;  // the caller owns the GOP structure; only the window size matters here
     if (ep.subsample != 420 || ep.log2_sb_size != 7 || ep.qmtx || ep.max_delta_qp || ep.bitrate || ep.sync)
       seam_fatal("thor_hip: unsupported encoder parameters (need 4:2:0, 128x128 SB, no qmtx / delta-QP / rate control / sync)");

@@ -59,6 +59,7 @@ static inline void cli_apply(CliArgs& a, const std::vector<std::string>& t) {
     else if (k == "-HQperiod") p.HQperiod = I();
     else if (k == "-num_reorder_pics") p.num_reorder_pics = I();
     else if (k == "-interp_ref") p.interp_ref = I();
+    else if (k == "-max_clpf_strength") p.max_clpf_strength = I();
     else if (k == "-dqpP") p.dqpP = I();
     else if (k == "-dqpB") p.dqpB = I();
     else if (k == "-dqpB0") p.dqpB0 = I();

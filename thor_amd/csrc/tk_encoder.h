@@ -16,6 +16,7 @@
 #include "tk_tables.h"
 #include "tk_cdef.h"
 #include "tk_interp.h"
+#include "tk_clpf.h"
 
 namespace tk {
 
@@ -30,6 +31,8 @@ void dev_sync();
 size_t team_ws_bytes(int pix_bytes);
 // jobs: device array of S FrameJob; hjobs: the same on the host.
 template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S);
+template <typename PIX> void run_clpf_stats(const ClpfJob<PIX>* jobs, const ClpfJob<PIX>* hjobs, int S);
+template <typename PIX> void run_clpf_apply(const ClpfJob<PIX>* jobs, const ClpfJob<PIX>* hjobs, int S);  // copies rec -> src first
 template <typename PIX> void run_deblock(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S);
 template <typename PIX> void run_make_ref(const FrameJob<PIX>* hjobs, const Plane3<PIX>* dst, int S);
 // copies rec -> src, then runs the five CDEF passes; cjobs/hcjobs: device/host arrays of S CdefJob
@@ -51,7 +54,7 @@ struct SeqParams {  // the enc_params fields this path honours (enc/mainenc.h:35
   int dqpP = 0, dqpI = 0, dqpB = 0, dqpB0 = 0, dqpB1 = 0, dqpB2 = 0, dqpB3 = 0;
   float mqpP = 1.f, mqpB = 1.f, mqpB0 = 1.f, mqpB1 = 1.f, mqpB2 = 1.f, mqpB3 = 1.f;
   int intra_period = 0, intra_rdo = 0, encoder_speed = 0;
-  int deblocking = 1, cdef = 2, clpf = 0, use_block_contexts = 0, enable_bipred = 0;
+  int deblocking = 1, cdef = 2, clpf = 0, max_clpf_strength = 4, use_block_contexts = 0, enable_bipred = 0;
   int cfl_intra = 1, cfl_inter = 0;
   int log2_sb_size = 7;
 };
@@ -314,6 +317,7 @@ template <typename PIX> struct Stream {
   // CDEF state
   int8_t* cdef_dir = nullptr; int* cdef_var = nullptr; int* cdef_fbc = nullptr; unsigned long long* cdef_mse = nullptr;
   int* cdef_sel = nullptr; int* cdef_fbsel = nullptr; CdefResult* cdef_res = nullptr; unsigned long long* cdef_tot = nullptr;
+  uint32_t* clpf_stats = nullptr; uint8_t* clpf_fb_on = nullptr;   // CLPF: per-8x8 statistics, per-filter-block switches
   int num_encoded = 0;
   GopScheduler gop;          // coding-order schedule (initialised by begin_sequence or lazily as open-ended low delay)
   FrameParams cur;           // frame returned by the last schedule()
@@ -332,6 +336,8 @@ template <typename PIX> class Engine {
   std::vector<FrameJob<PIX>> h_jobs;
   CdefJob<PIX>* d_cjobs = nullptr;
   std::vector<CdefJob<PIX>> h_cjobs;
+  ClpfJob<PIX>* d_ljobs = nullptr;
+  std::vector<ClpfJob<PIX>> h_ljobs;
   int nfb_h = 0, nfb_v = 0;
   size_t ws_bytes = 0;
   int* d_nbits_all = nullptr; int* d_status_all = nullptr;   // [S][nsb]
@@ -381,16 +387,24 @@ template <typename PIX> class Engine {
       s.cdef_fbsel = (int*)backend::dev_alloc(nfb * sizeof(int));
       s.cdef_res = (CdefResult*)backend::dev_alloc(sizeof(CdefResult));
       s.cdef_tot = (unsigned long long*)backend::dev_alloc((size_t)kCdefMaxStr * kCdefMaxStr * 8);
+      if (p.clpf) {
+        s.clpf_stats = (uint32_t*)backend::dev_alloc(clpf_stat_words() * 4);
+        s.clpf_fb_on = (uint8_t*)backend::dev_alloc((size_t)((p.width + 31) / 32) * ((p.height + 31) / 32));
+      }
       if (!raw_frames) write_sequence_header(s.bits, sp);
     }
+    d_ljobs = (ClpfJob<PIX>*)backend::dev_alloc(sizeof(ClpfJob<PIX>) * S);
+    h_ljobs.resize(S);
     d_jobs = (FrameJob<PIX>*)backend::dev_alloc(sizeof(FrameJob<PIX>) * S);
     h_jobs.resize(S);
     d_cjobs = (CdefJob<PIX>*)backend::dev_alloc(sizeof(CdefJob<PIX>) * S);
     h_cjobs.resize(S);
     d_prof = (long long*)backend::dev_alloc(16 * sizeof(long long));
   }
+  size_t clpf_stat_words() const { return 4 * ((size_t)(sp.width / 8) * (sp.height / 8) + 2 * (size_t)(sp.width / 16) * (sp.height / 16)); }
   void close() {
     for (auto& s : st) {
+      backend::dev_free(s.clpf_stats); backend::dev_free(s.clpf_fb_on);
       s.orig.release(); s.rec.release(); s.tmp.release(); s.interp.release();
       backend::dev_free(s.cdef_dir); backend::dev_free(s.cdef_var); backend::dev_free(s.cdef_fbc); backend::dev_free(s.cdef_mse);
       backend::dev_free(s.cdef_sel); backend::dev_free(s.cdef_fbsel); backend::dev_free(s.cdef_res); backend::dev_free(s.cdef_tot);
@@ -402,6 +416,7 @@ template <typename PIX> class Engine {
     d_nbits_all = d_status_all = nullptr; d_items = nullptr; d_payload = nullptr; payload_words = 0;
     backend::dev_free(d_jobs); d_jobs = nullptr;
     backend::dev_free(d_cjobs); d_cjobs = nullptr;
+    backend::dev_free(d_ljobs); d_ljobs = nullptr;
     backend::dev_free(d_prof); d_prof = nullptr;
   }
 
@@ -530,6 +545,40 @@ template <typename PIX> class Engine {
       backend::h2d(d_cjobs, h_cjobs.data(), sizeof(CdefJob<PIX>) * S);
       backend::run_cdef<PIX>(d_cjobs, h_cjobs.data(), S);
     }
+    // CLPF (encode_frame.c:785-817): statistics on the device, frame-level plan on the host, filter on the device
+    std::vector<ClpfPlan> lplan(sp.clpf ? S : 0);
+    if (sp.clpf) {
+      bool any = false;
+      for (int s = 0; s < S; s++) {
+        Stream<PIX>& q = st[s];
+        ClpfJob<PIX>& L = h_ljobs[s];
+        L.rec = q.rec.p; L.src = q.tmp.p; L.org = q.orig.p;
+        L.width = sp.width; L.height = sp.height; L.bitdepth = sp.bitdepth; L.qp = fp[s].qp;
+        L.cells = q.cells; L.cs = sp.width / 4; L.stats = q.clpf_stats;
+        L.strength[0] = L.strength[1] = L.strength[2] = 0; L.fb_log2 = 7; L.fb_on = q.clpf_fb_on;
+        any = any || fp[s].qp > 16;
+      }
+      if (any) {
+        backend::h2d(d_ljobs, h_ljobs.data(), sizeof(ClpfJob<PIX>) * S);
+        backend::run_clpf_stats<PIX>(d_ljobs, h_ljobs.data(), S);
+        backend::dev_sync();
+        std::vector<uint32_t> hst(clpf_stat_words());
+        bool filt = false;
+        for (int s = 0; s < S; s++) {
+          if (fp[s].qp > 16) backend::d2h(hst.data(), st[s].clpf_stats, hst.size() * 4);
+          lplan[s] = clpf_plan(hst.data(), sp.width, sp.height, fp[s].qp, h_jobs[s].lambda, sp.max_clpf_strength);
+          ClpfJob<PIX>& L = h_ljobs[s];
+          for (int k = 0; k < 3; k++) { L.strength[k] = lplan[s].strength[k]; filt = filt || L.strength[k]; }
+          L.fb_log2 = lplan[s].fb_log2;
+          if (!lplan[s].fb_on.empty()) backend::h2d(st[s].clpf_fb_on, lplan[s].fb_on.data(), lplan[s].fb_on.size());
+        }
+        if (filt) {
+          backend::h2d(d_ljobs, h_ljobs.data(), sizeof(ClpfJob<PIX>) * S);
+          backend::run_clpf_apply<PIX>(d_ljobs, h_ljobs.data(), S);
+        }
+      } else
+        for (int s = 0; s < S; s++) lplan[s] = clpf_plan(nullptr, sp.width, sp.height, fp[s].qp, h_jobs[s].lambda, sp.max_clpf_strength);
+    }
     // sliding window: the slot shifted out becomes ref[0] (encode_frame.c:826-835)
     std::vector<Plane3<PIX>> dst(S);
     for (int s = 0; s < S; s++) {
@@ -607,6 +656,8 @@ template <typename PIX> class Engine {
         for (int i = 0; i < 8; i++) { ch.strengths[i] = R.strengths[i]; ch.uv_strengths[i] = R.uv_strengths[i]; }
         write_cdef_params(b, cdef_pos, 1, ch);
       }
+      if (sp.clpf)
+        for (auto& pr : lplan[s].bits) b.put(pr.first, pr.second);
       q.num_encoded++;
       if (q.gop.started) q.gop.advance(f);
       if (raw_frames) continue;
