@@ -7,6 +7,8 @@ partition of this path that is bit-exact, SURVEY.md 8e: stream s is exactly what
 produces with -skip/-n for its chunk).  Warm-up steps include each stream's I frame; the timed K
 steps are the following P frames (the low-delay GOP has one I frame per chunk).  Inputs are staged
 in HBM before the timed region.  value = luma pixels coded by all ranks / max-over-ranks wall time.
+S defaults to 1024 per GPU: a frame's superblock dependency chain is ~32 superblocks long and the
+kernel keeps 3072 wavefronts resident, so fewer than ~730 streams cannot fill the chip.
 
   python bench.py --gpus N --steps K --warmup W [--streams S] [--width 1920 --height 1080]
 For N > 1 launch with torch.distributed.run (one rank per GPU); streams are sharded across ranks
@@ -100,7 +102,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--streams', type=int, default=int(os.environ.get('THOR_BENCH_STREAMS', '512')), help='streams PER GPU')
+    ap.add_argument('--streams', type=int, default=int(os.environ.get('THOR_BENCH_STREAMS', '1024')), help='streams PER GPU')
     ap.add_argument('--width', type=int, default=1920)
     ap.add_argument('--height', type=int, default=1080)
     ap.add_argument('--qp', type=int, default=32)
@@ -172,9 +174,9 @@ def main():
                          'frac': round(achieved / HBM_PEAK_GBS, 8), 'traffic': None,
                          'kernel': 'k_superblocks', 'launches': launches, 'avg_launch_ms': round(avg_launch_s * 1e3, 3),
                          'alg_bytes_per_px': bytes_per_px,
-                         'note': 'path is latency/VALU-bound, not HBM-bound (SURVEY.md 0.7); filters+ref kernels took %.1f ms' % filt_ms},
+                         'note': 'one persistent dependency-driven launch per frame; path is latency/VALU-bound, not HBM-bound (SURVEY.md 0.7); filters+ref kernels took %.1f ms' % filt_ms},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:
             cb = cpu_baseline(first, w, h, a.warmup, a.steps)
             if cb:
                 out['cpu_baseline'] = cb

@@ -9,13 +9,14 @@ sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import gen_clip
 
 def run_case(case, out, sim):
-    w, h, frames, seed, sigma, qp, extra = case
-    tag = f"{w}x{h}_f{frames}_s{seed}_n{sigma}_q{qp}_{hashlib.md5(' '.join(extra).encode()).hexdigest()[:6]}"
+    w, h, frames, seed, sigma, qp, extra = case[:7]
+    cfgname = case[7] if len(case) > 7 else 'ldb_high_efficiency.cfg'
+    tag = f"{w}x{h}_f{frames}_s{seed}_n{sigma}_q{qp}_{os.path.basename(cfgname).split('.')[0]}_{hashlib.md5(' '.join(extra).encode()).hexdigest()[:6]}"
     clip = os.path.join(out, f"clip_{w}x{h}_{frames}_{seed}_{sigma}.yuv")
     if not os.path.exists(clip):
         gen_clip.write_clip(clip + '.tmp', gen_clip.make_clip(w, h, frames, seed, sigma))
         os.replace(clip + '.tmp', clip)
-    cfg = os.path.join(ROOT, 'configs', 'ldb_high_efficiency.cfg')
+    cfg = cfgname if os.path.isabs(cfgname) else os.path.join(ROOT, 'configs', cfgname)
     args = ['-cf', cfg, '-if', clip, '-width', str(w), '-height', str(h), '-qp', str(qp), '-n', str(frames), '-f', '30'] + list(extra)
     r = subprocess.run([os.path.join(ROOT, 'oracle/_ref/Thorenc')] + args + ['-of', f'{out}/{tag}.ref.bit', '-rf', f'{out}/{tag}.ref.yuv'],
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -32,7 +33,7 @@ def run_case(case, out, sim):
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--jobs', type=int, default=8); ap.add_argument('--out', default='/tmp/pm')
-    ap.add_argument('--sim', default='/tmp/w/hostsim'); ap.add_argument('--quick', action='store_true')
+    ap.add_argument('--sim', default=os.path.join(ROOT, 'tests', 'hostsim', 'hostsim')); ap.add_argument('--quick', action='store_true')
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     cases = []
@@ -48,6 +49,19 @@ if __name__ == '__main__':
     cases.append((192, 128, 6, 25, 3, 32, ('-enable_tb_split', '0', '-enable_pb_split', '0')))
     cases.append((192, 128, 8, 26, 3, 30, ('-intra_period', '4')))
     cases.append((192, 128, 5, 27, 4, 46, ()))             # cdef_bits == 0 on P frames
+    # the other operating points: hierarchical B (+ interpolated refs), encoder_speed 1/2, CLPF
+    for cfgname in ('ra_high_efficiency.cfg', 'hdb16_high_efficiency.cfg', 'ldb_medium_complexity.cfg', 'ldb_low_complexity.cfg'):
+        nfr = 18 if cfgname.startswith(('ra', 'hdb')) else 6
+        for (w, h), qp, seed in (((192, 128), 32, 31), ((208, 120), 26, 32), ((320, 192), 38, 33)):
+            cases.append((w, h, nfr, seed, 3, qp, (), cfgname))
+    cases.append((192, 128, 6, 34, 3, 33, ('-clpf', '1'), 'ldb_high_efficiency.cfg'))     # CDEF and CLPF together
+    cases.append((192, 128, 10, 35, 3, 30, ('-interp_ref', '0'), 'ra_high_efficiency.cfg'))
+    ref_cfg = '/root/reference'
+    if os.path.isdir(ref_cfg):  # the reference's own files for the remaining (non-qm) operating points
+        for name in ('config_HDB_high_efficiency.txt', 'config_HDB_medium_complexity.txt', 'config_HDB_low_complexity.txt',
+                     'config_RA_medium_complexity.txt', 'config_RA_low_complexity.txt', 'config_RA16_high_efficiency.txt',
+                     'config_HDB16_medium_complexity.txt', 'config_HDB16_low_complexity.txt', 'config_RA16_low_complexity.txt'):
+            cases.append((192, 128, 18, 36, 3, 32, (), os.path.join(ref_cfg, name)))
     if a.quick: cases = cases[:6]
     with ThreadPoolExecutor(a.jobs) as ex:
         bad = 0

@@ -283,7 +283,13 @@ inline void write_cdef_params(HostBits& b, int pos_or_minus1, int cdef_on, const
   if (pos_or_minus1 < 0) {
     for (int i = 0; i < tmp.nbits; i++) b.put(1, (uint32_t)tmp.get(i));
   } else {
-    for (int i = 0; i < tmp.nbits; i++) b.overwrite(pos_or_minus1 + i, 1, (uint32_t)tmp.get(i));
+    // Back-patch as the reference's stream writer performs it (enc/putbits.c:130-144): write_stream_pos()
+    // back to the saved header position, rewrite, write_stream_pos() forward again.  The forward move restores
+    // the saved 32-bit accumulator of the CURRENT position, so patched bits that fall into the stream's last,
+    // not yet flushed word are lost and the originally written bits stay (visible on tiny frames).
+    const int unflushed = (b.nbits >> 5) << 5;
+    for (int i = 0; i < tmp.nbits; i++)
+      if (pos_or_minus1 + i < unflushed) b.overwrite(pos_or_minus1 + i, 1, (uint32_t)tmp.get(i));
   }
 }
 
