@@ -100,9 +100,9 @@ int thor_hip_get_recon(thor_hip_encoder* e, int stream, void* yuv_out);
  * reset; used by bench.py for the roofline figure. */
 void thor_hip_kernel_time(thor_hip_encoder* e, double* sb_ms, long* sb_launches, double* filter_ms);
 void thor_hip_kernel_time_reset(thor_hip_encoder* e);
-/* Development aid: 16 shader-cycle counters summed over all superblock wavefronts (all zero unless the
- * library was built with -DTHOR_PROF). */
-void thor_hip_read_prof(thor_hip_encoder* e, long long out[16]);
+/* Development aid: 32 shader-cycle / event counters summed over all superblock wavefronts (all zero unless
+ * the library was built with -DTHOR_PROF). */
+void thor_hip_read_prof(thor_hip_encoder* e, long long out[32]);
 
 /* ---- (3) kernel-level batch entry points (known-answer tests) ------------------------------- */
 /* SAD of `n` candidate positions: org is a compact w x h block (stride w); ref points at the

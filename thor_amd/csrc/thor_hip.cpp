@@ -644,7 +644,7 @@ void thor_hip_kernel_time(thor_hip_encoder*, double* sb_ms, long* sb_launches, d
   if (sb_launches) *sb_launches = g_clk.sb_launches;
   if (filter_ms) *filter_ms = g_clk.filt_ms;
 }
-void thor_hip_read_prof(thor_hip_encoder* e, long long out[16]) { ENC_DISPATCH(e, { backend::d2h(out, E.eng.d_prof, 16 * sizeof(long long)); }); }
+void thor_hip_read_prof(thor_hip_encoder* e, long long out[32]) { ENC_DISPATCH(e, { backend::d2h(out, E.eng.d_prof, 32 * sizeof(long long)); }); }
 void thor_hip_kernel_time_reset(thor_hip_encoder*) { g_clk.sb_ms = g_clk.filt_ms = 0; g_clk.sb_launches = 0; }
 
 }  // extern "C"

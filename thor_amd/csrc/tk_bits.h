@@ -306,8 +306,10 @@ TK_DEV void bs_coeff_any(BitSink& b, const Team* t, const int16_t* coeff, int si
   else bs_coeff(b, coeff, size, type);
 }
 
+// ybits (optional, counting mode only): bit lengths of the luma TU coefficient strings already counted by the
+// caller (partial-cost pruning), [0] for an unsplit block, [t] for TU t of a tb-split one.
 TK_DEVNI int bs_block(BitSink& b, const SynCtx& s, const BlkParam& p, const int16_t* cy, const int16_t* cu,
-                    const int16_t* cv, const Team* tm) {
+                    const int16_t* cv, const Team* tm, const int* ybits = nullptr) {
   const int start = b.pos;
   const int size = s.size, size_uv = size >> 1;
   const int mode = p.mode;
@@ -368,7 +370,7 @@ TK_DEVNI int bs_block(BitSink& b, const SynCtx& s, const BlkParam& p, const int1
     bs_vlc(b, 0, (uint32_t)code);
 
     if (tb_split == 0) {
-      if (p.cbp_y) bs_coeff_any(b, tm, cy, size, coeff_type | 0);
+      if (p.cbp_y) { if (ybits && !b.emit) b.pos += ybits[0]; else bs_coeff_any(b, tm, cy, size, coeff_type | 0); }
       if (p.cbp_u) bs_coeff_any(b, tm, cu, size_uv, coeff_type | 1);
       if (p.cbp_v) bs_coeff_any(b, tm, cv, size_uv, coeff_type | 1);
     } else if (size_uv > 4) {
@@ -377,7 +379,7 @@ TK_DEVNI int bs_block(BitSink& b, const SynCtx& s, const BlkParam& p, const int1
         int c = cbp_code(ty + (tu << 1) + (tv << 2));
         if (s.ctx_cbp == 0 && c < 2) c = 1 - c;
         bs_vlc(b, 0, (uint32_t)c);
-        if (ty) bs_coeff_any(b, tm, cy + t * sty, size / 2, coeff_type | 0);
+        if (ty) { if (ybits && !b.emit) b.pos += ybits[t]; else bs_coeff_any(b, tm, cy + t * sty, size / 2, coeff_type | 0); }
         if (tu) bs_coeff_any(b, tm, cu + t * stc, size_uv / 2, coeff_type | 1);
         if (tv) bs_coeff_any(b, tm, cv + t * stc, size_uv / 2, coeff_type | 1);
       }
@@ -385,7 +387,7 @@ TK_DEVNI int bs_block(BitSink& b, const SynCtx& s, const BlkParam& p, const int1
       for (int t = 0; t < 4; t++) {
         int ty = (p.cbp_y >> (3 - t)) & 1;
         bs_put(b, 1, (uint32_t)ty);
-        if (ty) bs_coeff_any(b, tm, cy + t * sty, size / 2, coeff_type | 0);
+        if (ty) { if (ybits && !b.emit) b.pos += ybits[t]; else bs_coeff_any(b, tm, cy + t * sty, size / 2, coeff_type | 0); }
       }
       bs_vlc(b, 13, (uint32_t)(p.cbp_u + 2 * p.cbp_v));
       if (p.cbp_u) bs_coeff_any(b, tm, cu, size_uv, coeff_type | 1);

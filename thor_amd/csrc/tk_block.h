@@ -32,7 +32,7 @@ struct Node {
 // Per-team working set.  The small, latency-critical part (transform tiles, candidate tables,
 // coefficient buffers, the recursion stack) lives in LDS on the GPU; the sample blocks (up to
 // 128x128) live in a per-team global scratch arena that stays L1/L2 resident.
-enum { kProfSlots = 16 };
+enum { kProfSlots = 32 };
 template <typename PIX> struct SmallWs {
   XformWs xf;
   MeWs me;
@@ -210,12 +210,13 @@ TK_DEV void ssd_acc(const Team& t, unsigned long long* acc, const PIX* a, int as
 
 // cost_calc (encode_block.c:916-926) on the trial recon in ws->rec_* vs. the original frame.
 template <typename PIX>
-TK_DEVNI unsigned rd_cost(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int nbits, double lambda) {
+TK_DEVNI unsigned rd_cost(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int nbits, double lambda,
+                         long long ssd_y = -1) {
   TK_PROF_T0();
-  if (t.rank == 0) ws->acc[0] = 0;
+  if (t.rank == 0) ws->acc[0] = ssd_y >= 0 ? (unsigned long long)ssd_y : 0ull;
   t.sync();
   const int yc = nd.ypos >> 1, xc = nd.xpos >> 1, sc = nd.size >> 1;
-  ssd_acc(t, &ws->acc[0], J.orig.y + nd.ypos * J.orig.sy + nd.xpos, J.orig.sy, ws->rec_y, nd.size, nd.bw, nd.bh);
+  if (ssd_y < 0) ssd_acc(t, &ws->acc[0], J.orig.y + nd.ypos * J.orig.sy + nd.xpos, J.orig.sy, ws->rec_y, nd.size, nd.bw, nd.bh);
   ssd_acc(t, &ws->acc[0], J.orig.u + yc * J.orig.sc + xc, J.orig.sc, ws->rec_u, sc, nd.bw >> 1, nd.bh >> 1);
   ssd_acc(t, &ws->acc[0], J.orig.v + yc * J.orig.sc + xc, J.orig.sc, ws->rec_v, sc, nd.bw >> 1, nd.bh >> 1);
   t.sync();
@@ -347,11 +348,61 @@ TK_DEV int code_inter_plane(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* 
   return cbp;
 }
 
+// Exact partial-cost pruning of RDO trials.  A trial only matters if its cost is below a threshold the caller
+// knows (the best cost so far; for the intra search also the best intra cost so far - strict '<' everywhere in
+// mode_decision_rdo).  cost = SSD_Y + SSD_U + SSD_V + (unsigned)(lambda * bits + 0.5) is monotone in every
+// term, so once the luma planes are coded, SSD_Y + (unsigned)(lambda * luma coefficient bits + 0.5) is a lower
+// bound of the final cost: if it already reaches the threshold the chroma transform units, CfL, the bit count
+// and the cost evaluation are skipped and the trial is reported as "not better" - results are unchanged.
+struct PruneCtx {
+  unsigned thr;       // prune when the lower bound is >= thr (0xffffffff: never)
+  double lambda;
+  long long ssd_y;    // out: luma SSD of the trial (reused by rd_cost), -1 if not computed
+  int ybits[4];       // out: luma coefficient bits per TU
+  int have_ybits;
+  int pruned;         // out
+};
+
+template <typename PIX>
+TK_DEV int prune_after_luma(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, const BlkParam& p, int cbp_y,
+                            int tb_split, PruneCtx* pc) {
+  if (!pc || pc->thr == 0xffffffffu) return 0;
+  const int size = nd.size;
+  t.sync();
+  if (t.rank == 0) ws->acc[1] = 0;
+  t.sync();
+  ssd_acc(t, &ws->acc[1], J.orig.y + nd.ypos * J.orig.sy + nd.xpos, J.orig.sy, ws->rec_y, size, nd.bw, nd.bh);
+  t.sync();
+  const unsigned long long ssd = ws->acc[1];
+  t.sync();
+  pc->ssd_y = (long long)ssd;
+  const int coeff_type = (p.mode == M_INTRA) << 1;
+  int bits = 0;
+  if (!tb_split) {
+    pc->ybits[0] = cbp_y ? coeff_bits_team(t, ws->coef_y, size, coeff_type) : 0;
+    bits = pc->ybits[0];
+  } else {
+    const int qy = size / 2 < kMaxQuant ? size / 2 : kMaxQuant;
+    for (int tu = 0; tu < 4; tu++) {
+      pc->ybits[tu] = ((cbp_y >> (3 - tu)) & 1) ? coeff_bits_team(t, ws->coef_y + tu * qy * qy, size / 2, coeff_type) : 0;
+      bits += pc->ybits[tu];
+    }
+  }
+  pc->have_ybits = 1;
+  unsigned long long lb = (ssd >> (J.cfg.bitdepth * 2 - 16)) + (unsigned long long)(long long)mul_add_nofma(pc->lambda, (double)bits, 0.5);
+  if (lb > (1ull << 30)) lb = 1ull << 30;
+#if TK_HOST
+  { extern long long g_prune_stat[8]; g_prune_stat[p.mode == M_INTRA ? 0 : 2] += 1; if (lb >= (unsigned long long)pc->thr) g_prune_stat[p.mode == M_INTRA ? 1 : 3] += 1; }
+#endif
+  if (lb >= (unsigned long long)pc->thr) { pc->pruned = 1; return 1; }
+  return 0;
+}
+
 // reuse_pred: the inter prediction of this (mode, refs, MVs) is already in ws->pred_* (previous trial
 // of the same candidate with another tb_param) - exact, the prediction does not depend on tb_param.
 template <typename PIX>
 TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BlkParam& p, BitSink& bs,
-                          int reuse_pred = 0) {
+                          int reuse_pred = 0, PruneCtx* pc = nullptr) {
   const EncCfg& c = J.cfg;
   const int size = nd.size, sizeC = size >> 1;
   const int yc = nd.ypos >> 1, xc = nd.xpos >> 1;
@@ -398,6 +449,7 @@ TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
       cbp_y = code_tu(t, ws->xfp, oy, J.orig.sy, ws->pred_y, size, ws->rec_y, size, size, qpY, ftI | 0,
                       c.encoder_speed > 1, ws->coef_y, bd);
     }
+    if (prune_after_luma(t, J, ws, nd, p, cbp_y, tb_split, pc)) return 0;
     // chroma (encode_and_reconstruct_block_intra_uv :1170-1273)
     const int csplit = tb_split && sizeC > 4;
     if (csplit) {
@@ -445,6 +497,7 @@ TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
       t.sync();
     } else {
       cbp_y = code_inter_plane(t, J, ws, oy, J.orig.sy, ws->pred_y, ws->rec_y, size, qpY, ftI | 0, tb_split, ws->coef_y);
+      if (prune_after_luma(t, J, ws, nd, p, cbp_y, tb_split, pc)) return 0;
       if (c.cfl_inter) improve_uv(t, ws, ws->pred_y, ws->pred_u, ws->pred_v, ws->rec_y, size, size, size, bd);
       const int csplit = tb_split && sizeC > 4;
       cbp_u = code_inter_plane(t, J, ws, ou, J.orig.sc, ws->pred_u, ws->rec_u, sizeC, qpC, ftI | 1, csplit, ws->coef_u);
@@ -455,7 +508,7 @@ TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
   p.cbp_u = (uint8_t)cbp_u;
   p.cbp_v = (uint8_t)cbp_v;
   TK_PROF_T0();
-  int nb_ = bs_block(bs, nd.syn, p, ws->coef_y, ws->coef_u, ws->coef_v, &t);
+  int nb_ = bs_block(bs, nd.syn, p, ws->coef_y, ws->coef_u, ws->coef_v, &t, (pc && pc->have_ybits) ? pc->ybits : nullptr);
   TK_PROF_ADD(ws, PF_BITS);
   return nb_;
 }
@@ -463,11 +516,14 @@ TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
 // One RDO trial: count bits, evaluate cost, keep `best` (copy_best_parameters, :1615-1677).
 template <typename PIX>
 TK_DEV unsigned rdo_trial(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BlkParam& p, double lambda,
-                          int reuse_pred = 0) {
+                          int reuse_pred = 0, unsigned prune_thr = 0xffffffffu) {
   BitSink cnt;
   cnt.buf = nullptr; cnt.pos = 0; cnt.cap = 0; cnt.emit = 0; cnt.ovf = 0;
-  int nbits = encode_block(t, J, ws, nd, p, cnt, reuse_pred);
-  return rd_cost(t, J, ws, nd, nbits, lambda);
+  PruneCtx pc;
+  pc.thr = prune_thr; pc.lambda = lambda; pc.ssd_y = -1; pc.have_ybits = 0; pc.pruned = 0;
+  int nbits = encode_block(t, J, ws, nd, p, cnt, reuse_pred, &pc);
+  if (pc.pruned) return kCostInit;  // lower bound >= threshold: cannot be selected
+  return rd_cost(t, J, ws, nd, nbits, lambda, pc.ssd_y);
 }
 
 TK_DEV void keep_best(Node& nd, const BlkParam& p) {
@@ -645,6 +701,7 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
   p.tb_param = 0; p.tb_split = 0; p.cbp_y = p.cbp_u = p.cbp_v = 0;
   for (int i = 0; i < 4; i++) { p.mv0[i] = mk_mv(0, 0); p.mv1[i] = mk_mv(0, 0); }
 
+  TK_PROF_MARK(pm0_);
   if (J.frame_type != F_I) {
     p.tb_param = 0;
     p.pb_part = P_NONE;
@@ -654,16 +711,20 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
       if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
     }
   }
+  TK_PROF_ACC(ws, 29, pm0_);
   if ((size < 128 || c.encoder_speed == 0) && !rect) {
     if (J.frame_type != F_I) {
+      TK_PROF_MARK(pm1_);
       for (int k = 0; k < nd.syn.num_merge; k++) {
         set_cand(p, nd.merge[k], k, M_MERGE);
         for (int tb = 0; tb <= max_tb - 1; tb++) {
           p.tb_param = (int8_t)tb;
-          unsigned cost = rdo_trial(t, J, ws, nd, p, lambda, tb > 0);
+          unsigned cost = rdo_trial(t, J, ws, nd, p, lambda, tb > 0, min_cost);
           if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
         }
       }
+      TK_PROF_ACC(ws, 29, pm1_);
+      TK_PROF_MARK(pu0_);
       // encoder_speed > 0: intra-vs-inter pre-decision by SAD (encode_block.c:1943-1947, 1990-1993)
       const int intra_inter_sad = c.encoder_speed > 0;
       unsigned sad_intra = 0xffffffffu;
@@ -710,7 +771,9 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
           const int min_tb = c.encoder_speed < 1 ? -1 : 0;
           for (int tb = min_tb; tb <= max_tb - 1; tb++) {
             p.tb_param = (int8_t)tb;
-            unsigned cost = rdo_trial(t, J, ws, nd, p, lambda, tb > min_tb);
+            // worst/best cost feed only the encoder_speed 2 reference shortcut; where that is inactive the
+            // exact costs of losing trials are never used and the trial may be pruned
+            unsigned cost = rdo_trial(t, J, ws, nd, p, lambda, tb > min_tb, (c.encoder_speed < 2 || c.enable_bipred) ? min_cost : 0xffffffffu);
             worst_cost = cost > worst_cost ? cost : worst_cost;
             best_cost = cost < best_cost ? cost : best_cost;
             if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
@@ -724,6 +787,8 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
         if (t.rank == 0) ws->mep->best_ref = 0;
         t.sync();
       }
+      TK_PROF_ACC(ws, 27, pu0_);
+      TK_PROF_MARK(pb0_);
       // bi-prediction
       if (J.num_ref > 1 && c.enable_bipred && do_inter) {
         int r0, r1;
@@ -735,7 +800,7 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
         for (int i = 0; i < 4; i++) { p.mv0[i] = a0[i]; p.mv1[i] = a1[i]; }
         for (int tb = 0; tb <= max_tb - 1; tb++) {
           p.tb_param = (int8_t)tb;
-          unsigned cost = rdo_trial(t, J, ws, nd, p, lambda, tb > 0);
+          unsigned cost = rdo_trial(t, J, ws, nd, p, lambda, tb > 0, min_cost);
           if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
         }
         if (J.frame_type == F_B && c.encoder_speed == 0) {
@@ -759,7 +824,9 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
           if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
         }
       }
+      TK_PROF_ACC(ws, 28, pb0_);
     }
+    TK_PROF_MARK(pi0_);
     // intra (encode_block.c:2070-2114).  The reference re-encodes the winning mode for both
     // tb_param values after the search; those trials are repeats of trials already made (same inputs,
     // deterministic), so their costs are taken from the search instead of being recomputed.
@@ -775,7 +842,8 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
         int improved = 0;
         for (int tb = 0; tb <= max_tb - 1; tb++) {
           p.tb_param = (int8_t)tb;
-          unsigned cost = rdo_trial(t, J, ws, nd, p, lambda);
+          // only a cost below both the best intra cost and the best overall cost can change the outcome
+          unsigned cost = rdo_trial(t, J, ws, nd, p, lambda, 0, min_intra < min_cost ? min_intra : min_cost);
           tbc[tb] = cost;
           if (cost < min_intra) { min_intra = cost; intra_mode = m; improved = 1; }
         }
@@ -796,6 +864,7 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
         if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
       }
     }
+    TK_PROF_ACC(ws, 26, pi0_);
   }
   return min_cost;
 }

@@ -351,7 +351,7 @@ template <typename PIX> class Engine {
   backend::GatherItem* d_items = nullptr;
   bool external_interp = false;  // drop-in mode: the caller uploads st[s].interp itself
   bool raw_frames = false;  // drop-in mode: no sequence header / framing; caller consumes st[s].bits
-  long long* d_prof = nullptr;  // 16 cycle counters summed over all superblocks (THOR_PROF builds)
+  long long* d_prof = nullptr;  // 32 cycle counters summed over all superblocks (THOR_PROF builds)
 
   void open(const SeqParams& p, int num_streams) {
     sp = p; S = num_streams;
@@ -405,7 +405,7 @@ template <typename PIX> class Engine {
     h_jobs.resize(S);
     d_cjobs = (CdefJob<PIX>*)backend::dev_alloc(sizeof(CdefJob<PIX>) * S);
     h_cjobs.resize(S);
-    d_prof = (long long*)backend::dev_alloc(16 * sizeof(long long));
+    d_prof = (long long*)backend::dev_alloc(32 * sizeof(long long));
   }
   size_t clpf_stat_words() const { return 4 * ((size_t)(sp.width / 8) * (sp.height / 8) + 2 * (size_t)(sp.width / 16) * (sp.height / 16)); }
   void close() {

@@ -11,9 +11,15 @@
 #if defined(THOR_PROF) && !TK_HOST
 #define TK_PROF_T0() long long pt0_ = (long long)__builtin_readcyclecounter()
 #define TK_PROF_ADD(ws, id) do { if (t.rank == 0) (ws)->prof[id] += (long long)__builtin_readcyclecounter() - pt0_; } while (0)
+#define TK_PROF_MARK(v) long long v = (long long)__builtin_readcyclecounter()
+#define TK_PROF_ACC(ws, id, v) do { if (t.rank == 0) (ws)->prof[id] += (long long)__builtin_readcyclecounter() - (v); } while (0)
+#define TK_PROF_CNT(ws, id) do { if (t.rank == 0) (ws)->prof[id] += 1; } while (0)
 #else
 #define TK_PROF_T0() do {} while (0)
 #define TK_PROF_ADD(ws, id) do {} while (0)
+#define TK_PROF_MARK(v) do {} while (0)
+#define TK_PROF_ACC(ws, id, v) do {} while (0)
+#define TK_PROF_CNT(ws, id) do {} while (0)
 #endif
 #endif
 
@@ -263,21 +269,21 @@ TK_DEVNI int code_tu(const Team& t, XformWs* ws, const PIX* org, int ostride, co
                    int rstride, int size, int qp, int coeff_type, int fast, int16_t* coefq, int bitdepth) {
   TK_PROF_T0();
   fwd_transform(t, ws, org, ostride, pred, pstride, size, fast, bitdepth);
-  long long pq0_ = 0; (void)pq0_;
-#if defined(THOR_PROF) && !TK_HOST
-  pq0_ = (long long)__builtin_readcyclecounter();
-#endif
+  TK_PROF_ADD(ws, 30);
+  TK_PROF_MARK(pq0_);
   int cbp = quantize_team(t, ws, coefq, qp, size, (coeff_type >> 1) & 1);
-#if defined(THOR_PROF) && !TK_HOST
-  if (t.rank == 0) ws->prof[12] += (long long)__builtin_readcyclecounter() - pq0_;
-#endif
+  TK_PROF_ACC(ws, 12, pq0_);
   if (cbp) {
+    TK_PROF_MARK(pi0_);
     dequantize(t, ws, coefq, qp, size);
     inv_transform_recon(t, ws, pred, pstride, rec, rstride, size, bitdepth);
+    TK_PROF_ACC(ws, 31, pi0_);
   } else {
     copy_block(t, rec, rstride, pred, pstride, size, size);
     t.sync();
   }
+  TK_PROF_ADD(ws, (size <= 4 ? 16 : size == 8 ? 17 : size == 16 ? 18 : size == 32 ? 19 : 20));
+  TK_PROF_CNT(ws, (size <= 4 ? 21 : size == 8 ? 22 : size == 16 ? 23 : size == 32 ? 24 : 25));
   TK_PROF_ADD(ws, 6);
   return cbp;
 }
