@@ -326,28 +326,6 @@ TK_DEV void predict_inter(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
   TK_PROF_ADD(ws, PF_PRED_INTER);
 }
 
-// residual coding of one plane of an inter block (encode_and_reconstruct_block_inter :1275-1338)
-template <typename PIX>
-TK_DEV int code_inter_plane(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const PIX* org, int ostride,
-                            const PIX* pred, PIX* rec, int size, int qp, int coeff_type, int tb_split, int16_t* coef) {
-  const int bd = J.cfg.bitdepth;
-  if (!tb_split) {
-    int fast = (size == 64 && J.cfg.encoder_speed > 0) || J.cfg.encoder_speed > 1;
-    return code_tu(t, ws->xfp, org, ostride, pred, size, rec, size, size, qp, coeff_type, fast, coef, bd);
-  }
-  const int s2 = size / 2;
-  int cbp = 0, index = 0;
-  for (int i = 0; i < size; i += s2)
-    for (int j = 0; j < size; j += s2) {
-      int fast = size == 64 || J.cfg.encoder_speed > 1;
-      int bit = code_tu(t, ws->xfp, org + i * ostride + j, ostride, pred + i * size + j, size, rec + i * size + j, size,
-                        s2, qp, coeff_type, fast, coef + index, bd);
-      cbp = (cbp << 1) + bit;
-      index += tmin(s2, 16) * tmin(s2, 16);
-    }
-  return cbp;
-}
-
 // Exact partial-cost pruning of RDO trials.  A trial only matters if its cost is below a threshold the caller
 // knows (the best cost so far; for the intra search also the best intra cost so far - strict '<' everywhere in
 // mode_decision_rdo).  cost = SSD_Y + SSD_U + SSD_V + (unsigned)(lambda * bits + 0.5) is monotone in every
@@ -361,12 +339,41 @@ struct PruneCtx {
   int ybits[4];       // out: luma coefficient bits per TU
   int have_ybits;
   int pruned;         // out
+  long long ssd_part; // tb-split luma: SSD / bits of the quadrants coded so far
+  int bits_part;
 };
+
+// tb-split luma: call after quadrant `tu` (0..3, size s2 at (i,j) of the block) has been coded.  The first three
+// quadrants give an early lower bound; after the fourth the accumulated values are the block's luma SSD / bits.
+template <typename PIX>
+TK_DEV int prune_after_quadrant(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int intra, int tu, int i, int j,
+                                int s2, int bit, const int16_t* coef, PruneCtx* pc) {
+  if (!pc || pc->thr == 0xffffffffu) return 0;
+  t.sync();
+  if (t.rank == 0) ws->acc[1] = 0;
+  t.sync();
+  ssd_acc(t, &ws->acc[1], J.orig.y + (nd.ypos + i) * J.orig.sy + nd.xpos + j, J.orig.sy, ws->rec_y + i * nd.size + j, nd.size, s2, s2);
+  t.sync();
+  pc->ssd_part += (long long)ws->acc[1];
+  t.sync();
+  pc->ybits[tu] = bit ? coeff_bits_team(t, coef, s2, intra << 1) : 0;
+  pc->bits_part += pc->ybits[tu];
+  if (tu == 3) { pc->ssd_y = pc->ssd_part; pc->have_ybits = 1; }
+  unsigned long long lb = ((unsigned long long)pc->ssd_part >> (J.cfg.bitdepth * 2 - 16)) + (unsigned long long)(long long)mul_add_nofma(pc->lambda, (double)pc->bits_part, 0.5);
+  if (lb > (1ull << 30)) lb = 1ull << 30;
+#if TK_HOST
+  { extern long long g_prune_stat[8]; g_prune_stat[4] += 1; if (lb >= (unsigned long long)pc->thr) g_prune_stat[5 + (tu == 3)] += 1; }
+#endif
+  if (lb >= (unsigned long long)pc->thr) { pc->pruned = 1; return 1; }
+  return 0;
+}
 
 template <typename PIX>
 TK_DEV int prune_after_luma(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, const BlkParam& p, int cbp_y,
                             int tb_split, PruneCtx* pc) {
   if (!pc || pc->thr == 0xffffffffu) return 0;
+  if (pc->pruned) return 1;
+  if (pc->have_ybits) return 0;  // tb-split luma: bound already evaluated quadrant by quadrant
   const int size = nd.size;
   t.sync();
   if (t.rank == 0) ws->acc[1] = 0;
@@ -396,6 +403,30 @@ TK_DEV int prune_after_luma(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* 
 #endif
   if (lb >= (unsigned long long)pc->thr) { pc->pruned = 1; return 1; }
   return 0;
+}
+
+// residual coding of one plane of an inter block (encode_and_reconstruct_block_inter :1275-1338)
+template <typename PIX>
+TK_DEV int code_inter_plane(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const PIX* org, int ostride,
+                            const PIX* pred, PIX* rec, int size, int qp, int coeff_type, int tb_split, int16_t* coef,
+                            const Node* nd = nullptr, PruneCtx* pc = nullptr) {
+  const int bd = J.cfg.bitdepth;
+  if (!tb_split) {
+    int fast = (size == 64 && J.cfg.encoder_speed > 0) || J.cfg.encoder_speed > 1;
+    return code_tu(t, ws->xfp, org, ostride, pred, size, rec, size, size, qp, coeff_type, fast, coef, bd);
+  }
+  const int s2 = size / 2;
+  int cbp = 0, index = 0;
+  for (int i = 0; i < size; i += s2)
+    for (int j = 0; j < size; j += s2) {
+      int fast = size == 64 || J.cfg.encoder_speed > 1;
+      int bit = code_tu(t, ws->xfp, org + i * ostride + j, ostride, pred + i * size + j, size, rec + i * size + j, size,
+                        s2, qp, coeff_type, fast, coef + index, bd);
+      cbp = (cbp << 1) + bit;
+      if (nd && prune_after_quadrant(t, J, ws, *nd, 0, (i ? 2 : 0) + (j ? 1 : 0), i, j, s2, bit, coef + index, pc)) return cbp;
+      index += tmin(s2, 16) * tmin(s2, 16);
+    }
+  return cbp;
 }
 
 // reuse_pred: the inter prediction of this (mode, refs, MVs) is already in ws->pred_* (previous trial
@@ -440,6 +471,7 @@ TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
           int bit = code_tu(t, ws->xfp, oy + i * J.orig.sy + j, J.orig.sy, ws->pred_y + i * size + j, size,
                             ws->rec_y + i * size + j, size, s2, qpY, ftI | 0, c.encoder_speed > 1, ws->coef_y + index, bd);
           cbp_y = (cbp_y << 1) + bit;
+          if (prune_after_quadrant(t, J, ws, nd, 1, (i ? 2 : 0) + (j ? 1 : 0), i, j, s2, bit, ws->coef_y + index, pc)) return 0;
           index += tmin(s2, 16) * tmin(s2, 16);
         }
     } else {
@@ -496,7 +528,7 @@ TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
       copy_block(t, ws->rec_v, sizeC, ws->pred_v, sizeC, nd.bw >> 1, nd.bh >> 1);
       t.sync();
     } else {
-      cbp_y = code_inter_plane(t, J, ws, oy, J.orig.sy, ws->pred_y, ws->rec_y, size, qpY, ftI | 0, tb_split, ws->coef_y);
+      cbp_y = code_inter_plane(t, J, ws, oy, J.orig.sy, ws->pred_y, ws->rec_y, size, qpY, ftI | 0, tb_split, ws->coef_y, &nd, pc);
       if (prune_after_luma(t, J, ws, nd, p, cbp_y, tb_split, pc)) return 0;
       if (c.cfl_inter) improve_uv(t, ws, ws->pred_y, ws->pred_u, ws->pred_v, ws->rec_y, size, size, size, bd);
       const int csplit = tb_split && sizeC > 4;
@@ -520,7 +552,7 @@ TK_DEV unsigned rdo_trial(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
   BitSink cnt;
   cnt.buf = nullptr; cnt.pos = 0; cnt.cap = 0; cnt.emit = 0; cnt.ovf = 0;
   PruneCtx pc;
-  pc.thr = prune_thr; pc.lambda = lambda; pc.ssd_y = -1; pc.have_ybits = 0; pc.pruned = 0;
+  pc.thr = prune_thr; pc.lambda = lambda; pc.ssd_y = -1; pc.have_ybits = 0; pc.pruned = 0; pc.ssd_part = 0; pc.bits_part = 0;
   int nbits = encode_block(t, J, ws, nd, p, cnt, reuse_pred, &pc);
   if (pc.pruned) return kCostInit;  // lower bound >= threshold: cannot be selected
   return rd_cost(t, J, ws, nd, nbits, lambda, pc.ssd_y);

@@ -148,6 +148,19 @@ TK_DEV double mul_add_nofma(double a, double b, double c) {
 #endif
 }
 
+// On the device the per-team small state (transform workspace, intra edges, ...) always lives in LDS (SmallWs /
+// the KAT kernels' __shared__ copies).  The engine passes it around as generic pointers, for which the compiler emits flat_load/flat_store with
+// 64-bit address arithmetic and a full s_waitcnt per access; the hot loops below therefore re-type the
+// pointer as an LDS (address space 3) pointer: ds_read/ds_write with 32-bit addressing and immediate
+// offsets, several loads in flight.  On the host simulation the qualifier is empty.
+#if TK_HOST
+#define TK_LDS
+#else
+#define TK_LDS __attribute__((address_space(3)))
+#endif
+typedef TK_LDS int16_t lds_i16;
+#define TK_LDS_PTR(p) ((lds_i16*)(p))
+
 template <typename T> TK_DEV T tmin(T a, T b) { return a < b ? a : b; }
 template <typename T> TK_DEV T tmax(T a, T b) { return a > b ? a : b; }
 TK_DEV int iabs(int a) { return a < 0 ? -a : a; }

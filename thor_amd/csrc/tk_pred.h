@@ -224,8 +224,8 @@ TK_DEV void make_edges(const Team& t, IntraEdge<PIX>* e, const PIX* rec_frame, i
       int kk = k < leftlen ? k : leftlen - 1;
       lv = left_from_block ? rblock[kk * rbstride - 1] : rec_frame[(i + kk) * fstride - 1];
     }
-    e->top[k] = tv;
-    e->left[k] = lv;
+    ((TK_LDS PIX*)e->top)[k] = tv;
+    ((TK_LDS PIX*)e->left)[k] = lv;
   }
   if (t.rank == 0) {
     PIX tl;
@@ -256,13 +256,14 @@ template <typename PIX> TK_DEV int f5(const PIX* a, int k, int size) {
 template <typename PIX>
 TK_DEV void pred_intra(const Team& t, const IntraEdge<PIX>* e, int ypos, int xpos, int size, PIX* dst, int dstride,
                        int mode, int bitdepth) {
-  const PIX* left = e->left;
-  const PIX* top = e->top;
+  typedef TK_LDS PIX lpix;  // the edge arrays live in LDS on the device (see tk_common.h)
+  const lpix* left = (const lpix*)e->left;
+  const lpix* top = (const lpix*)e->top;
   const int tl = e->top_left;
   int dc = 0, tlF = 0, tlP = 0;
   if (mode == 0 || mode > 9) {
-    const PIX* a = xpos != 0 ? left : top;
-    const PIX* b = ypos != 0 ? top : left;
+    const lpix* a = xpos != 0 ? left : top;
+    const lpix* b = ypos != 0 ? top : left;
     unsigned sum = 0;
     for (int k = 0; k < size; k++) sum += (unsigned)a[k] + (unsigned)b[k];
     dc = (int)((sum + (unsigned)size) / (2u * (unsigned)size));

@@ -61,6 +61,7 @@ TK_DEV void fwd_transform(const Team& t, XformWs* ws, const PIX* org, int ostrid
     scale = size / size1;
   }
   // residual (+ optional saturating box sum, transform.c:262-277)
+  lds_i16* const in_l = TK_LDS_PTR(ws->in);
   for (int k = t.rank; k < size1 * size1; k += t.size) {
     int i, j;
     split2(mk_div(size1), k, i, j);
@@ -75,7 +76,7 @@ TK_DEV void fwd_transform(const Team& t, XformWs* ws, const PIX* org, int ostrid
           sum = clampi((int16_t)sum + r, -16384, 16383);
         }
     }
-    ws->in[j * size1 + i] = (int16_t)sum;  // transposed store: conflict-free column reads in stage 1
+    in_l[j * size1 + i] = (int16_t)sum;  // transposed store: conflict-free column reads in stage 1
   }
   t.sync();
   fwd_core(t, ws, size1, qsize, ilog2(size) + ilog2(scale) + bitdepth - 8);
@@ -90,20 +91,37 @@ TK_DEV void fwd_core(const Team& t, XformWs* ws, int size1, int qsize, int shift
   const int add_1 = 1 << (shift_1 - 1);
   const int shift_2 = ilog2(size1) + 5;
   const int add_2 = 1 << (shift_2 - 1);
+  const lds_i16* const in = TK_LDS_PTR(ws->in);
+  const lds_i16* const dct = TK_LDS_PTR(ws->dct32);
+  lds_i16* const tmp = TK_LDS_PTR(ws->tmp);
+  lds_i16* const coef = TK_LDS_PTR(ws->coef);
+  const Div2 d1 = mk_div(size1), dq = mk_div(qsize);
   for (int k = t.rank; k < qsize * size1; k += t.size) {
     int i, j;
-    split2(mk_div(size1), k, i, j);  // row j fastest: M[i][q] is a broadcast, in[q][j] consecutive
+    split2(d1, k, i, j);  // row j fastest: M[i][q] is a broadcast, in[q][j] consecutive
+    const lds_i16* M = dct + ((i << rs) << 5);
+    const lds_i16* col = in + j;
     int sum = 0;
-    for (int q = 0; q < size1; q++) sum += dct_at(ws, rs, i, q) * ws->in[q * size1 + j];
-    ws->tmp[j * qsize + i] = (int16_t)((sum + add_1) >> shift_1);
+    for (int q = 0; q < size1; q += 4) {  // size1 is 4, 8, 16 or 32; all eight loads issue before the first use
+      const int m0 = M[q], m1 = M[q + 1], m2 = M[q + 2], m3 = M[q + 3];
+      const int a0 = col[q * size1], a1 = col[(q + 1) * size1], a2 = col[(q + 2) * size1], a3 = col[(q + 3) * size1];
+      sum += m0 * a0 + m1 * a1 + m2 * a2 + m3 * a3;
+    }
+    tmp[j * qsize + i] = (int16_t)((sum + add_1) >> shift_1);
   }
   t.sync();
   for (int k = t.rank; k < qsize * qsize; k += t.size) {
     int i, j;
-    split2(mk_div(qsize), k, i, j);
+    split2(dq, k, i, j);
+    const lds_i16* M = dct + ((i << rs) << 5);
+    const lds_i16* col = tmp + j;
     int sum = 0;
-    for (int q = 0; q < size1; q++) sum += dct_at(ws, rs, i, q) * ws->tmp[q * qsize + j];
-    ws->coef[i * qsize + j] = (int16_t)((sum + add_2) >> shift_2);
+    for (int q = 0; q < size1; q += 4) {
+      const int m0 = M[q], m1 = M[q + 1], m2 = M[q + 2], m3 = M[q + 3];
+      const int a0 = col[q * qsize], a1 = col[(q + 1) * qsize], a2 = col[(q + 2) * qsize], a3 = col[(q + 3) * qsize];
+      sum += m0 * a0 + m1 * a1 + m2 * a2 + m3 * a3;
+    }
+    coef[i * qsize + j] = (int16_t)((sum + add_2) >> shift_2);
   }
   t.sync();
 }
@@ -166,13 +184,14 @@ TK_DEV int quantize_team(const Team& t, XformWs* ws, int16_t* coefq, int qp, int
   const int off0 = (intra_block ? 102 : 51) << (shift2 - 8);
   const int off1 = (intra_block ? 115 : 90) << (shift2 - 8);
   const int W = t.size;
+  const lds_i16* const coef = TK_LDS_PTR(ws->coef);
   // last_pos: highest position whose level under the "last position" offset is non-zero
   int last_pos = -1;
   for (int base = 0; base < N; base += W) {
     const int p = base + t.rank;
     int nz = 0;
     if (p < N) {
-      int l = iabs((int)ws->coef[izz[p]]) * scale + offl;
+      int l = iabs((int)coef[izz[p]]) * scale + offl;
       nz = ((l > 0 ? l : -l) >> shift2) != 0;
     }
     const unsigned long long m = team_ballot(t, nz);
@@ -184,7 +203,7 @@ TK_DEV int quantize_team(const Team& t, XformWs* ws, int16_t* coefq, int qp, int
     const int active = p < N && p <= last_pos;
     int c = 0, lev0 = 0, lev1 = 0;
     if (active) {
-      c = ws->coef[izz[p]];
+      c = coef[izz[p]];
       const int ac = scale * iabs(c);
       const int level0 = ac >> shift2;
       lev1 = (ac + (level0 > 0 ? off1 : off0)) >> shift2;   // level_mode == 1
@@ -209,12 +228,13 @@ TK_DEV void dequantize(const Team& t, XformWs* ws, const int16_t* coefq, int qp,
   const int qsize = size < kMaxQuant ? size : kMaxQuant;
   const int lshift = qp / 6, rshift = ilog2(size) - 1;
   const int64_t scale = dequant_scale(qp % 6);
+  lds_i16* const rcoef = TK_LDS_PTR(ws->coef);
   for (int k = t.rank; k < qsize * qsize; k += t.size) {
     int64_t c = coefq[k];
     int16_t r;
     if (lshift >= rshift) r = (int16_t)((c * scale) << (lshift - rshift));
     else r = (int16_t)((c * scale + ((int64_t)1 << (rshift - lshift - 1))) >> (rshift - lshift));
-    ws->coef[k] = r;  // rcoef aliases coef (the forward coefficients are dead after quantisation)
+    rcoef[k] = r;  // rcoef aliases coef (the forward coefficients are dead after quantisation)
   }
   t.sync();
 }
@@ -227,22 +247,38 @@ TK_DEV void inv_transform_recon(const Team& t, XformWs* ws, const PIX* pred, int
   const int scale = size / n;
   const int qsize = n < kMaxQuant ? n : kMaxQuant;
   const int rs = 5 - ilog2((unsigned)n);
-  int16_t* itmp = ws->in;  // aliases `in`
+  lds_i16* const itmp = TK_LDS_PTR(ws->in);  // aliases `in`
+  const lds_i16* const dct = TK_LDS_PTR(ws->dct32);
+  const lds_i16* const rcoef = TK_LDS_PTR(ws->coef);
   const int shift_2 = 20 - bitdepth, add_2 = 1 << (shift_2 - 1);
+  const int mstride = (1 << rs) << 5;  // basis row pitch in the 32-point table
+  const Div2 dn = mk_div(n);
   // stage 1: itmp[i*n + j] = clip((sum_k M[k][j]*rcoef[k][i] + 64) >> 7)   i < qsize, j < n
   for (int k = t.rank; k < qsize * n; k += t.size) {
     int i, j;
-    split2(mk_div(n), k, i, j);
+    split2(dn, k, i, j);
+    const lds_i16* M = dct + j;
+    const lds_i16* col = rcoef + i;
     int sum = 0;
-    for (int q = 0; q < qsize; q++) sum += dct_at(ws, rs, q, j) * ws->coef[q * qsize + i];
+    for (int q = 0; q < qsize; q += 4) {  // qsize is 4, 8 or 16
+      const int m0 = M[q * mstride], m1 = M[(q + 1) * mstride], m2 = M[(q + 2) * mstride], m3 = M[(q + 3) * mstride];
+      const int a0 = col[q * qsize], a1 = col[(q + 1) * qsize], a2 = col[(q + 2) * qsize], a3 = col[(q + 3) * qsize];
+      sum += m0 * a0 + m1 * a1 + m2 * a2 + m3 * a3;
+    }
     itmp[i * n + j] = (int16_t)clampi((sum + 64) >> 7, -32768, 32767);
   }
   t.sync();
   for (int k = t.rank; k < n * n; k += t.size) {
     int i, j;
-    split2(mk_div(n), k, i, j);
+    split2(dn, k, i, j);
+    const lds_i16* M = dct + j;
+    const lds_i16* col = itmp + i;
     int sum = 0;
-    for (int q = 0; q < qsize; q++) sum += dct_at(ws, rs, q, j) * itmp[q * n + i];
+    for (int q = 0; q < qsize; q += 4) {
+      const int m0 = M[q * mstride], m1 = M[(q + 1) * mstride], m2 = M[(q + 2) * mstride], m3 = M[(q + 3) * mstride];
+      const int a0 = col[q * n], a1 = col[(q + 1) * n], a2 = col[(q + 2) * n], a3 = col[(q + 3) * n];
+      sum += m0 * a0 + m1 * a1 + m2 * a2 + m3 * a3;
+    }
     int r = clampi((sum + add_2) >> shift_2, -32768, 32767);
     for (int m = 0; m < scale; m++)
       for (int x = 0; x < scale; x++) {
