@@ -91,7 +91,7 @@ template <typename PIX> __global__ __launch_bounds__(64, 3) void k_superblocks(c
   const unsigned total = (unsigned)A.S * (unsigned)A.nsb;
   TeamWs<PIX> wsv = make_ws(&sws, (BigWs<PIX>*)(A.pool + (size_t)blockIdx.x * A.slot_bytes));
   TeamWs<PIX>* ws = &wsv;
-  Team t{(int)threadIdx.x, 64};
+  Team t{(int)threadIdx.x, 64, sws.xf.izz};  // scan tables: filled by process_sb (xform_tables_init)
   for (;;) {
     __syncthreads();
     unsigned long long tpop = 0;
@@ -815,7 +815,7 @@ __global__ __launch_bounds__(64) void k_kat_tu(const uint8_t* org, const uint8_t
                                               int16_t* coefq, uint8_t* rec, int* cbp) {
   __shared__ XformWs xf;
   __shared__ int16_t cq[256];
-  Team t{(int)threadIdx.x, 64};
+  Team t{(int)threadIdx.x, 64, xf.izz};
   xf.prof = nullptr;
   xform_tables_init(t, &xf);
   const int i = blockIdx.x, qs = size < 16 ? size : 16;

@@ -172,7 +172,7 @@ struct BlkParam {  // block_param_t without the coefficient arrays (common/types
 TK_DEV int coeff_bits_team(const Team& t, const int16_t* coeff, int size, int type) {
   const int qsize = size < kMaxQuant ? size : kMaxQuant;
   const int N = qsize * qsize;
-  const int16_t* izz = qsize == 4 ? TK_TAB.izz4 : (qsize == 8 ? TK_TAB.izz8 : TK_TAB.izz16);
+  const IzzRef izzr = izz_ref(t, qsize);
   const int chroma = type & 1, intra = (type >> 1) & 1;
   const uint32_t eob_pos = chroma ? 0u : 2u;
   const int runtab = (chroma && size <= 8) ? 10 : 6;
@@ -180,13 +180,13 @@ TK_DEV int coeff_bits_team(const Team& t, const int16_t* coeff, int size, int ty
   int last = 0;
   for (int base = 0; base < N; base += W) {
     const int p = base + t.rank;
-    const unsigned long long m = team_ballot(t, p < N && coeff[izz[p]] != 0);
+    const unsigned long long m = team_ballot(t, p < N && coeff[izzr.z[p]] != 0);
     if (m) last = base + top_set(m);
   }
   int bits = 0;  // per-lane partial, reduced at the end
   int head = 0;  // uniform part
   if (chroma) {
-    const int c0 = coeff[izz[0]];
+    const int c0 = coeff[izzr.z[0]];
     if (last == 0 && iabs(c0) == 1) return 2;
     head = 1;
   }
@@ -197,7 +197,7 @@ TK_DEV int coeff_bits_team(const Team& t, const int16_t* coeff, int size, int ty
   for (int base = 0; base <= last; base += W) {
     const int p = base + t.rank;
     const int active = p <= last;
-    const int c = active ? (int)coeff[izz[p]] : 0;
+    const int c = active ? (int)coeff[izzr.z[p]] : 0;
     const int a = iabs(c);
     const unsigned long long mK = team_ballot(t, active && a != 1), mBig = team_ballot(t, active && a > 1);
     const int j = prev_set(mK, t.rank);

@@ -42,6 +42,10 @@ namespace tk {
 struct Team {
   int rank;
   int size;
+  // team-local copy of the scan-order tables (scan index -> position): [0,16) 4x4, [16,80) 8x8, [80,336) 16x16.
+  // On the device it points into LDS (XformWs::izz) so the per-coefficient lookups of quantisation and bit
+  // counting do not take a global-memory round trip each; unused (nullptr) on the host simulation.
+  const int16_t* izz = nullptr;
 #if TK_HOST
   inline void sync() const {}
 #else
@@ -161,6 +165,14 @@ TK_DEV double mul_add_nofma(double a, double b, double c) {
 typedef TK_LDS int16_t lds_i16;
 #define TK_LDS_PTR(p) ((lds_i16*)(p))
 
+// scan index -> coefficient position for a qsize x qsize block (qsize 4, 8 or 16)
+struct IzzRef {
+#if TK_HOST
+  const int16_t* z;
+#else
+  const lds_i16* z;
+#endif
+};
 template <typename T> TK_DEV T tmin(T a, T b) { return a < b ? a : b; }
 template <typename T> TK_DEV T tmax(T a, T b) { return a > b ? a : b; }
 TK_DEV int iabs(int a) { return a < 0 ? -a : a; }
@@ -246,6 +258,18 @@ extern Tables g_tab;
 extern __device__ Tables g_tab;
 #define TK_TAB (tk::g_tab)
 #endif
+
+TK_DEV IzzRef izz_ref(const Team& t, int qsize) {
+  IzzRef r;
+#if TK_HOST
+  (void)t;
+  r.z = qsize == 4 ? TK_TAB.izz4 : (qsize == 8 ? TK_TAB.izz8 : TK_TAB.izz16);
+#else
+  r.z = TK_LDS_PTR(t.izz) + (qsize == 4 ? 0 : (qsize == 8 ? 16 : 80));
+#endif
+  return r;
+}
+
 
 // quant / dequant scales (common_tables.c:74-75)
 TK_DEV int quant_scale(int r) {

@@ -60,6 +60,36 @@ TK_DEV SubPel luma_setup(mv_t mv, int sign, int width, int height, int pic_w, in
   return s;
 }
 
+// Six consecutive samples starting at p (any alignment) with wide loads.  Reads up to 2 samples past the
+// sixth: always inside the padded reference planes (160-sample borders + 64 samples of slack at the end).
+template <typename PIX> TK_DEV void load6(const PIX* p, int r[6]) {
+  if (sizeof(PIX) == 1) {
+    unsigned long long v;
+    __builtin_memcpy(&v, p, 8);
+    for (int m = 0; m < 6; m++) r[m] = (int)((v >> (8 * m)) & 0xffu);
+  } else {
+    unsigned long long v0;
+    unsigned v1;
+    __builtin_memcpy(&v0, p, 8);
+    __builtin_memcpy(&v1, (const char*)p + 8, 4);
+    for (int m = 0; m < 4; m++) r[m] = (int)((v0 >> (16 * m)) & 0xffffu);
+    r[4] = (int)(v1 & 0xffffu);
+    r[5] = (int)(v1 >> 16);
+  }
+}
+
+template <typename PIX> TK_DEV void load4(const PIX* p, int r[4]) {
+  if (sizeof(PIX) == 1) {
+    unsigned v;
+    __builtin_memcpy(&v, p, 4);
+    for (int m = 0; m < 4; m++) r[m] = (int)((v >> (8 * m)) & 0xffu);
+  } else {
+    unsigned long long v;
+    __builtin_memcpy(&v, p, 8);
+    for (int m = 0; m < 4; m++) r[m] = (int)((v >> (16 * m)) & 0xffffu);
+  }
+}
+
 // One luma prediction sample at (i=row, j=col) of a PU whose reference pointer (at integer
 // displacement 0) is `ref`.
 template <typename PIX>
@@ -67,8 +97,9 @@ TK_DEV int luma_sample(const PIX* ref, int stride, int i, int j, const SubPel& s
   const PIX* p = ref + (i + s.ver_int) * stride + (j + s.hor_int);
   if (s.ver_frac == 0 && s.hor_frac == 0) return p[0];
   if (s.ver_frac == 2 && s.hor_frac == 2 && bipred < 2) {
-    int sum = p[-stride] + p[-stride + 1] + p[-1] + 2 * p[0] + 2 * p[1] + p[2] + p[stride - 1] + 2 * p[stride] +
-              2 * p[stride + 1] + p[stride + 2] + p[2 * stride] + p[2 * stride + 1];
+    int a[4], b[4], c[4], d[4];  // rows -1 .. 2, columns -1 .. 2
+    load4(p - stride - 1, a); load4(p - 1, b); load4(p + stride - 1, c); load4(p + 2 * stride - 1, d);
+    int sum = a[1] + a[2] + b[0] + 2 * b[1] + 2 * b[2] + b[3] + c[0] + 2 * c[1] + 2 * c[2] + c[3] + d[1] + d[2];
     return sat_pix((sum + 8) >> 4, bitdepth);
   }
   if (s.hor_frac == 0) {
@@ -77,14 +108,20 @@ TK_DEV int luma_sample(const PIX* ref, int stride, int i, int j, const SubPel& s
     return sat_pix((sum * 64 + 2048) >> 12, bitdepth);
   }
   if (s.ver_frac == 0) {
+    int r[6];
+    load6(p - 2, r);
     int sum = 0;
-    for (int m = 0; m < 6; m++) sum += s.th[m] * p[m - 2];
+    for (int m = 0; m < 6; m++) sum += s.th[m] * r[m];
     return sat_pix((sum * 64 + 2048) >> 12, bitdepth);
   }
+  // 2-D: six rows of six samples; each row is fetched with one (u8) or two (u16) wide loads instead of six
+  // narrow ones, and all rows are in flight before the first multiply
+  int r[6][6];
+  for (int m = 0; m < 6; m++) load6(p + (m - 2) * stride - 2, r[m]);
   int sum = 0;
   for (int n = 0; n < 6; n++) {
     int col = 0;
-    for (int m = 0; m < 6; m++) col += s.tv[m] * p[(m - 2) * stride + (n - 2)];
+    for (int m = 0; m < 6; m++) col += s.tv[m] * r[m][n];
     sum += s.th[n] * col;
   }
   return sat_pix((sum + 2048) >> 12, bitdepth);

@@ -37,14 +37,15 @@ struct XformWs {
   // team-local copy of the 32-point DCT basis (LDS on the GPU); the N-point basis is its rows
   // 0, 32/N, 2*32/N, ... restricted to the first N columns (HEVC nesting property).
   int16_t dct32[1024];
+  int16_t izz[336];       // scan tables 4x4 | 8x8 | 16x16 (Team::izz points here)
 };
 
 // entry (i, q) of the N-point basis, log2(32/N) = rs
 TK_DEV int dct_at(const XformWs* ws, int rs, int i, int q) { return ws->dct32[((i << rs) << 5) + q]; }
-TK_DEV const int16_t* izz_table(const XformWs*, int qsize) { return qsize == 4 ? TK_TAB.izz4 : (qsize == 8 ? TK_TAB.izz8 : TK_TAB.izz16); }
 // Fill the team-local table (call once per team before any transform).
 TK_DEV void xform_tables_init(const Team& t, XformWs* ws) {
   for (int k = t.rank; k < 1024; k += t.size) ws->dct32[k] = TK_TAB.dct32[k];
+  for (int k = t.rank; k < 336; k += t.size) ws->izz[k] = k < 16 ? TK_TAB.izz4[k] : (k < 80 ? TK_TAB.izz8[k - 16] : TK_TAB.izz16[k - 80]);
   t.sync();
 }
 
@@ -177,7 +178,7 @@ TK_DEV int quantize_serial(const int16_t* coef, int16_t* coefq, int qp, int size
 TK_DEV int quantize_team(const Team& t, XformWs* ws, int16_t* coefq, int qp, int size, int intra_block) {
   const int qsize = size < kMaxQuant ? size : kMaxQuant;
   const int N = qsize * qsize;
-  const int16_t* izz = izz_table(ws, qsize);
+  const IzzRef izzr = izz_ref(t, qsize);
   const int scale = quant_scale(qp % 6);
   const int shift2 = 21 - ilog2(size) + qp / 6;
   const int offl = intra_block ? (38 << (shift2 - 8)) : -(26 << (shift2 - 8));
@@ -191,7 +192,7 @@ TK_DEV int quantize_team(const Team& t, XformWs* ws, int16_t* coefq, int qp, int
     const int p = base + t.rank;
     int nz = 0;
     if (p < N) {
-      int l = iabs((int)coef[izz[p]]) * scale + offl;
+      int l = iabs((int)coef[izzr.z[p]]) * scale + offl;
       nz = ((l > 0 ? l : -l) >> shift2) != 0;
     }
     const unsigned long long m = team_ballot(t, nz);
@@ -203,7 +204,7 @@ TK_DEV int quantize_team(const Team& t, XformWs* ws, int16_t* coefq, int qp, int
     const int active = p < N && p <= last_pos;
     int c = 0, lev0 = 0, lev1 = 0;
     if (active) {
-      c = coef[izz[p]];
+      c = coef[izzr.z[p]];
       const int ac = scale * iabs(c);
       const int level0 = ac >> shift2;
       lev1 = (ac + (level0 > 0 ? off1 : off0)) >> shift2;   // level_mode == 1
@@ -214,7 +215,7 @@ TK_DEV int quantize_team(const Team& t, XformWs* ws, int16_t* coefq, int qp, int
     const int j = prev_set(mK, t.rank);
     const int mode = j < 0 ? carry : (int)((mV >> j) & 1ull);
     const int lev = mode ? lev1 : lev0;
-    if (p < N) coefq[izz[p]] = (int16_t)(c < 0 ? -lev : lev);
+    if (p < N) coefq[izzr.z[p]] = (int16_t)(c < 0 ? -lev : lev);
     cbp |= team_ballot(t, active && lev != 0) != 0ull;
     const int jj = top_set(mK);
     if (jj >= 0) carry = (int)((mV >> jj) & 1ull);
