@@ -169,7 +169,7 @@ struct BlkParam {  // block_param_t without the coefficient arrays (common/types
 // must be called by ALL lanes of the team).  The level/run mode is again a {identity, ->run, ->level}
 // automaton (zero -> run mode, |c| > 1 -> level mode, |c| == 1 keeps the mode), so ballots give each
 // position its mode, its adaptive-VLC flag and its run length.  With W = 1 this is the serial loop.
-TK_DEV int coeff_bits_team(const Team& t, const int16_t* coeff, int size, int type) {
+TK_DEV int coeff_bits_team(const Team t, const int16_t* coeff, int size, int type) {
   const int qsize = size < kMaxQuant ? size : kMaxQuant;
   const int N = qsize * qsize;
   const IzzRef izzr = izz_ref(t, qsize);

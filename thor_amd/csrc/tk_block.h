@@ -197,20 +197,31 @@ TK_DEV void find_contexts(const DbCell* cells, int cs, int ypos, int xpos, int f
 // SSD / cost
 // ---------------------------------------------------------------------------------
 template <typename PIX>
-TK_DEV void ssd_acc(const Team& t, unsigned long long* acc, const PIX* a, int as, const PIX* b, int bs, int w, int h) {
+TK_DEV void ssd_acc(const Team t, unsigned long long* acc, const PIX* a, int as, const PIX* b, int bs, int w, int h) {
   unsigned long long local = 0;
-  for (int k = t.rank; k < w * h; k += t.size) {
-    int i, j;
-    split2(mk_div(w), k, i, j);
-    int d = (int)a[i * as + j] - (int)b[i * bs + j];
-    local += (unsigned long long)(d * d);
+  if ((w & (w - 1)) == 0) {  // every width except the frame-edge rectangles
+    const Pow2 pw = mk_pow2(w);
+    for (int k = t.rank; k < w * h; k += t.size) {
+      int i, j;
+      split2(pw, k, i, j);
+      int d = (int)a[i * as + j] - (int)b[i * bs + j];
+      local += (unsigned long long)(d * d);
+    }
+  } else {
+    for (int k = t.rank; k < w * h; k += t.size) {
+      int i = k / w, j = k - i * w;
+      int d = (int)a[i * as + j] - (int)b[i * bs + j];
+      local += (unsigned long long)(d * d);
+    }
   }
-  team_add64(acc, local);
+  // butterfly reduction + one writer instead of 64 same-address LDS atomics (the callers sync before reading)
+  local = team_sum64(t, local);
+  if (t.rank == 0) *acc += local;
 }
 
 // cost_calc (encode_block.c:916-926) on the trial recon in ws->rec_* vs. the original frame.
 template <typename PIX>
-TK_DEVNI unsigned rd_cost(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int nbits, double lambda,
+TK_DEVNI unsigned rd_cost(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int nbits, double lambda,
                          long long ssd_y = -1) {
   TK_PROF_T0();
   if (t.rank == 0) ws->acc[0] = ssd_y >= 0 ? (unsigned long long)ssd_y : 0ull;
@@ -233,7 +244,7 @@ TK_DEVNI unsigned rd_cost(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
 // prediction (stride cstride>>1), ry: reconstructed luma (stride `stride`), n = luma size.
 // ---------------------------------------------------------------------------------
 template <typename PIX>
-TK_DEVNI void improve_uv(const Team& t, TeamWs<PIX>* ws, const PIX* y, PIX* u, PIX* v, const PIX* ry, int n, int cstride,
+TK_DEVNI void improve_uv(const Team t, TeamWs<PIX>* ws, const PIX* y, PIX* u, PIX* v, const PIX* ry, int n, int cstride,
                        int stride, int bitdepth) {
   const int nc = n >> 1, lognc = ilog2(nc), cs = cstride >> 1;
   for (int k = t.rank; k < 9; k += t.size) ws->acc[k] = 0;
@@ -242,11 +253,12 @@ TK_DEVNI void improve_uv(const Team& t, TeamWs<PIX>* ws, const PIX* y, PIX* u, P
     unsigned long long local = 0;
     for (int k = t.rank; k < n * n; k += t.size) {
       int i, j;
-      split2(mk_div(n), k, i, j);
+      split2(mk_pow2(n), k, i, j);
       int d = (int)ry[i * stride + j] - (int)y[i * n + j];
       local += (unsigned long long)(d * d);
     }
-    team_add64(&ws->acc[0], local);
+    local = team_sum64(t, local);
+    if (t.rank == 0) ws->acc[0] += local;
   }
   t.sync();
   long long sq = (long long)ws->acc[0];
@@ -255,14 +267,17 @@ TK_DEVNI void improve_uv(const Team& t, TeamWs<PIX>* ws, const PIX* y, PIX* u, P
     unsigned long long ls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = t.rank; k < nc * nc; k += t.size) {
       int i, j;
-      split2(mk_div(nc), k, i, j);
+      split2(mk_pow2(nc), k, i, j);
       int us = u[i * cs + j], vs = v[i * cs + j];
       int ys = (y[(i * 2) * n + j * 2] + y[(i * 2) * n + j * 2 + 1] + y[(i * 2 + 1) * n + j * 2] + y[(i * 2 + 1) * n + j * 2 + 1] + 2) >> 2;
       ls[0] += ys; ls[1] += us; ls[2] += vs;
       ls[3] += (unsigned)(ys * ys); ls[4] += (unsigned)(ys * us); ls[5] += (unsigned)(ys * vs);
       ls[6] += (unsigned)(us * us); ls[7] += (unsigned)(vs * vs);
     }
-    for (int q = 0; q < 8; q++) team_add64(&ws->acc[1 + q], ls[q]);
+    for (int q = 0; q < 8; q++) {
+      const unsigned long long tot = team_sum64(t, ls[q]);
+      if (t.rank == 0) ws->acc[1 + q] += tot;
+    }
   }
   t.sync();
   const long long ysum = ws->acc[1], usum = ws->acc[2], vsum = ws->acc[3], yysum = ws->acc[4], yusum = ws->acc[5],
@@ -286,7 +301,7 @@ TK_DEVNI void improve_uv(const Team& t, TeamWs<PIX>* ws, const PIX* y, PIX* u, P
       int b = (int)(bb < -(1ll << 31) ? -(1ll << 31) : (bb > ((1ll << 31) - 1) ? ((1ll << 31) - 1) : bb));
       for (int k = t.rank; k < nc * nc; k += t.size) {
         int i, j;
-        split2(mk_div(nc), k, i, j);
+        split2(mk_pow2(nc), k, i, j);
         int s = 2;
         for (int q = 0; q < 4; q++) {
           int r = ry[(i * 2 + (q >> 1)) * stride + j * 2 + (q & 1)];
@@ -305,7 +320,7 @@ TK_DEVNI void improve_uv(const Team& t, TeamWs<PIX>* ws, const PIX* y, PIX* u, P
 // buffers ws->rec_* / ws->coef_*; returns the number of bits of write_block.  `bs` counts or emits.
 // ---------------------------------------------------------------------------------
 template <typename PIX>
-TK_DEV void predict_inter(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, const BlkParam& p,
+TK_DEV void predict_inter(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, const BlkParam& p,
                           int split) {
   TK_PROF_T0();
   const EncCfg& c = J.cfg;
@@ -346,7 +361,7 @@ struct PruneCtx {
 // tb-split luma: call after quadrant `tu` (0..3, size s2 at (i,j) of the block) has been coded.  The first three
 // quadrants give an early lower bound; after the fourth the accumulated values are the block's luma SSD / bits.
 template <typename PIX>
-TK_DEV int prune_after_quadrant(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int intra, int tu, int i, int j,
+TK_DEV int prune_after_quadrant(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int intra, int tu, int i, int j,
                                 int s2, int bit, const int16_t* coef, PruneCtx* pc) {
   if (!pc || pc->thr == 0xffffffffu) return 0;
   t.sync();
@@ -369,7 +384,7 @@ TK_DEV int prune_after_quadrant(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
 }
 
 template <typename PIX>
-TK_DEV int prune_after_luma(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, const BlkParam& p, int cbp_y,
+TK_DEV int prune_after_luma(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, const BlkParam& p, int cbp_y,
                             int tb_split, PruneCtx* pc) {
   if (!pc || pc->thr == 0xffffffffu) return 0;
   if (pc->pruned) return 1;
@@ -407,7 +422,7 @@ TK_DEV int prune_after_luma(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* 
 
 // residual coding of one plane of an inter block (encode_and_reconstruct_block_inter :1275-1338)
 template <typename PIX>
-TK_DEV int code_inter_plane(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const PIX* org, int ostride,
+TK_DEV int code_inter_plane(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const PIX* org, int ostride,
                             const PIX* pred, PIX* rec, int size, int qp, int coeff_type, int tb_split, int16_t* coef,
                             const Node* nd = nullptr, PruneCtx* pc = nullptr) {
   const int bd = J.cfg.bitdepth;
@@ -432,7 +447,7 @@ TK_DEV int code_inter_plane(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* 
 // reuse_pred: the inter prediction of this (mode, refs, MVs) is already in ws->pred_* (previous trial
 // of the same candidate with another tb_param) - exact, the prediction does not depend on tb_param.
 template <typename PIX>
-TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BlkParam& p, BitSink& bs,
+TK_DEVNI int encode_block(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BlkParam& p, BitSink& bs,
                           int reuse_pred = 0, PruneCtx* pc = nullptr) {
   const EncCfg& c = J.cfg;
   const int size = nd.size, sizeC = size >> 1;
@@ -547,7 +562,7 @@ TK_DEVNI int encode_block(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
 
 // One RDO trial: count bits, evaluate cost, keep `best` (copy_best_parameters, :1615-1677).
 template <typename PIX>
-TK_DEV unsigned rdo_trial(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BlkParam& p, double lambda,
+TK_DEV unsigned rdo_trial(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BlkParam& p, double lambda,
                           int reuse_pred = 0, unsigned prune_thr = 0xffffffffu) {
   BitSink cnt;
   cnt.buf = nullptr; cnt.pos = 0; cnt.cap = 0; cnt.emit = 0; cnt.ovf = 0;
@@ -581,7 +596,7 @@ TK_DEV void set_cand(BlkParam& p, const InterPred& c, int idx, int mode) {
 
 // search_inter_prediction_params (encode_block.c:1033-1098)
 template <typename PIX>
-TK_DEV unsigned search_inter(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, int ypos, int xpos, int size,
+TK_DEV unsigned search_inter(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, int ypos, int xpos, int size,
                              const PIX* org, int ostride, int ref_idx, mv_t mvc, mv_t mvp, mv_t* mv_arr, int part,
                              int sign) {
   const Plane3<PIX>& ref = J.ref[ref_idx];
@@ -624,7 +639,7 @@ TK_DEV unsigned search_inter(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>*
   return sad;
 }
 
-template <typename PIX> TK_DEV void add_cands4(const Team& t, TeamWs<PIX>* ws, int ref_idx, const mv_t* mv4) {
+template <typename PIX> TK_DEV void add_cands4(const Team t, TeamWs<PIX>* ws, int ref_idx, const mv_t* mv4) {
   if (t.rank == 0)
     for (int i = 0; i < 4; i++) add_mvcand(ws->mep, ref_idx, mv4[i]);
   t.sync();
@@ -632,7 +647,7 @@ template <typename PIX> TK_DEV void add_cands4(const Team& t, TeamWs<PIX>* ws, i
 
 // search_bipred_prediction_params, me_mode 0 (encode_block.c:1739-1832) - P and B frames.
 template <typename PIX>
-TK_DEVNI void search_bipred(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int part,
+TK_DEVNI void search_bipred(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int part,
                           const mv_t* mv_center, mv_t mvp, int* ref_idx0, int* ref_idx1, mv_t* mv_arr0, mv_t* mv_arr1) {
   const EncCfg& c = J.cfg;
   const int size = nd.size;
@@ -652,7 +667,7 @@ TK_DEVNI void search_bipred(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* 
       t.sync();
       for (int k = t.rank; k < size * size; k += t.size) {
         int i, j;
-        split2(mk_div(size), k, i, j);
+        split2(mk_pow2(size), k, i, j);
         ws->org8[k] = (PIX)sat_pix(2 * (int)oy[i * J.orig.sy + j] - (int)ws->pred_y[k], c.bitdepth);
       }
       t.sync();
@@ -684,7 +699,7 @@ TK_DEVNI void search_bipred(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* 
 // prediction; evaluation order DC, HOR, VER, PLANAR (stop here when num_intra_modes == 4), then the six
 // angular modes; first minimum wins.  DC is always built from (left, top) here (sic: `xposY >= 0` :953).
 template <typename PIX>
-TK_DEVNI unsigned intra_sad_search(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int num_modes, int* mode_out) {
+TK_DEVNI unsigned intra_sad_search(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int num_modes, int* mode_out) {
   const EncCfg& c = J.cfg;
   const int size = nd.size, bd = c.bitdepth;
   const int ur = upright_avail(nd.ypos, nd.xpos, size, size, c.width, kMaxSb);
@@ -703,7 +718,7 @@ TK_DEVNI unsigned intra_sad_search(const Team& t, const FrameJob<PIX>& J, TeamWs
     int local = 0;
     for (int k = t.rank; k < size * size; k += t.size) {
       int i, j;
-      split2(mk_div(size), k, i, j);
+      split2(mk_pow2(size), k, i, j);
       local += iabs((int)oy[i * J.orig.sy + j] - (int)ws->pred_y[k]);
     }
     const unsigned sad = (unsigned)team_sum(t, local) >> (bd - 8);
@@ -718,7 +733,7 @@ TK_DEVNI unsigned intra_sad_search(const Team& t, const FrameJob<PIX>& J, TeamWs
 // mode_decision_rdo (encode_block.c:1835-2121).  Result in nd.best; returns min cost.
 // ---------------------------------------------------------------------------------
 template <typename PIX>
-TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd) {
+TK_DEVNI unsigned mode_decision(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd) {
   const EncCfg& c = J.cfg;
   const int size = nd.size;
   const double lambda = J.lambda;
@@ -905,14 +920,14 @@ TK_DEVNI unsigned mode_decision(const Team& t, const FrameJob<PIX>& J, TeamWs<PI
 // Early skip (encode_block.c:2123-2392)
 // ---------------------------------------------------------------------------------
 template <typename PIX>
-TK_DEV int early_skip_sub(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const PIX* org, int ostride,
+TK_DEV int early_skip_sub(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const PIX* org, int ostride,
                           const PIX* pred, int pstride, int size, int qp, float thr) {
   // luma: 2x2 average + (N/2) transform (size > 4 always here), threshold 0.5*thr
   const int bd = J.cfg.bitdepth;
   const int s2 = size / 2;
   for (int k = t.rank; k < s2 * s2; k += t.size) {
     int i, j;
-    split2(mk_div(s2), k, i, j);
+    split2(mk_pow2(s2), k, i, j);
     int a = (int16_t)((int)org[(2 * i) * ostride + 2 * j] - (int)pred[(2 * i) * pstride + 2 * j]);
     int b = (int16_t)((int)org[(2 * i) * ostride + 2 * j + 1] - (int)pred[(2 * i) * pstride + 2 * j + 1]);
     int cc = (int16_t)((int)org[(2 * i + 1) * ostride + 2 * j] - (int)pred[(2 * i + 1) * pstride + 2 * j]);
@@ -938,7 +953,7 @@ TK_DEV int early_skip_sub(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
 }
 
 template <typename PIX>
-TK_DEV int early_skip_subC(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const PIX* org, int ostride,
+TK_DEV int early_skip_subC(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const PIX* org, int ostride,
                            const PIX* pred, int pstride, int size, int qp, float thr) {
   const int shift2 = 21 - 5 + qp / 6;
   const double fql = (double)(1 << shift2) / (double)quant_scale(qp % 6);
@@ -973,7 +988,7 @@ TK_DEV int early_skip_subC(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* w
 }
 
 template <typename PIX>
-TK_DEVNI int check_early_skip(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, const BlkParam& p) {
+TK_DEVNI int check_early_skip(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, const BlkParam& p) {
   const EncCfg& c = J.cfg;
   const int size = nd.size, size0 = size < 32 ? size : 32;
   const int qpY = J.qp, qpC = TK_TAB.chroma_qp[qpY];
@@ -1012,7 +1027,7 @@ TK_DEVNI int check_early_skip(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>
 // Final encode of a CB: recompute (encode_block final), write recon + cell state, emit bits.
 // ---------------------------------------------------------------------------------
 template <typename PIX>
-TK_DEVNI int final_encode(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BitSink& out) {
+TK_DEVNI int final_encode(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BitSink& out) {
   TK_PROF_T0();
   BlkParam p = nd.best;
   BitSink cnt;
@@ -1062,7 +1077,7 @@ TK_DEVNI int final_encode(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
 // process_block (encode_block.c:2401-2566) as an explicit-stack traversal of one superblock.
 // ---------------------------------------------------------------------------------
 template <typename PIX>
-TK_DEV void process_sb(const Team& t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, int sb_y, int sb_x, BitSink& out) {
+TK_DEV void process_sb(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, int sb_y, int sb_x, BitSink& out) {
   TK_PROF_T0();
   const EncCfg& c = J.cfg;
   const int fw = c.width, fh = c.height;

@@ -77,7 +77,7 @@ TK_DEV void team_or(unsigned* p, unsigned v) {
 
 // Cross-lane helpers.  A team of 1 lane (host simulation) degenerates to the identity, so code
 // written against them is also the serial algorithm.
-TK_DEV unsigned long long team_ballot(const Team& t, int pred) {
+TK_DEV unsigned long long team_ballot(const Team t, int pred) {
 #if TK_HOST
   (void)t;
   return pred ? 1ull : 0ull;
@@ -86,7 +86,7 @@ TK_DEV unsigned long long team_ballot(const Team& t, int pred) {
   return __ballot(pred);
 #endif
 }
-TK_DEV int team_sum(const Team& t, int v) {
+TK_DEV int team_sum(const Team t, int v) {
 #if TK_HOST
   (void)t;
   return v;
@@ -96,7 +96,7 @@ TK_DEV int team_sum(const Team& t, int v) {
   return v;
 #endif
 }
-TK_DEV int team_max(const Team& t, int v) {
+TK_DEV int team_max(const Team t, int v) {
 #if TK_HOST
   (void)t;
   return v;
@@ -106,7 +106,7 @@ TK_DEV int team_max(const Team& t, int v) {
   return v;
 #endif
 }
-TK_DEV int team_shfl_xor(const Team& t, int v, int d) {
+TK_DEV int team_shfl_xor(const Team t, int v, int d) {
 #if TK_HOST
   (void)t; (void)d;
   return v;
@@ -115,7 +115,7 @@ TK_DEV int team_shfl_xor(const Team& t, int v, int d) {
   return __shfl_xor(v, d);
 #endif
 }
-TK_DEV unsigned long long team_min64(const Team& t, unsigned long long v) {
+TK_DEV unsigned long long team_min64(const Team t, unsigned long long v) {
 #if TK_HOST
   (void)t;
   return v;
@@ -125,6 +125,17 @@ TK_DEV unsigned long long team_min64(const Team& t, unsigned long long v) {
     unsigned long long o = __shfl_xor(v, d);
     v = o < v ? o : v;
   }
+  return v;
+#endif
+}
+// sum over the team, result in every lane (xor-shuffle butterfly; identity for a 1-lane team)
+TK_DEV unsigned long long team_sum64(const Team t, unsigned long long v) {
+#if TK_HOST
+  (void)t;
+  return v;
+#else
+  (void)t;
+  for (int d = 32; d >= 1; d >>= 1) v += (unsigned long long)__shfl_xor(v, d);
   return v;
 #endif
 }
@@ -199,6 +210,21 @@ TK_DEV void split2(const Div2& d, int k, int& i, int& j) {
   if (d.sh >= 0) { i = k >> d.sh; j = k & (d.w - 1); }
   else { i = k / d.w; j = k - i * d.w; }
 }
+// Same for dimensions that are powers of two by construction (TU / PU / CB sizes): no division fallback is
+// compiled into the loop.
+struct Pow2 {
+  int sh, mask;
+};
+TK_DEV Pow2 mk_pow2(int w) {
+  Pow2 d;
+  d.sh = ilog2((unsigned)w);
+  d.mask = w - 1;
+  return d;
+}
+TK_DEV void split2(const Pow2& d, int k, int& i, int& j) {
+  i = k >> d.sh;
+  j = k & d.mask;
+}
 TK_DEV int sat_pix(int v, int bitdepth) { return clampi(v, 0, (1 << bitdepth) - 1); }
 
 // ---------------------------------------------------------------------------------
@@ -259,7 +285,7 @@ extern __device__ Tables g_tab;
 #define TK_TAB (tk::g_tab)
 #endif
 
-TK_DEV IzzRef izz_ref(const Team& t, int qsize) {
+TK_DEV IzzRef izz_ref(const Team t, int qsize) {
   IzzRef r;
 #if TK_HOST
   (void)t;

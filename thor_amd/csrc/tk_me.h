@@ -51,7 +51,7 @@ TK_DEV void add_mvcand(MeWs* w, int r, mv_t mv) {
 
 // sad[c] = sum over w x h of |org - F(c, i, j)| for c < ncand.
 template <typename PIX, class F>
-TK_DEV void sad_many(const Team& t, int* sad, int ncand, const PIX* org, int ostride, int w, int h, F sample) {
+TK_DEV void sad_many(const Team t, int* sad, int ncand, const PIX* org, int ostride, int w, int h, F sample) {
   for (int c = t.rank; c < ncand; c += t.size) sad[c] = 0;
   t.sync();
   const int npix = w * h;
@@ -93,7 +93,7 @@ template <> __device__ __forceinline__ int sad4<uint8_t>(const uint8_t* a, const
 // sad[c] = SAD(org block, block at base(c)) for c < ncand; full-pel candidates given as pointers.
 // Work item = (candidate, row, group of 4 samples).
 template <typename PIX, class F>
-TK_DEV void sad_many_ptr(const Team& t, int* sad, int ncand, const PIX* org, int ostride, int w, int h, int rstride, F base) {
+TK_DEV void sad_many_ptr(const Team t, int* sad, int ncand, const PIX* org, int ostride, int w, int h, int rstride, F base) {
   // G lanes cooperate on one candidate (G = min(team, items per candidate), a power of two), P = team/G
   // candidates are evaluated per pass; partial sums are combined with xor-shuffles (no atomics).
   const int gpr = w >> 2, nit = h * gpr;
@@ -127,7 +127,7 @@ TK_DEV void sad_many_ptr(const Team& t, int* sad, int ncand, const PIX* org, int
 // item r < nit, cost(c, ctx, sad) -> cost.  G lanes share a candidate, partial sums are combined with
 // xor-shuffles, the final minimum with a 64-bit wave reduction; no LDS traffic, no barriers.
 template <class PrepF, class ItemF, class CostF>
-TK_DEV unsigned long long eval_min(const Team& t, int n, int nit, PrepF prep, ItemF item, CostF cost) {
+TK_DEV unsigned long long eval_min(const Team t, int n, int nit, PrepF prep, ItemF item, CostF cost) {
   const int G = nit < t.size ? nit : t.size;
   const int P = t.size / G;
   const int slot = t.rank / G, sub = t.rank - slot * G;
@@ -174,7 +174,7 @@ template <> __device__ __forceinline__ int sad4v<uint8_t>(const Px4<uint8_t>& a,
 // reduction).  All reference loads of a pass are issued before the first use.
 // cand(c) -> {clipped mv, pointer to the displaced reference block}; returns min (cost<<32 | index).
 template <typename PIX, class CandF, class CostF>
-TK_DEV unsigned long long eval_fullpel(const Team& t, int n, const PIX* org, int ostride, int rstride, int width, int height,
+TK_DEV unsigned long long eval_fullpel(const Team t, int n, const PIX* org, int ostride, int rstride, int width, int height,
                                        CandF cand, CostF cost) {
   const int gpr = width >> 2, lg = ilog2((unsigned)gpr), nit = height * gpr;
   int G = nit >> 4;
@@ -239,9 +239,9 @@ struct MeArgs {
 // sad_calc_fasthalf_simd enc_kernels.c:330, sad_calc_fastquarter :286-415): the SADs of the 8 half-
 // (quarter-) pel neighbours of the centre built from rounding (avg) and truncating (rdavg) byte averages;
 // returns the smallest of them and its offset.  Lanes split the samples, 8 shuffle reductions.
-template <typename PIX> TK_DEV unsigned fast_halfpel(const Team& t, const PIX* a, const PIX* b, int as, int bs, int width, int height, int* bx, int* by) {
+template <typename PIX> TK_DEV unsigned fast_halfpel(const Team t, const PIX* a, const PIX* b, int as, int bs, int width, int height, int* bx, int* by) {
   int tl = 0, tr = 0, br = 0, bl = 0, top = 0, right = 0, down = 0, left = 0;
-  const Div2 dw = mk_div(width);
+  const Pow2 dw = mk_pow2(width);
   for (int r = t.rank; r < width * height; r += t.size) {
     int i, j;
     split2(dw, r, i, j);
@@ -277,10 +277,10 @@ template <typename PIX> TK_DEV unsigned fast_halfpel(const Team& t, const PIX* a
   return utop;
 }
 
-template <typename PIX> TK_DEV unsigned fast_quarterpel(const Team& t, const PIX* o_, const PIX* r_, int os, int rs, int width, int height, int* bx, int* by) {
+template <typename PIX> TK_DEV unsigned fast_quarterpel(const Team t, const PIX* o_, const PIX* r_, int os, int rs, int width, int height, int* bx, int* by) {
   int tl = 0, tr = 0, br = 0, bl = 0, top = 0, right = 0, down = 0, left = 0;
   const int hx = *bx, hy = *by;  // half-pel offset chosen before (0 or +-2): selects the interpolation pattern
-  const Div2 dw = mk_div(width);
+  const Pow2 dw = mk_pow2(width);
   for (int q = t.rank; q < width * height; q += t.size) {
     int i, j;
     split2(dw, q, i, j);
@@ -328,7 +328,7 @@ template <typename PIX> TK_DEV unsigned fast_quarterpel(const Team& t, const PIX
 }
 
 template <typename PIX>
-TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const PIX* ref, const MeArgs& a, mv_t mvc,
+TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const PIX* ref, const MeArgs& a, mv_t mvc,
                                 mv_t mvp, int ref_idx, mv_t* mv_out) {
   TK_PROF_T0();
   const int s = a.sign ? -1 : 1;
@@ -494,7 +494,7 @@ TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const 
       x.sp = luma_setup(x.mv, a.sign, a.width, a.height, a.fwidth, a.fheight, a.xpos, a.ypos, a.enable_bipred);
       return x;
     };
-    const Div2 dw = mk_div(a.width);
+    const Pow2 dw = mk_pow2(a.width);
     auto sub_item = [&](const SP& x, int r) -> int {
       int i, j;
       split2(dw, r, i, j);
@@ -539,7 +539,7 @@ TK_DEVNI unsigned motion_estimate(const Team& t, MeWs* w, const PIX* org, const 
 // as quarter-pel vectors.  The vector is clipped for ref0's sign and then AGAIN for ref1's sign; ref0 is
 // predicted with the once-clipped vector, ref1 and the cost use the twice-clipped one.
 template <typename PIX>
-TK_DEVNI unsigned motion_estimate_bi(const Team& t, MeWs* w, const PIX* org, const PIX* ref0, const PIX* ref1, const MeArgs& a,
+TK_DEVNI unsigned motion_estimate_bi(const Team t, MeWs* w, const PIX* org, const PIX* ref0, const PIX* ref1, const MeArgs& a,
                                     mv_t mvc, mv_t mvp, int r_idx0, mv_t* mv_out) {
   const int sh = a.bitdepth - 8;
   const int size = a.cb_size;
@@ -556,7 +556,7 @@ TK_DEVNI unsigned motion_estimate_bi(const Team& t, MeWs* w, const PIX* org, con
     x.s1 = luma_setup(m1, 1 - a.sign, size, size, a.fwidth, a.fheight, a.xpos, a.ypos, a.enable_bipred);
     return x;
   };
-  const Div2 dw = mk_div(size);
+  const Pow2 dw = mk_pow2(size);
   auto bi_item = [&](const BI& x, int r) -> int {
     int i, j;
     split2(dw, r, i, j);

@@ -129,18 +129,19 @@ TK_DEV int luma_sample(const PIX* ref, int stride, int i, int j, const SubPel& s
 
 // get_inter_prediction_luma for a whole PU (team-parallel over samples).
 template <typename PIX>
-TK_DEV void pred_luma(const Team& t, PIX* dst, int dstride, const PIX* ref, int rstride, int width, int height, mv_t mv,
+TK_DEV void pred_luma(const Team t, PIX* dst, int dstride, const PIX* ref, int rstride, int width, int height, mv_t mv,
                       int sign, int bipred, int pic_w, int pic_h, int xpos, int ypos, int bitdepth) {
   SubPel s = luma_setup(mv, sign, width, height, pic_w, pic_h, xpos, ypos, bipred);
+  const Div2 pw = mk_div(width);  // rectangular frame-edge skip blocks have non power-of-two widths
   for (int k = t.rank; k < width * height; k += t.size) {
     int i, j;
-    split2(mk_div(width), k, i, j);
+    split2(pw, k, i, j);
     dst[i * dstride + j] = (PIX)luma_sample(ref, rstride, i, j, s, bipred, bitdepth);
   }
 }
 
 template <typename PIX>
-TK_DEV void pred_chroma(const Team& t, PIX* dst, int dstride, const PIX* ref, int rstride, int width, int height,
+TK_DEV void pred_chroma(const Team t, PIX* dst, int dstride, const PIX* ref, int rstride, int width, int height,
                         mv_t mv, int sign, int pic_w2, int pic_h2, int xpos, int ypos, int bitdepth) {
   int mx = sign ? -mv.x : mv.x, my = sign ? -mv.y : mv.y;
   int vf = my & 7, hf = mx & 7;
@@ -172,7 +173,7 @@ TK_DEV void pred_chroma(const Team& t, PIX* dst, int dstride, const PIX* ref, in
 // get_inter_prediction_yuv (inter_prediction.c:185-226), 4:2:0.  dst planes are compact blocks
 // of stride `size` (luma) / size/2 (chroma).  `split`: 1 => four quadrant PUs with mv_arr[0..3].
 template <typename PIX>
-TK_DEVNI void pred_inter_yuv(const Team& t, const Plane3<PIX>& ref, PIX* py, PIX* pu, PIX* pv, int ypos, int xpos,
+TK_DEVNI void pred_inter_yuv(const Team t, const Plane3<PIX>& ref, PIX* py, PIX* pu, PIX* pv, int ypos, int xpos,
                            int size, int bw, int bh, const mv_t* mv_arr, int sign, int pic_w, int pic_h,
                            int enable_bipred, int split, int bitdepth) {
   const int div = split + 1;
@@ -200,7 +201,7 @@ TK_DEVNI void pred_inter_yuv(const Team& t, const Plane3<PIX>& ref, PIX* py, PIX
 
 // average_blocks_all: truncating (a+b)>>1 (inter_prediction.c:228-247).
 template <typename PIX>
-TK_DEV void average_yuv(const Team& t, PIX* dy, PIX* du, PIX* dv, const PIX* ay, const PIX* au, const PIX* av,
+TK_DEV void average_yuv(const Team t, PIX* dy, PIX* du, PIX* dv, const PIX* ay, const PIX* au, const PIX* av,
                         const PIX* by, const PIX* bu, const PIX* bv, int size, int bw, int bh) {
   for (int k = t.rank; k < bw * bh; k += t.size) {
     int i, j;
@@ -231,7 +232,7 @@ template <typename PIX> struct IntraEdge {
 // the reconstructed frame; rblock at the TU's top-left in the CB-local recon block (tb_split only);
 // (i, j) = TU offset inside the CB; (ypos, xpos) = CB position in this plane.
 template <typename PIX>
-TK_DEV void make_edges(const Team& t, IntraEdge<PIX>* e, const PIX* rec_frame, int fstride, const PIX* rblock,
+TK_DEV void make_edges(const Team t, IntraEdge<PIX>* e, const PIX* rec_frame, int fstride, const PIX* rblock,
                        int rbstride, int i, int j, int ypos, int xpos, int size, int cb_upright, int cb_downleft,
                        int tb_split, int bitdepth) {
   const int len = 2 * size;
@@ -291,7 +292,7 @@ template <typename PIX> TK_DEV int f5(const PIX* a, int k, int size) {
 // get_intra_prediction (intra_prediction.c:403-428) - writes size x size at dst (stride dstride).
 // (ypos, xpos) = TU position in this plane (only the ==0 tests matter, for DC).
 template <typename PIX>
-TK_DEV void pred_intra(const Team& t, const IntraEdge<PIX>* e, int ypos, int xpos, int size, PIX* dst, int dstride,
+TK_DEV void pred_intra(const Team t, const IntraEdge<PIX>* e, int ypos, int xpos, int size, PIX* dst, int dstride,
                        int mode, int bitdepth) {
   typedef TK_LDS PIX lpix;  // the edge arrays live in LDS on the device (see tk_common.h)
   const lpix* left = (const lpix*)e->left;
@@ -309,9 +310,10 @@ TK_DEV void pred_intra(const Team& t, const IntraEdge<PIX>* e, int ypos, int xpo
   } else if (mode == 4 || mode == 7 || mode == 8) {
     tlF = (PIX)((2 * tl + left[0] + top[0] + 2) >> 2);
   }
+  const Pow2 pw = mk_pow2(size);
   for (int k = t.rank; k < size * size; k += t.size) {
     int i, j;
-    split2(mk_div(size), k, i, j);
+    split2(pw, k, i, j);
     int v;
     switch (mode) {
       case 1:  // planar

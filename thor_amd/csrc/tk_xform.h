@@ -43,17 +43,17 @@ struct XformWs {
 // entry (i, q) of the N-point basis, log2(32/N) = rs
 TK_DEV int dct_at(const XformWs* ws, int rs, int i, int q) { return ws->dct32[((i << rs) << 5) + q]; }
 // Fill the team-local table (call once per team before any transform).
-TK_DEV void xform_tables_init(const Team& t, XformWs* ws) {
+TK_DEV void xform_tables_init(const Team t, XformWs* ws) {
   for (int k = t.rank; k < 1024; k += t.size) ws->dct32[k] = TK_TAB.dct32[k];
   for (int k = t.rank; k < 336; k += t.size) ws->izz[k] = k < 16 ? TK_TAB.izz4[k] : (k < 80 ? TK_TAB.izz8[k - 16] : TK_TAB.izz16[k - 80]);
   t.sync();
 }
 
-TK_DEV void fwd_core(const Team& t, XformWs* ws, int size1, int qsize, int shift_1);
+TK_DEV void fwd_core(const Team t, XformWs* ws, int size1, int qsize, int shift_1);
 
 // Forward transform of (org - pred) -> ws->coef (qsize x qsize compact).
 template <typename PIX>
-TK_DEV void fwd_transform(const Team& t, XformWs* ws, const PIX* org, int ostride, const PIX* pred, int pstride,
+TK_DEV void fwd_transform(const Team t, XformWs* ws, const PIX* org, int ostride, const PIX* pred, int pstride,
                           int size, int fast, int bitdepth) {
   const int qsize = size < kMaxQuant ? size : kMaxQuant;
   int size1 = size, scale = 1;
@@ -65,7 +65,7 @@ TK_DEV void fwd_transform(const Team& t, XformWs* ws, const PIX* org, int ostrid
   lds_i16* const in_l = TK_LDS_PTR(ws->in);
   for (int k = t.rank; k < size1 * size1; k += t.size) {
     int i, j;
-    split2(mk_div(size1), k, i, j);
+    split2(mk_pow2(size1), k, i, j);
     int sum = 0;
     if (scale == 1) {
       sum = (int16_t)((int)org[i * ostride + j] - (int)pred[i * pstride + j]);
@@ -87,7 +87,7 @@ TK_DEV void fwd_transform(const Team& t, XformWs* ws, const PIX* org, int ostrid
 // Stage 1 (rows):   tmp[j][i] = (sum_q M[i][q] * in[j][q] + add1) >> shift1   -> stored [row j][coef i]
 // Stage 2 (cols):   coef[i][j] = (sum_q M[i][q] * tmp[q][j] + add2) >> shift2
 // Lane mappings are chosen so that every LDS access is either consecutive across lanes or a broadcast.
-TK_DEV void fwd_core(const Team& t, XformWs* ws, int size1, int qsize, int shift_1) {
+TK_DEV void fwd_core(const Team t, XformWs* ws, int size1, int qsize, int shift_1) {
   const int rs = 5 - ilog2((unsigned)size1);
   const int add_1 = 1 << (shift_1 - 1);
   const int shift_2 = ilog2(size1) + 5;
@@ -96,7 +96,7 @@ TK_DEV void fwd_core(const Team& t, XformWs* ws, int size1, int qsize, int shift
   const lds_i16* const dct = TK_LDS_PTR(ws->dct32);
   lds_i16* const tmp = TK_LDS_PTR(ws->tmp);
   lds_i16* const coef = TK_LDS_PTR(ws->coef);
-  const Div2 d1 = mk_div(size1), dq = mk_div(qsize);
+  const Pow2 d1 = mk_pow2(size1), dq = mk_pow2(qsize);
   for (int k = t.rank; k < qsize * size1; k += t.size) {
     int i, j;
     split2(d1, k, i, j);  // row j fastest: M[i][q] is a broadcast, in[q][j] consecutive
@@ -128,7 +128,7 @@ TK_DEV void fwd_core(const Team& t, XformWs* ws, int size1, int qsize, int shift
 }
 
 // Same core transform on an explicit int16 block already stored TRANSPOSED in ws->in (early skip).
-TK_DEV void fwd_transform_block(const Team& t, XformWs* ws, int size, int bitdepth) {
+TK_DEV void fwd_transform_block(const Team t, XformWs* ws, int size, int bitdepth) {
   fwd_core(t, ws, size, size, ilog2(size) + bitdepth - 8);
 }
 
@@ -175,7 +175,7 @@ TK_DEV int quantize_serial(const int16_t* coef, int16_t* coefq, int qp, int size
 // {identity, ->0, ->1} (never a swap, because the level under mode 1 is >= the level under mode 0),
 // so the state entering a position is the target of the nearest earlier constant transition; a
 // ballot + count-leading-zeros finds it.  With W = 1 this is literally the serial loop.
-TK_DEV int quantize_team(const Team& t, XformWs* ws, int16_t* coefq, int qp, int size, int intra_block) {
+TK_DEV int quantize_team(const Team t, XformWs* ws, int16_t* coefq, int qp, int size, int intra_block) {
   const int qsize = size < kMaxQuant ? size : kMaxQuant;
   const int N = qsize * qsize;
   const IzzRef izzr = izz_ref(t, qsize);
@@ -225,7 +225,7 @@ TK_DEV int quantize_team(const Team& t, XformWs* ws, int16_t* coefq, int qp, int
 }
 
 // dequantize (common_block.c:45-73): coefq -> ws->rcoef, int16 truncation as in the reference.
-TK_DEV void dequantize(const Team& t, XformWs* ws, const int16_t* coefq, int qp, int size) {
+TK_DEV void dequantize(const Team t, XformWs* ws, const int16_t* coefq, int qp, int size) {
   const int qsize = size < kMaxQuant ? size : kMaxQuant;
   const int lshift = qp / 6, rshift = ilog2(size) - 1;
   const int64_t scale = dequant_scale(qp % 6);
@@ -242,7 +242,7 @@ TK_DEV void dequantize(const Team& t, XformWs* ws, const int16_t* coefq, int qp,
 
 // inverse transform of ws->rcoef + prediction -> rec (saturated), replicating for 64/128.
 template <typename PIX>
-TK_DEV void inv_transform_recon(const Team& t, XformWs* ws, const PIX* pred, int pstride, PIX* rec, int rstride,
+TK_DEV void inv_transform_recon(const Team t, XformWs* ws, const PIX* pred, int pstride, PIX* rec, int rstride,
                                 int size, int bitdepth) {
   const int n = size < 32 ? size : 32;
   const int scale = size / n;
@@ -253,7 +253,7 @@ TK_DEV void inv_transform_recon(const Team& t, XformWs* ws, const PIX* pred, int
   const lds_i16* const rcoef = TK_LDS_PTR(ws->coef);
   const int shift_2 = 20 - bitdepth, add_2 = 1 << (shift_2 - 1);
   const int mstride = (1 << rs) << 5;  // basis row pitch in the 32-point table
-  const Div2 dn = mk_div(n);
+  const Pow2 dn = mk_pow2(n);
   // stage 1: itmp[i*n + j] = clip((sum_k M[k][j]*rcoef[k][i] + 64) >> 7)   i < qsize, j < n
   for (int k = t.rank; k < qsize * n; k += t.size) {
     int i, j;
@@ -291,18 +291,26 @@ TK_DEV void inv_transform_recon(const Team& t, XformWs* ws, const PIX* pred, int
 }
 
 template <typename PIX>
-TK_DEV void copy_block(const Team& t, PIX* dst, int dstride, const PIX* src, int sstride, int w, int h) {
-  for (int k = t.rank; k < w * h; k += t.size) {
-    int i, j;
-    split2(mk_div(w), k, i, j);
-    dst[i * dstride + j] = src[i * sstride + j];
+TK_DEV void copy_block(const Team t, PIX* dst, int dstride, const PIX* src, int sstride, int w, int h) {
+  if ((w & (w - 1)) == 0) {
+    const Pow2 pw = mk_pow2(w);
+    for (int k = t.rank; k < w * h; k += t.size) {
+      int i, j;
+      split2(pw, k, i, j);
+      dst[i * dstride + j] = src[i * sstride + j];
+    }
+  } else {  // frame-edge rectangles (skip blocks)
+    for (int k = t.rank; k < w * h; k += t.size) {
+      int i = k / w, j = k - i * w;
+      dst[i * dstride + j] = src[i * sstride + j];
+    }
   }
 }
 
 // One transform unit: residual -> T -> Q -> (IQ -> IT -> recon | recon = pred). Returns cbp bit.
 // coeff_type: bit0 chroma, bit1 = (frame_type == I) [sic: frame type, Appendix B.6].
 template <typename PIX>
-TK_DEVNI int code_tu(const Team& t, XformWs* ws, const PIX* org, int ostride, const PIX* pred, int pstride, PIX* rec,
+TK_DEVNI int code_tu(const Team t, XformWs* ws, const PIX* org, int ostride, const PIX* pred, int pstride, PIX* rec,
                    int rstride, int size, int qp, int coeff_type, int fast, int16_t* coefq, int bitdepth) {
   TK_PROF_T0();
   fwd_transform(t, ws, org, ostride, pred, pstride, size, fast, bitdepth);
