@@ -503,7 +503,41 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
     auto sub_cost = [&](int, const SP& x, int sad) -> unsigned {
       return ((unsigned)sad >> sh) + mv_cost(a.lam, x.mv.y - mvp.y, x.mv.x - mvp.x);
     };
-    unsigned long long k = eval_min(t, 8, a.width * a.height, sub_prep, sub_item, sub_cost);
+    // Fast path: all eight candidates read from the 8x8 window around the centre's integer position (always,
+    // except when luma_setup's frame-edge clamps pull a candidate further away).
+    SP cand[8];
+    const SubPel ctr = luma_setup(base, a.sign, a.width, a.height, a.fwidth, a.fheight, a.xpos, a.ypos, a.enable_bipred);
+    int in_window = 1;
+    for (int c = 0; c < 8; c++) {
+      cand[c] = sub_prep(c);
+      const int dy = cand[c].sp.ver_int - ctr.ver_int + 1, dx = cand[c].sp.hor_int - ctr.hor_int + 1;
+      if (dy < 0 || dy > 2 || dx < 0 || dx > 2) in_window = 0;
+    }
+    unsigned long long k;
+    if (in_window) {
+      int sad8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int r = t.rank; r < a.width * a.height; r += t.size) {
+        int i, j;
+        split2(dw, r, i, j);
+        const PIX* p0 = ref + (i + ctr.ver_int - 3) * a.rstride + (j + ctr.hor_int - 3);
+        WinRow<PIX> win[8];
+        for (int q = 0; q < 8; q++) win_load(p0 + q * a.rstride, win[q]);
+        const int o = (int)org[i * a.ostride + j];
+        for (int c = 0; c < 8; c++) {
+          const int dy = cand[c].sp.ver_int - ctr.ver_int + 1, dx = cand[c].sp.hor_int - ctr.hor_int + 1;
+          WinRow<PIX> rows[6];
+          for (int m = 0; m < 6; m++) rows[m] = win_pick(win[m], win[m + 1], win[m + 2], dy, dx);
+          sad8[c] += iabs(o - luma_sample_win<PIX>(rows, cand[c].sp, a.enable_bipred, a.bitdepth));
+        }
+      }
+      k = ~0ull;
+      for (int c = 0; c < 8; c++) {
+        const int tot = team_sum(t, sad8[c]);
+        const unsigned long long kk = ((unsigned long long)sub_cost(c, cand[c], tot) << 32) | (unsigned)c;
+        k = kk < k ? kk : k;
+      }
+    } else
+      k = eval_min(t, 8, a.width * a.height, sub_prep, sub_item, sub_cost);
     mv_t best = base;
     if ((unsigned)(k >> 32) < cmin) { cmin = (unsigned)(k >> 32); best = sub_prep((int)(unsigned)k).mv; }
     // mv_opt += delta of the winning position (none => unchanged)

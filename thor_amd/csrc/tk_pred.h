@@ -127,6 +127,61 @@ TK_DEV int luma_sample(const PIX* ref, int stride, int i, int j, const SubPel& s
   return sat_pix((sum + 2048) >> 12, bitdepth);
 }
 
+// ---------------------------------------------------------------------------------
+// Register-resident 8x8 reference window for the sub-pel search.  The eight half- (quarter-) pel candidates
+// around one centre all interpolate from integer positions within +-1 sample of the centre's, i.e. from the
+// same 8 rows x 8 columns of the reference (taps -2..+3 around -1..+1).  A lane therefore fetches that window
+// ONCE per sample (8 wide loads in flight together) and evaluates all eight candidates from registers instead
+// of issuing six dependent row loads per candidate and sample.
+// ---------------------------------------------------------------------------------
+template <typename PIX> struct WinRow;
+template <> struct WinRow<uint8_t> { unsigned long long a; };
+template <> struct WinRow<uint16_t> { unsigned long long a, b; };
+TK_DEV void win_load(const uint8_t* p, WinRow<uint8_t>& r) { __builtin_memcpy(&r.a, p, 8); }
+TK_DEV void win_load(const uint16_t* p, WinRow<uint16_t>& r) { __builtin_memcpy(&r.a, p, 8); __builtin_memcpy(&r.b, p + 4, 8); }
+// row selected by dy in {0,1,2} (uniform) out of three consecutive rows, then shifted right by dx samples
+TK_DEV WinRow<uint8_t> win_pick(const WinRow<uint8_t>& r0, const WinRow<uint8_t>& r1, const WinRow<uint8_t>& r2, int dy, int dx) {
+  WinRow<uint8_t> o;
+  o.a = (dy == 0 ? r0.a : (dy == 1 ? r1.a : r2.a)) >> (8 * dx);
+  return o;
+}
+TK_DEV WinRow<uint16_t> win_pick(const WinRow<uint16_t>& r0, const WinRow<uint16_t>& r1, const WinRow<uint16_t>& r2, int dy, int dx) {
+  const unsigned long long a = dy == 0 ? r0.a : (dy == 1 ? r1.a : r2.a), b = dy == 0 ? r0.b : (dy == 1 ? r1.b : r2.b);
+  WinRow<uint16_t> o;
+  if (dx == 0) { o.a = a; o.b = b; }
+  else { o.a = (a >> (16 * dx)) | (b << (64 - 16 * dx)); o.b = b >> (16 * dx); }
+  return o;
+}
+TK_DEV int win_at(const WinRow<uint8_t>& r, int n) { return (int)((r.a >> (8 * n)) & 0xffu); }          // n = 0..5
+TK_DEV int win_at(const WinRow<uint16_t>& r, int n) { return n < 4 ? (int)((r.a >> (16 * n)) & 0xffffu) : (int)((r.b >> (16 * (n - 4))) & 0xffffu); }
+
+// luma_sample() evaluated on six picked rows (row m, column n <-> p[(m-2)*stride + (n-2)])
+template <typename PIX> TK_DEV int luma_sample_win(const WinRow<PIX> w[6], const SubPel& s, int bipred, int bitdepth) {
+  if (s.ver_frac == 0 && s.hor_frac == 0) return win_at(w[2], 2);
+  if (s.ver_frac == 2 && s.hor_frac == 2 && bipred < 2) {
+    int sum = win_at(w[1], 2) + win_at(w[1], 3) + win_at(w[2], 1) + 2 * win_at(w[2], 2) + 2 * win_at(w[2], 3) + win_at(w[2], 4) +
+              win_at(w[3], 1) + 2 * win_at(w[3], 2) + 2 * win_at(w[3], 3) + win_at(w[3], 4) + win_at(w[4], 2) + win_at(w[4], 3);
+    return sat_pix((sum + 8) >> 4, bitdepth);
+  }
+  if (s.hor_frac == 0) {
+    int sum = 0;
+    for (int m = 0; m < 6; m++) sum += s.tv[m] * win_at(w[m], 2);
+    return sat_pix((sum * 64 + 2048) >> 12, bitdepth);
+  }
+  if (s.ver_frac == 0) {
+    int sum = 0;
+    for (int n = 0; n < 6; n++) sum += s.th[n] * win_at(w[2], n);
+    return sat_pix((sum * 64 + 2048) >> 12, bitdepth);
+  }
+  int sum = 0;
+  for (int n = 0; n < 6; n++) {
+    int col = 0;
+    for (int m = 0; m < 6; m++) col += s.tv[m] * win_at(w[m], n);
+    sum += s.th[n] * col;
+  }
+  return sat_pix((sum + 2048) >> 12, bitdepth);
+}
+
 // get_inter_prediction_luma for a whole PU (team-parallel over samples).
 template <typename PIX>
 TK_DEV void pred_luma(const Team t, PIX* dst, int dstride, const PIX* ref, int rstride, int width, int height, mv_t mv,
