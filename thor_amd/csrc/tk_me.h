@@ -180,10 +180,25 @@ TK_DEV unsigned long long eval_fullpel(const Team t, int n, const PIX* org, int 
   int G = nit >> 4;
   if (G < 1) G = 1;
   if (G > t.size) G = t.size;
-  const int ipl = nit / G;            // items per lane: 4, 8, 16 or a multiple of 16
+  const int ipl = nit / G;            // items per lane: 1, 2, 4, 8 or 16 (PUs are at most 64x64 samples)
   const int P = t.size / G;
   const int slot = t.rank / G, sub = t.rank - slot * G;
   unsigned long long best = ~0ull;
+  // A lane's items do not depend on the candidate: when they fit (ipl <= 16, i.e. always with a 64-lane team,
+  // PUs being at most 64x64) its share of the original block is fetched once and kept in registers for all
+  // passes; a smaller team (host simulation) walks its items in chunks of 16 and reloads.
+  const int hoist = ipl <= 16;
+  Px4<PIX> o[16];
+  if (hoist) {
+#if !TK_HOST
+#pragma unroll
+#endif
+    for (int k = 0; k < 16; k++)
+      if (k < ipl) {
+        const int r = sub + k * G, i = r >> lg, g = r & (gpr - 1);
+        o[k] = ld4(org + i * ostride + 4 * g);
+      }
+  }
   for (int c0 = 0; c0 < n; c0 += 2 * P) {
     const int ca = c0 + slot, cb = c0 + P + slot;
     const int va = ca < n, vb = cb < n;
@@ -193,14 +208,14 @@ TK_DEV unsigned long long eval_fullpel(const Team t, int n, const PIX* org, int 
     if (va) {
       for (int k0 = 0; k0 < ipl; k0 += 16) {
         const int cnt = ipl - k0 < 16 ? ipl - k0 : 16;
-        Px4<PIX> o[16], a[16], b[16];
+        Px4<PIX> a[16], b[16];
 #if !TK_HOST
 #pragma unroll
 #endif
         for (int k = 0; k < 16; k++)
           if (k < cnt) {
             const int r = sub + (k0 + k) * G, i = r >> lg, g = r & (gpr - 1);
-            o[k] = ld4(org + i * ostride + 4 * g);
+            if (!hoist) o[k] = ld4(org + i * ostride + 4 * g);
             a[k] = ld4(xa.p + i * rstride + 4 * g);
             if (vb) b[k] = ld4(xb.p + i * rstride + 4 * g);
           }
