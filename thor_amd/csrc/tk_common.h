@@ -128,6 +128,16 @@ TK_DEV unsigned long long team_min64(const Team t, unsigned long long v) {
   return v;
 #endif
 }
+// Value known to be identical in every lane of the team: on the device it is moved to a scalar register so that
+// selects / branches on it are scalar instead of exec-mask juggling (the compiler cannot prove uniformity of values
+// that went through memory or shuffles).
+TK_DEV int tk_uniform(int v) {
+#if TK_HOST
+  return v;
+#else
+  return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
 // sum over the team, result in every lane (xor-shuffle butterfly; identity for a 1-lane team)
 TK_DEV unsigned long long team_sum64(const Team t, unsigned long long v) {
 #if TK_HOST

@@ -520,6 +520,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
     };
     // Fast path: all eight candidates read from the 8x8 window around the centre's integer position (always,
     // except when luma_setup's frame-edge clamps pull a candidate further away).
+    TK_PROF_MARK(ps0_);
     SP cand[8];
     const SubPel ctr = luma_setup(base, a.sign, a.width, a.height, a.fwidth, a.fheight, a.xpos, a.ypos, a.enable_bipred);
     int in_window = 1;
@@ -529,8 +530,22 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
       if (dy < 0 || dy > 2 || dx < 0 || dx > 2) in_window = 0;
     }
     unsigned long long k;
+    TK_PROF_ACC(w, 5, ps0_);
+    TK_PROF_MARK(ps1_);
     if (in_window) {
       int sad8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      // per-candidate parameters are identical in every lane: keep them in scalar registers
+      PackedTaps ptap[8];
+      SubPel usp[8];
+      int udy[8], udx[8];
+      for (int c = 0; c < 8; c++) {
+        usp[c] = cand[c].sp;
+        usp[c].ver_frac = tk_uniform(usp[c].ver_frac); usp[c].hor_frac = tk_uniform(usp[c].hor_frac);
+        for (int m = 0; m < 6; m++) { usp[c].tv[m] = tk_uniform(usp[c].tv[m]); usp[c].th[m] = tk_uniform(usp[c].th[m]); }
+        ptap[c] = pack_taps(usp[c]);
+        udy[c] = tk_uniform(cand[c].sp.ver_int - ctr.ver_int + 1);
+        udx[c] = tk_uniform(cand[c].sp.hor_int - ctr.hor_int + 1);
+      }
       for (int r = t.rank; r < a.width * a.height; r += t.size) {
         int i, j;
         split2(dw, r, i, j);
@@ -538,13 +553,26 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
         WinRow<PIX> win[8];
         for (int q = 0; q < 8; q++) win_load(p0 + q * a.rstride, win[q]);
         const int o = (int)org[i * a.ostride + j];
-        for (int c = 0; c < 8; c++) {
-          const int dy = cand[c].sp.ver_int - ctr.ver_int + 1, dx = cand[c].sp.hor_int - ctr.hor_int + 1;
-          WinRow<PIX> rows[6];
-          for (int m = 0; m < 6; m++) rows[m] = win_pick(win[m], win[m + 1], win[m + 2], dy, dx);
-          sad8[c] += iabs(o - luma_sample_win<PIX>(rows, cand[c].sp, a.enable_bipred, a.bitdepth));
+        if constexpr (sizeof(PIX) == 1) {
+          for (int q = 0; q < 8; q++) win[q] = win_bias(win[q]);
+          for (int c = 0; c < 8; c++) {
+            WinRow<PIX> rows[6];
+            const int dx8 = 8 * udx[c];
+            if (udy[c] == 0) { for (int m = 0; m < 6; m++) rows[m].a = win[m].a >> dx8; }
+            else if (udy[c] == 1) { for (int m = 0; m < 6; m++) rows[m].a = win[m + 1].a >> dx8; }
+            else { for (int m = 0; m < 6; m++) rows[m].a = win[m + 2].a >> dx8; }
+            sad8[c] += iabs(o - luma_sample_win8(rows, usp[c], ptap[c], a.enable_bipred));
+          }
+        } else {
+          for (int c = 0; c < 8; c++) {
+            const int dy = cand[c].sp.ver_int - ctr.ver_int + 1, dx = cand[c].sp.hor_int - ctr.hor_int + 1;
+            WinRow<PIX> rows[6];
+            for (int m = 0; m < 6; m++) rows[m] = win_pick(win[m], win[m + 1], win[m + 2], dy, dx);
+            sad8[c] += iabs(o - luma_sample_win<PIX>(rows, cand[c].sp, a.enable_bipred, a.bitdepth));
+          }
         }
       }
+      TK_PROF_ACC(w, 10, ps1_);
       k = ~0ull;
       for (int c = 0; c < 8; c++) {
         const int tot = team_sum(t, sad8[c]);
