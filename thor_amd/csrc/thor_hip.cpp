@@ -1,8 +1,8 @@
 // thor_hip.cpp - libthor_hip.so: gfx950 kernels, device backend and the C ABI (include/thor_hip.h).
-// One 64-lane wavefront (= one workgroup) encodes one 128x128 superblock; superblocks of a frame
-// run in anti-diagonal waves (SB(k,l) needs (k,l-1) and (k-1,l+1)), one
-// kernel launch per wave covering every stream.  There is NO CPU path in this library: every
-// entry point aborts if no HIP device is usable.
+// One 64-lane wavefront (= one workgroup) encodes one 128x128 superblock at a time; one persistent,
+// dependency-driven launch per frame covers every superblock of every stream (SB(k,l) needs (k,l-1) and
+// (k-1,l+1)).  There is NO CPU path in this library: every entry point aborts if no
+// HIP device is usable.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>

@@ -49,34 +49,6 @@ TK_DEV void add_mvcand(MeWs* w, int r, mv_t mv) {
   w->mvcand_mask[r] |= m;
 }
 
-// sad[c] = sum over w x h of |org - F(c, i, j)| for c < ncand.
-template <typename PIX, class F>
-TK_DEV void sad_many(const Team t, int* sad, int ncand, const PIX* org, int ostride, int w, int h, F sample) {
-  for (int c = t.rank; c < ncand; c += t.size) sad[c] = 0;
-  t.sync();
-  const int npix = w * h;
-  if (npix >= t.size) {
-    for (int c = 0; c < ncand; c++) {
-      int local = 0;
-      for (int k = t.rank; k < npix; k += t.size) {
-        int i, j;
-        split2(mk_div(w), k, i, j);
-        local += iabs((int)org[i * ostride + j] - sample(c, i, j));
-      }
-      team_add(&sad[c], local);
-    }
-  } else {
-    for (int it = t.rank; it < ncand * npix; it += t.size) {
-      int c, k;
-      split2(mk_div(npix), it, c, k);
-      int i, j;
-      split2(mk_div(w), k, i, j);
-      team_add(&sad[c], iabs((int)org[i * ostride + j] - sample(c, i, j)));
-    }
-  }
-  t.sync();
-}
-
 // |a-b| summed over 4 horizontally adjacent samples (a: 4-sample aligned, b: any alignment).
 template <typename PIX> TK_DEV int sad4(const PIX* a, const PIX* b) {
   return iabs((int)a[0] - (int)b[0]) + iabs((int)a[1] - (int)b[1]) + iabs((int)a[2] - (int)b[2]) + iabs((int)a[3] - (int)b[3]);

@@ -132,49 +132,12 @@ TK_DEV void fwd_transform_block(const Team t, XformWs* ws, int size, int bitdept
   fwd_core(t, ws, size, size, ilog2(size) + bitdepth - 8);
 }
 
-// quantize (encode_block.c:84-160), serial zigzag state machine. Returns cbp (0/1).
-TK_DEV int quantize_serial(const int16_t* coef, int16_t* coefq, int qp, int size, int intra_block) {
-  const int qsize = size < kMaxQuant ? size : kMaxQuant;
-  const int N = qsize * qsize;
-  const int16_t* izz = qsize == 4 ? TK_TAB.izz4 : (qsize == 8 ? TK_TAB.izz8 : TK_TAB.izz16);
-  const int64_t scale = quant_scale(qp % 6);
-  const int shift2 = 21 - ilog2(size) + qp / 6;
-  int64_t offset = (int64_t)(intra_block ? 38 : -26) << (shift2 - 8);
-  if (!intra_block) offset = -((int64_t)26 << (shift2 - 8));
-  int level = 0, pos = N - 1;
-  while (level == 0 && pos >= 0) {
-    int c = coef[izz[pos]];
-    int64_t l64 = (int64_t)iabs(c) * scale + offset;
-    level = (int)((l64 > 0 ? l64 : -l64) >> shift2);
-    pos--;
-  }
-  const int last_pos = level ? pos + 1 : pos;
-  const int64_t off0 = (int64_t)(intra_block ? 102 : 51) << (shift2 - 8);
-  const int64_t off1 = (int64_t)(intra_block ? 115 : 90) << (shift2 - 8);
-  int cbp = 0, level_mode = 1;
-  for (int p = 0; p < N; p++) {
-    int q = 0;
-    if (p <= last_pos) {
-      int c = coef[izz[p]];
-      int64_t ac = scale * (int64_t)iabs(c);
-      int level0 = (int)(ac >> shift2);
-      int64_t off = (level0 > (1 - level_mode)) ? off1 : off0;
-      int lev = (int)((ac + off) >> shift2);
-      q = c < 0 ? -lev : lev;
-      cbp |= (lev != 0);
-      if (level_mode) { if (lev == 0) level_mode = 0; }
-      else if (lev > 1) level_mode = 1;
-    }
-    coefq[izz[p]] = (int16_t)q;
-  }
-  return cbp;
-}
-
-// Same function as quantize_serial, evaluated W = team.size scan positions at a time.
+// quantize (encode_block.c:84-160): zigzag scan with the `level_mode` state machine, evaluated W = team.size scan
+// positions at a time.
 // The level_mode state is a 2-state automaton whose per-coefficient transition is one of
 // {identity, ->0, ->1} (never a swap, because the level under mode 1 is >= the level under mode 0),
 // so the state entering a position is the target of the nearest earlier constant transition; a
-// ballot + count-leading-zeros finds it.  With W = 1 this is literally the serial loop.
+// ballot + count-leading-zeros finds it.  With W = 1 this is literally the reference's serial loop.
 TK_DEV int quantize_team(const Team t, XformWs* ws, int16_t* coefq, int qp, int size, int intra_block) {
   const int qsize = size < kMaxQuant ? size : kMaxQuant;
   const int N = qsize * qsize;
