@@ -21,3 +21,19 @@ int ref_coeff_bits(int16_t* coeff, int size, int type) {
   write_coeff(&s, coeff, size, type);
   return get_bit_pos(&s);
 }
+
+/* encoder_speed > 0 sub-pel approximations (file-static in encode_block.c) and their SIMD twins */
+unsigned ref_fasthalf(uint8_t* a, uint8_t* b, int as, int bs, int w, int h, int* x, int* y, int simd) {
+  if (simd) return sad_calc_fasthalf_simd_lbd(a, b, as, bs, w, h, x, y);
+  return sad_calc_fasthalf(a, b, as, bs, w, h, x, y);
+}
+unsigned ref_fastquarter(uint8_t* o, uint8_t* r, int os, int rs, int w, int h, int* x, int* y, int simd) {
+  if (simd) return sad_calc_fastquarter_simd_lbd(o, r, os, rs, w, h, x, y);
+  return sad_calc_fastquarter(o, r, os, rs, w, h, x, y);
+}
+int ref_clpf_sample(int X, int A, int B, int C, int D, int E, int F, int G, int H, int s, unsigned dmp) { return clpf_sample(X, A, B, C, D, E, F, G, H, s, dmp); }
+void ref_detect_multi_clpf(const uint8_t* rec, const uint8_t* org, int x0, int y0, int width, int height, int ostride, int rstride, int* sum,
+                           unsigned shift, unsigned size, unsigned dmp, int simd) {
+  if (simd) detect_multi_clpf_simd_lbd(rec, org, x0, y0, width, height, ostride, rstride, sum, shift, size, dmp);
+  else detect_multi_clpf_lbd(rec, org, x0, y0, width, height, ostride, rstride, sum, shift, size, dmp);
+}

@@ -4,8 +4,9 @@
  * used as the checker for the kernel-level entry points of libthor_hip.so (tests/ and
  * __graft_entry__.smoke()).  Every function cites the reference code it follows.  The restatement
  * is pinned: tests/test_oracle_c.py checks it against known-answer vectors recorded from the real
- * reference functions (tests/golden/kat.npz, produced by tests/golden/gen_kat.py through
- * oracle/_ref/libthorref.so), and, when /root/reference is present, against the live reference.
+ * reference functions (tests/golden/kat.npz and kat2.npz, produced by tests/golden/gen_kat.py / gen_kat2.py
+ * through oracle/_ref/libthorref.so; both the scalar C and the SIMD variant of every reference function are run
+ * by the generators and must agree), and, when /root/reference is present, against the live reference.
  * The frame-level oracle is the reference encoder itself (oracle/_ref/Thorenc).
  *
  * 8-bit samples, 4:2:0.  Build: gcc -O2 -std=c99 -fPIC -shared -ffp-contract=off
@@ -275,4 +276,113 @@ int orc_coeff_bits(const int16_t* coeff, int size, int type) {
   if (pos < N && level_mode) { bits += vlc_len(adaptive, 0); pos++; }
   if (pos < N) bits += vlc_len(runtab, eob);
   return bits;
+}
+
+/* ---- encoder_speed > 0 bilinear sub-pel approximations -------------------------------------------------
+ * sad_calc_fasthalf (enc/encode_block.c:174-283; SIMD twin enc_kernels.c:330-513): SADs of the eight half-pel
+ * neighbours of the block at b, each neighbour built from rounding ("avg", (x+y+1)>>1) and truncating ("rd",
+ * (x+y)>>1) two-sample averages; returns the smallest SAD and writes its offset (+-2 quarter-pel units).
+ * Evaluation order of the strict-'<' scan: top (initial), down, right, left, tl, tr, br, bl. */
+static int av2(int x, int y) { return (x + y + 1) >> 1; }
+static int rd2(int x, int y) { return (x + y) >> 1; }
+unsigned orc_fast_halfpel(const uint8_t* a, const uint8_t* b, int as, int bs, int w, int h, int* bx, int* by) {
+  unsigned s[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* top, down, right, left, tl, tr, br, bl */
+  for (int i = 0; i < h; i++)
+    for (int j = 0; j < w; j++) {
+      const uint8_t* c = b + i * bs + j;
+#define B(dy, dx) ((int)c[(dy) * bs + (dx)])
+      int o = a[i * as + j];
+      int hl = av2(B(0, -1), B(0, 0)), hr = av2(B(0, 0), B(0, 1));
+      int vu = av2(B(-2, 0), B(1, 0)), vd = av2(B(-1, 0), B(2, 0));
+      int wl = av2(B(0, -2), B(0, 1)), wr = av2(B(0, -1), B(0, 2));
+      int ptl = rd2(rd2(rd2(av2(B(-2, -1), B(1, -1)), vu), rd2(av2(B(-1, -2), B(-1, 1)), wl)), rd2(av2(B(-1, -1), B(-1, 0)), hl));
+      int ptr = rd2(rd2(rd2(vu, av2(B(-2, 1), B(1, 1))), rd2(wr, av2(B(-1, -1), B(-1, 2)))), rd2(av2(B(-1, 0), B(-1, 1)), hr));
+      int pbl = rd2(rd2(rd2(vd, av2(B(-1, -1), B(2, -1))), rd2(wl, av2(B(1, -2), B(1, 1)))), rd2(av2(B(1, -1), B(1, 0)), hl));
+      int pbr = rd2(rd2(rd2(vd, av2(B(-1, 1), B(2, 1))), rd2(wr, av2(B(1, -1), B(1, 2)))), rd2(hr, av2(B(1, 0), B(1, 1))));
+      s[0] += abs(o - av2(B(0, 0), B(-1, 0))); s[1] += abs(o - av2(B(0, 0), B(1, 0)));
+      s[2] += abs(o - hr); s[3] += abs(o - hl);
+      s[4] += abs(o - ptl); s[5] += abs(o - ptr); s[6] += abs(o - pbr); s[7] += abs(o - pbl);
+#undef B
+    }
+  static const int ox[8] = {0, 0, 2, -2, -2, 2, 2, -2}, oy[8] = {-2, 2, 0, 0, -2, -2, 2, 2};
+  unsigned best = s[0];
+  int k = 0;
+  for (int q = 1; q < 8; q++)
+    if (s[q] < best) { best = s[q]; k = q; }
+  *bx = ox[k]; *by = oy[k];
+  return best;
+}
+
+/* sad_calc_fastquarter (enc/encode_block.c:286-415): the eight quarter-pel neighbours of a position whose half-pel
+ * phase is (*x != 0, *y != 0) on entry; order of the strict-'<' scan: top (initial), tl, tr, left, right, bl, down, br. */
+unsigned orc_fast_quarterpel(const uint8_t* o_, const uint8_t* r_, int os, int rs, int w, int h, int* x, int* y) {
+  unsigned s[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* top, tl, tr, left, right, bl, down, br */
+  const int hx = *x != 0, hy = *y != 0;
+  for (int i = 0; i < h; i++)
+    for (int j = 0; j < w; j++) {
+      const uint8_t* c = r_ + i * rs + j;
+      int o = o_[i * os + j], a = c[0], d = c[1], f = c[rs];
+      int p[8];
+      if (hx && hy) {
+        int e = c[rs + 1], ad = av2(a, d), de = av2(d, e), af = av2(a, f), fe = av2(f, e);
+        p[1] = (ad + af) >> 1; p[0] = (de + a) >> 1; p[2] = (ad + de) >> 1; p[3] = (ad + f) >> 1; p[4] = (ad + e) >> 1;
+        p[5] = (af + fe) >> 1; p[6] = (de + f) >> 1; p[7] = (de + fe) >> 1;
+      } else if (hx) {
+        int b = c[-rs], cc = c[-rs + 1], e = c[rs + 1], ad = av2(a, d), de = av2(d, e), dc = av2(d, cc), af = av2(a, f), ab = av2(a, b);
+        p[1] = (ad + ab) >> 1; p[0] = (dc + a) >> 1; p[2] = (ad + dc) >> 1; p[3] = (ad + a) >> 1; p[4] = (ad + d) >> 1;
+        p[5] = (ad + af) >> 1; p[6] = (af + d) >> 1; p[7] = (ad + de) >> 1;
+      } else if (hy) {
+        int e = c[rs + 1], g = c[rs - 1], hh = c[-1], ad = av2(a, d), af = av2(a, f), fe = av2(f, e), ah = av2(a, hh), gf = av2(g, f);
+        p[1] = (ah + af) >> 1; p[0] = (af + a) >> 1; p[2] = (ad + af) >> 1; p[3] = (gf + a) >> 1; p[4] = (ad + f) >> 1;
+        p[5] = (af + gf) >> 1; p[6] = (af + f) >> 1; p[7] = (af + fe) >> 1;
+      } else {
+        int b = c[-rs], hh = c[-1], ad = av2(a, d), af = av2(a, f), ah = av2(a, hh), ab = av2(a, b);
+        p[1] = (ah + ab) >> 1; p[0] = (ab + a) >> 1; p[2] = (ad + ab) >> 1; p[3] = (ah + a) >> 1; p[4] = (ad + a) >> 1;
+        p[5] = (ah + af) >> 1; p[6] = (af + a) >> 1; p[7] = (af + ad) >> 1;
+      }
+      for (int q = 0; q < 8; q++) s[q] += abs(o - p[q]);
+    }
+  static const int ox[8] = {0, -1, 1, -1, 1, -1, 0, 1}, oy[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+  unsigned best = s[0];
+  int k = 0;
+  for (int q = 1; q < 8; q++)
+    if (s[q] < best) { best = s[q]; k = q; }
+  *x = ox[k]; *y = oy[k];
+  return best;
+}
+
+/* ---- CLPF -------------------------------------------------------------------------------------------------
+ * constrain (common/common_block.c:217-221) and clpf_sample (:315-321): cross-shaped 8-tap low-pass of the
+ * constrained differences, weights 1 3 1 3 | 3 1 3 1 for A B C D | E F G H, rounded towards zero on a 1/16 grid. */
+static int orc_constrain(int diff, int thr, int damping) {
+  if (!thr) return 0;
+  int ad = abs(diff), lim = thr - (ad >> (damping - ilog2((unsigned)thr)));
+  if (lim < 0) lim = 0;
+  int m = ad < lim ? ad : lim;
+  return diff < 0 ? -m : m;
+}
+int orc_clpf_sample(int X, int A, int B, int C, int D, int E, int F, int G, int H, int s, int dmp) {
+  int delta = orc_constrain(A - X, s, dmp) + 3 * orc_constrain(B - X, s, dmp) + orc_constrain(C - X, s, dmp) + 3 * orc_constrain(D - X, s, dmp) +
+              3 * orc_constrain(E - X, s, dmp) + orc_constrain(F - X, s, dmp) + 3 * orc_constrain(G - X, s, dmp) + orc_constrain(H - X, s, dmp);
+  return (8 + delta - (delta < 0)) >> 4;
+}
+/* detect_multi_clpf (enc/encode_block.c:2584-2621): squared error of one size x size block against the original,
+ * unfiltered and filtered with strengths 1, 2, 4 (<< shift), neighbours clamped to the frame. sum[0..3] += ... */
+void orc_detect_multi_clpf(const uint8_t* rec, const uint8_t* org, int x0, int y0, int width, int height, int ostride, int rstride,
+                           int* sum, int shift, int size, int dmp) {
+  unsigned s[4] = {0, 0, 0, 0};
+  for (int y = y0; y < y0 + size; y++)
+    for (int x = x0; x < x0 + size; x++) {
+      int ym2 = y - 2 < 0 ? 0 : y - 2, ym1 = y - 1 < 0 ? 0 : y - 1, yp1 = y + 1 > height - 1 ? height - 1 : y + 1, yp2 = y + 2 > height - 1 ? height - 1 : y + 2;
+      int xm2 = x - 2 < 0 ? 0 : x - 2, xm1 = x - 1 < 0 ? 0 : x - 1, xp1 = x + 1 > width - 1 ? width - 1 : x + 1, xp2 = x + 2 > width - 1 ? width - 1 : x + 2;
+      int O = org[y * ostride + x], X = rec[y * rstride + x];
+      int A = rec[ym2 * rstride + x], B = rec[ym1 * rstride + x], Cc = rec[y * rstride + xm2], D = rec[y * rstride + xm1];
+      int E = rec[y * rstride + xp1], F = rec[y * rstride + xp2], G = rec[yp1 * rstride + x], H = rec[yp2 * rstride + x];
+      s[0] += (unsigned)((O - X) * (O - X));
+      for (int k = 1; k < 4; k++) {
+        int Y = X + orc_clpf_sample(X, A, B, Cc, D, E, F, G, H, (1 << (k - 1)) << shift, dmp);
+        s[k] += (unsigned)((O - Y) * (O - Y));
+      }
+    }
+  for (int k = 0; k < 4; k++) sum[k] += (int)(s[k] >> (shift * 2));
 }

@@ -59,3 +59,39 @@ def test_tu_pipeline_and_coeff_bits():
                 assert O.orc_coeff_bits(vp(cq), size, ctype) == K[f'tu_bits{k}'][i], ('bits', k, i)
         k += 1
     assert k == 24
+
+
+K2 = np.load(os.path.join(GOLD, 'kat2.npz'))
+
+
+def test_fast_subpel_approximations():
+    """encoder_speed > 0: sad_calc_fasthalf / sad_calc_fastquarter (enc/encode_block.c:174, :286)."""
+    plane = np.ascontiguousarray(K2['fs_plane'])
+    k = 0
+    while f'fs_geo{k}' in K2:
+        w, h, bx, by = [int(v) for v in K2[f'fs_geo{k}']]
+        org = np.ascontiguousarray(K2[f'fs_org{k}'])
+        base = C.c_void_p(int(plane.ctypes.data) + by * 112 + bx)
+        x, y = C.c_int(0), C.c_int(0)
+        O.orc_fast_halfpel.restype = C.c_uint
+        s = O.orc_fast_halfpel(vp(org), base, w, 112, w, h, C.byref(x), C.byref(y))
+        assert [s, x.value, y.value] == [int(v) for v in K2[f'fs_half{k}']], ('half', k)
+        for hx, hy, ws, wx, wy in K2[f'fs_quarter{k}']:
+            x, y = C.c_int(int(hx)), C.c_int(int(hy))
+            O.orc_fast_quarterpel.restype = C.c_uint
+            s = O.orc_fast_quarterpel(vp(org), base, w, 112, w, h, C.byref(x), C.byref(y))
+            assert [s, x.value, y.value] == [int(ws), int(wx), int(wy)], ('quarter', k, int(hx), int(hy))
+        k += 1
+    assert k == 36
+
+
+def test_clpf_sample_and_block_statistics():
+    """CLPF: clpf_sample (common/common_block.c:315) and detect_multi_clpf (enc/encode_block.c:2584)."""
+    got = [O.orc_clpf_sample(*[int(t) for t in row], int(s), int(d)) for row, (s, d) in zip(K2['cs_in'], K2['cs_par'])]
+    assert (np.array(got) == K2['cs_out']).all()
+    org, rec = np.ascontiguousarray(K2['dm_org']), np.ascontiguousarray(K2['dm_rec'])
+    H, W = org.shape
+    for (x0, y0, dmp), want in zip(K2['dm_blocks'], K2['dm_sums']):
+        s = (C.c_int * 4)(0, 0, 0, 0)
+        O.orc_detect_multi_clpf(vp(rec), vp(org), int(x0), int(y0), W, H, W, W, s, 0, 8, int(dmp))
+        assert list(s) == [int(v) for v in want], (int(x0), int(y0), int(dmp))
