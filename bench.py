@@ -26,7 +26,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 CFG = os.path.join(ROOT, 'configs', 'ldb_high_efficiency.cfg')
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 
@@ -121,10 +120,10 @@ def main():
         dist.init_process_group('nccl')
 
     import thor_amd
-    import gen_clip
+    from thor_amd import synth
     w, h, S = a.width, a.height, a.streams
     nframes = a.warmup + a.steps
-    base = gen_clip.make_clip(w, h, nframes + 3, 2, 2.0)  # BASELINE cfg 2 content model, seed 2
+    base = synth.make_clip(w, h, nframes + 3, 2, 2.0)  # BASELINE cfg 2 content model, seed 2
     p = thor_amd.load_config(CFG, width=w, height=h, qp=a.qp, f=30)
     enc = thor_amd.Encoder(p, S, device=local_rank)
     first = None

@@ -5,8 +5,8 @@ Usage: parity_matrix.py [--jobs 8] [--out /tmp/pm] [--quick]"""
 import argparse, itertools, os, subprocess, sys, hashlib
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-import gen_clip
+sys.path.insert(0, ROOT)
+from thor_amd import synth as gen_clip
 
 def run_case(case, out, sim):
     w, h, frames, seed, sigma, qp, extra = case[:7]

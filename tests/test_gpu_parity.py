@@ -51,8 +51,7 @@ def test_two_streams_equal_two_reference_chunks():
 
 @pytest.mark.skipif(not os.path.exists(REF_ENC), reason='oracle/_ref/Thorenc not in the snapshot')
 def test_live_reference_cif_hard_clip():
-    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    import gen_clip
+    from thor_amd import synth as gen_clip
     clip = b''.join(p.tobytes() for fr in gen_clip.make_clip(352, 288, 5, 7, 6.0) for p in fr)
     rb, rr = run_encoder(REF_ENC, clip, 352, 288, 5, 32)
     bits, rec = encode_gpu(clip, 352, 288, 5, 32)
@@ -62,8 +61,7 @@ def test_live_reference_cif_hard_clip():
 @pytest.mark.skipif(not os.path.exists(REF_ENC), reason='oracle/_ref/Thorenc not in the snapshot')
 def test_full_size_1080p_vs_reference_and_roundtrip():
     """BASELINE config 2 geometry: 1920x1080 (last SB row is 56 px: rectangular-skip path), I + P."""
-    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    import gen_clip
+    from thor_amd import synth as gen_clip
     clip = b''.join(p.tobytes() for fr in gen_clip.make_clip(1920, 1080, 2, 2, 2.0) for p in fr)
     rb, rr = run_encoder(REF_ENC, clip, 1920, 1080, 2, 32)
     bits, rec = encode_gpu(clip, 1920, 1080, 2, 32)
@@ -97,8 +95,7 @@ def test_dropin_front_end_hierarchical_b(name):
 @pytest.mark.skipif(not os.path.exists(REF_ENC), reason='oracle/_ref/Thorenc not in the snapshot')
 def test_live_reference_random_access_17_frames():
     """RA operating point (sub-GOP 8, interpolated refs) over two sub-GOPs + tail, 416x240, through the CLI tool."""
-    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    import gen_clip
+    from thor_amd import synth as gen_clip
     clip = b''.join(p.tobytes() for fr in gen_clip.make_clip(416, 240, 19, 7, 2.0) for p in fr)
     rb, rr = run_encoder(REF_ENC, clip, 416, 240, 19, 30, cfg='ra_high_efficiency.cfg')
     bits, rec = run_encoder(os.path.join(ROOT, 'tools', 'thorenc_hip'), clip, 416, 240, 19, 30, cfg='ra_high_efficiency.cfg')

@@ -28,10 +28,9 @@ def golden_streams():
 
 
 def golden_clip(name):
-    """Committed clip, or 'gen:w,h,frames,seed,sigma' = the seeded synthetic generator (oracle/gen_clip.py)."""
+    """Committed clip, or 'gen:w,h,frames,seed,sigma' = the seeded synthetic generator (thor_amd/synth.py)."""
     if name.startswith('gen:'):
-        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-        import gen_clip
+        from thor_amd import synth as gen_clip
         w, h, n, seed, sigma = name[4:].split(',')
         return b''.join(p.tobytes() for fr in gen_clip.make_clip(int(w), int(h), int(n), int(seed), float(sigma)) for p in fr)
     return gzip.open(os.path.join(GOLD, name)).read()
