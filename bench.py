@@ -5,8 +5,10 @@
 Workload ("step"): one lock-step frame of S independent closed streams (sequence chunks - the only
 partition of this path that is bit-exact, SURVEY.md 8e: stream s is exactly what the reference
 produces with -skip/-n for its chunk).  Warm-up steps include each stream's I frame; the timed K
-steps are the following P frames (the low-delay GOP has one I frame per chunk).  Inputs are staged
-in HBM before the timed region.  value = luma pixels coded by all ranks / max-over-ranks wall time.
+steps are the following P frames (the low-delay GOP has one I frame per chunk).  Defaults: warm-up 1 (the I
+frame) + 4 timed P frames, so that the last timed frame searches all 4 reference frames of the operating
+point ("I+4P so all 4 refs are exercised").  Inputs are staged in HBM before the
+timed region.  value = luma pixels coded by all ranks / max-over-ranks wall time.
 S defaults to 1024 per GPU: a frame's superblock dependency chain is ~32 superblocks long and the
 kernel keeps 3072 wavefronts resident, so fewer than ~730 streams cannot fill the chip.
 
@@ -99,7 +101,7 @@ def cpu_baseline(frames, w, h, warmup, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=4)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--streams', type=int, default=int(os.environ.get('THOR_BENCH_STREAMS', '1024')), help='streams PER GPU')
     ap.add_argument('--width', type=int, default=1920)
@@ -156,7 +158,8 @@ def main():
     if rank == 0:
         # roofline of the dominant kernel (k_superblocks): algorithmic HBM bytes per luma pixel of a
         # P frame with R references = 1.5 * (1 orig + R refs + 1 rec) (block-path terms).
-        R = min(4, a.warmup + a.steps - 1) if a.steps else 0
+        # frame f of a chunk (f >= 1) references min(max_num_ref, f) earlier frames: average over the timed frames
+        R = sum(min(int(p.max_num_ref), f) for f in range(a.warmup, nframes)) / max(a.steps, 1)
         bytes_per_px = 1.5 * (2 + R)
         alg_bytes_per_launch = (w * h * a.steps * S * bytes_per_px) / max(launches, 1)
         avg_launch_s = (sb_ms / 1e3) / max(launches, 1)
@@ -172,7 +175,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 4), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 8), 'traffic': None,
                          'kernel': 'k_superblocks', 'launches': launches, 'avg_launch_ms': round(avg_launch_s * 1e3, 3),
-                         'alg_bytes_per_px': bytes_per_px,
+                         'alg_bytes_per_px': round(bytes_per_px, 3),
                          'note': 'one persistent dependency-driven launch per frame; path is latency/VALU-bound, not HBM-bound (SURVEY.md 0.7); filters+ref kernels took %.1f ms' % filt_ms},
         }
         if not a.no_cpu_baseline and world == 1:
