@@ -44,18 +44,24 @@ def stream_ids(total, world, rank):
     return list(range(start, start + parts[rank]))
 
 
+def _reduce_device(dist):
+    """Collectives run on the GPU with RCCL (backend "nccl") and on the host with gloo (CPU tests)."""
+    import torch
+    return torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+
+
 def reduce_max_time(t, dist):
     import torch
-    x = torch.tensor([t], dtype=torch.float64)
+    x = torch.tensor([t], dtype=torch.float64, device=_reduce_device(dist))
     dist.all_reduce(x, op=dist.ReduceOp.MAX)
-    return float(x[0])
+    return float(x.item())
 
 
 def reduce_sum(v, dist):
     import torch
-    x = torch.tensor([v], dtype=torch.float64)
+    x = torch.tensor([v], dtype=torch.float64, device=_reduce_device(dist))
     dist.all_reduce(x, op=dist.ReduceOp.SUM)
-    return float(x[0])
+    return float(x.item())
 
 
 # ---- synthetic input -------------------------------------------------------------------------------
