@@ -9,13 +9,14 @@ _LIB = None
 
 
 def lib_path():
-    return os.path.join(REPO_ROOT, 'thor_amd', 'libthor_hip.so')
+    """In-tree library; THOR_HIP_LIB selects another build of it (A/B measurements of kernel variants)."""
+    return os.environ.get('THOR_HIP_LIB') or os.path.join(REPO_ROOT, 'thor_amd', 'libthor_hip.so')
 
 
 def build_native(force=False):
     """Compile libthor_hip.so (gfx950) and the C front end in-tree with hipcc/gcc."""
     src = os.path.join(REPO_ROOT, 'thor_amd', 'csrc', 'thor_hip.cpp')
-    out = lib_path()
+    out = os.path.join(REPO_ROOT, 'thor_amd', 'libthor_hip.so')
     hdrs = [os.path.join(REPO_ROOT, 'thor_amd', 'csrc', f) for f in os.listdir(os.path.join(REPO_ROOT, 'thor_amd', 'csrc'))]
     hdrs += [os.path.join(REPO_ROOT, 'include', f) for f in os.listdir(os.path.join(REPO_ROOT, 'include'))]
     newest = max(os.path.getmtime(h) for h in hdrs)
