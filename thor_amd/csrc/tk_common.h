@@ -138,6 +138,31 @@ TK_DEV int tk_uniform(int v) {
   return __builtin_amdgcn_readfirstlane(v);
 #endif
 }
+// EXPERIMENTAL (-DTHOR_EXP_UNIFORM, off by default, not yet measured on the GPU): scalarise more wave-uniform values
+// of the motion search.  TKU*/tk_uniform* are identities when the flag is off, so the default build is unchanged.
+TK_DEV unsigned long long tk_uniform64(unsigned long long v) {
+#if TK_HOST
+  return v;
+#else
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+#endif
+}
+TK_DEV double tk_uniform_f64(double d) {
+  unsigned long long b;
+  __builtin_memcpy(&b, &d, 8);
+  b = tk_uniform64(b);
+  __builtin_memcpy(&d, &b, 8);
+  return d;
+}
+#ifdef THOR_EXP_UNIFORM
+#define TKU(x) tk_uniform(x)
+#define TKU64(x) tk_uniform64(x)
+#else
+#define TKU(x) (x)
+#define TKU64(x) (x)
+#endif
 // sum over the team, result in every lane (xor-shuffle butterfly; identity for a 1-lane team)
 TK_DEV unsigned long long team_sum64(const Team t, unsigned long long v) {
 #if TK_HOST

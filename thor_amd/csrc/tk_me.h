@@ -118,7 +118,7 @@ TK_DEV unsigned long long eval_min(const Team t, int n, int nit, PrepF prep, Ite
       if (vb) { unsigned long long k = ((unsigned long long)cost(cb, xb, lb) << 32) | (unsigned)cb; best = k < best ? k : best; }
     }
   }
-  return team_min64(t, best);
+  return TKU64(team_min64(t, best));
 }
 
 // 4-sample load helpers for the packed SAD
@@ -207,7 +207,7 @@ TK_DEV unsigned long long eval_fullpel(const Team t, int n, const PIX* org, int 
       if (vb) { unsigned long long k = ((unsigned long long)cost(xb, sb) << 32) | (unsigned)cb; best = k < best ? k : best; }
     }
   }
-  return team_min64(t, best);
+  return TKU64(team_min64(t, best));
 }
 
 struct MeArgs {
@@ -315,9 +315,23 @@ template <typename PIX> TK_DEV unsigned fast_quarterpel(const Team t, const PIX*
 }
 
 template <typename PIX>
-TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const PIX* ref, const MeArgs& a, mv_t mvc,
+TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const PIX* ref, const MeArgs& a_in, mv_t mvc,
                                 mv_t mvp, int ref_idx, mv_t* mv_out) {
   TK_PROF_T0();
+#ifdef THOR_EXP_UNIFORM
+  MeArgs a_u;
+  a_u.cb_size = tk_uniform(a_in.cb_size); a_u.ostride = tk_uniform(a_in.ostride); a_u.width = tk_uniform(a_in.width);
+  a_u.height = tk_uniform(a_in.height); a_u.rstride = tk_uniform(a_in.rstride); a_u.sign = tk_uniform(a_in.sign);
+  a_u.fwidth = tk_uniform(a_in.fwidth); a_u.fheight = tk_uniform(a_in.fheight); a_u.xpos = tk_uniform(a_in.xpos);
+  a_u.ypos = tk_uniform(a_in.ypos); a_u.enable_bipred = tk_uniform(a_in.enable_bipred); a_u.bitdepth = tk_uniform(a_in.bitdepth);
+  a_u.speed = tk_uniform(a_in.speed); a_u.lam = tk_uniform_f64(a_in.lam);
+  const MeArgs& a = a_u;
+  mvc = mk_mv(tk_uniform(mvc.x), tk_uniform(mvc.y));
+  mvp = mk_mv(tk_uniform(mvp.x), tk_uniform(mvp.y));
+  ref_idx = tk_uniform(ref_idx);
+#else
+  const MeArgs& a = a_in;
+#endif
   const int s = a.sign ? -1 : 1;
   const int sh = a.bitdepth - 8;
   unsigned min_sad = kCostInit;
@@ -372,7 +386,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
         k = kk < k ? kk : k;
       }
       t.sync();
-      k = team_min64(t, k);
+      k = TKU64(team_min64(t, k));
       bestk = k < bestk ? k : bestk;
     }
     return bestk;
@@ -407,7 +421,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
 #endif
   // --- candidate list (encode_block.c:564-581)
   {
-    const int n = w->mvcand_num[ref_idx];
+    const int n = TKU(w->mvcand_num[ref_idx]);
     if (n > 0) {
       const int wide = a.cb_size == 16;
       for (int c = t.rank; c < n; c += t.size) {
