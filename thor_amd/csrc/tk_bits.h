@@ -308,8 +308,37 @@ TK_DEV void bs_coeff_any(BitSink& b, const Team* t, const int16_t* coeff, int si
 
 // ybits (optional, counting mode only): bit lengths of the luma TU coefficient strings already counted by the
 // caller (partial-cost pruning), [0] for an unsplit block, [t] for TU t of a tb-split one.
-TK_DEVNI int bs_block(BitSink& b, const SynCtx& s, const BlkParam& p, const int16_t* cy, const int16_t* cu,
+#ifdef THOR_EXP_UNIFORM
+TK_DEV mv_t uniform_mv(mv_t m) { return mk_mv(tk_uniform(m.x), tk_uniform(m.y)); }
+TK_DEV SynCtx uniform_syn(const SynCtx& a) {
+  SynCtx u;
+  u.frame_type = tk_uniform(a.frame_type); u.num_ref = tk_uniform(a.num_ref); u.enable_bipred = tk_uniform(a.enable_bipred);
+  u.interp_ref = tk_uniform(a.interp_ref); u.max_pb_part = tk_uniform(a.max_pb_part); u.max_tb_part = tk_uniform(a.max_tb_part);
+  u.num_intra_modes = tk_uniform(a.num_intra_modes); u.size = tk_uniform(a.size); u.encode_this_size = tk_uniform(a.encode_this_size);
+  u.ctx_index = tk_uniform(a.ctx_index); u.ctx_cbp = tk_uniform(a.ctx_cbp); u.num_skip = tk_uniform(a.num_skip);
+  u.num_merge = tk_uniform(a.num_merge); u.mvp = uniform_mv(a.mvp);
+  return u;
+}
+TK_DEV BlkParam uniform_blk(const BlkParam& a) {
+  BlkParam u;
+  u.mode = (int8_t)tk_uniform(a.mode); u.intra_mode = (int8_t)tk_uniform(a.intra_mode); u.skip_idx = (int8_t)tk_uniform(a.skip_idx);
+  u.pb_part = (int8_t)tk_uniform(a.pb_part); u.ref0 = (int8_t)tk_uniform(a.ref0); u.ref1 = (int8_t)tk_uniform(a.ref1);
+  u.dir = (int8_t)tk_uniform(a.dir); u.tb_param = (int8_t)tk_uniform(a.tb_param); u.tb_split = (int8_t)tk_uniform(a.tb_split);
+  u.cbp_y = (uint8_t)tk_uniform(a.cbp_y); u.cbp_u = (uint8_t)tk_uniform(a.cbp_u); u.cbp_v = (uint8_t)tk_uniform(a.cbp_v);
+  for (int i = 0; i < 4; i++) { u.mv0[i] = uniform_mv(a.mv0[i]); u.mv1[i] = uniform_mv(a.mv1[i]); }
+  return u;
+}
+#endif
+
+TK_DEVNI int bs_block(BitSink& b, const SynCtx& s_in, const BlkParam& p_in, const int16_t* cy, const int16_t* cu,
                     const int16_t* cv, const Team* tm, const int* ybits = nullptr) {
+#ifdef THOR_EXP_UNIFORM
+  const SynCtx s = uniform_syn(s_in);
+  const BlkParam p = uniform_blk(p_in);
+#else
+  const SynCtx& s = s_in;
+  const BlkParam& p = p_in;
+#endif
   const int start = b.pos;
   const int size = s.size, size_uv = size >> 1;
   const int mode = p.mode;
