@@ -450,13 +450,13 @@ template <typename PIX>
 TK_DEVNI int encode_block(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BlkParam& p, BitSink& bs,
                           int reuse_pred = 0, PruneCtx* pc = nullptr) {
   const EncCfg& c = J.cfg;
-  const int size = nd.size, sizeC = size >> 1;
-  const int yc = nd.ypos >> 1, xc = nd.xpos >> 1;
-  const int qpY = J.qp, qpC = TK_TAB.chroma_qp[qpY];
-  const int tb_split = p.tb_param > 0 ? p.tb_param : 0;
-  const int zero_block = p.tb_param == -1;
-  const int ftI = (J.frame_type == F_I) << 1;
-  const int bd = c.bitdepth;
+  const int size = TKU(nd.size), sizeC = size >> 1;
+  const int yc = TKU(nd.ypos) >> 1, xc = TKU(nd.xpos) >> 1;
+  const int qpY = TKU(J.qp), qpC = TK_TAB.chroma_qp[qpY];
+  const int tb_split = TKU(p.tb_param) > 0 ? TKU(p.tb_param) : 0;
+  const int zero_block = TKU(p.tb_param) == -1;
+  const int ftI = (TKU(J.frame_type) == F_I) << 1;
+  const int bd = TKU(c.bitdepth);
   p.tb_split = (int8_t)tb_split;
   {
     const int bigc = tb_split && sizeC >= 32;  // 4 chroma TUs of 16x16 coefficients
@@ -468,7 +468,7 @@ TK_DEVNI int encode_block(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
   const PIX* ov = J.orig.v + yc * J.orig.sc + xc;
   int cbp_y = 0, cbp_u = 0, cbp_v = 0;
 
-  if (p.mode == M_INTRA) {
+  if (TKU(p.mode) == M_INTRA) {
     const int ur = upright_avail(nd.ypos, nd.xpos, size, size, c.width, kMaxSb);
     const int dl = downleft_avail(nd.ypos, nd.xpos, size, size, c.height, kMaxSb);
     const PIX* fy = J.rec.y + nd.ypos * J.rec.sy + nd.xpos;
@@ -535,9 +535,9 @@ TK_DEVNI int encode_block(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
                       c.encoder_speed > 1, ws->coef_v, bd);
     }
   } else {
-    const int split = (p.mode == M_INTER || p.mode == M_BIPRED) ? c.enable_pb_split : 0;
+    const int split = (TKU(p.mode) == M_INTER || TKU(p.mode) == M_BIPRED) ? c.enable_pb_split : 0;
     if (!(reuse_pred && !c.cfl_inter)) predict_inter(t, J, ws, nd, p, split);
-    if (p.mode == M_SKIP || zero_block) {
+    if (TKU(p.mode) == M_SKIP || zero_block) {
       copy_block(t, ws->rec_y, size, ws->pred_y, size, nd.bw, nd.bh);
       copy_block(t, ws->rec_u, sizeC, ws->pred_u, sizeC, nd.bw >> 1, nd.bh >> 1);
       copy_block(t, ws->rec_v, sizeC, ws->pred_v, sizeC, nd.bw >> 1, nd.bh >> 1);
