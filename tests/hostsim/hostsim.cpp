@@ -3,6 +3,12 @@
 // executable so that the bit-exactness of the algorithm can be checked against the reference
 // encoder (oracle/_ref/Thorenc) in a container without a GPU.  The product library
 // (thor_amd/csrc/thor_hip.cpp) never links or calls this; it has no CPU path.
+//
+// With -DTHOR_HOSTSIM_LANES=N (N a power of two <= 64, e.g. 8) every superblock is processed by a team of N lanes, each lane
+// an OS thread executing the same SPMD code as a GPU lane; barriers, ballots, shuffles and reductions go through one
+// "every lane publishes a value, all lanes read" exchange.  This exercises the lane-parallel logic of the engine (work
+// distribution, reductions, the ballot automata, uniformity assumptions - tk_uniform() aborts if lanes disagree) without a
+// GPU; a lane that skips a collective deadlocks the run, which is the bug being looked for.
 #include "../../thor_amd/csrc/tk_block.h"
 #include "../../thor_amd/csrc/tk_filters.h"
 #include <math.h>
@@ -21,6 +27,74 @@ size_t team_ws_bytes(int pix_bytes) {
   return pix_bytes == 1 ? sizeof(BigWs<uint8_t>) + sizeof(SmallWs<uint8_t>) : sizeof(BigWs<uint16_t>) + sizeof(SmallWs<uint16_t>);
 }
 
+#ifdef THOR_HOSTSIM_LANES
+}  // namespace backend
+}  // namespace tk
+#include <atomic>
+#include <thread>
+#include <vector>
+namespace tk {
+namespace hostlanes {
+struct Shared {
+  int n = 1;
+  std::atomic<int> count{0};
+  std::atomic<int> sense{0};
+  unsigned long long slots[64];
+};
+static thread_local Shared* tl_sh = nullptr;
+static thread_local int tl_rank = 0;
+static thread_local int tl_sense = 0;
+int lanes() { return tl_sh ? tl_sh->n : 1; }
+int rank() { return tl_rank; }
+void barrier() {
+  Shared* sh = tl_sh;
+  if (!sh || sh->n == 1) return;
+  const int my = tl_sense ^= 1;
+  if (sh->count.fetch_add(1, std::memory_order_acq_rel) == sh->n - 1) {
+    sh->count.store(0, std::memory_order_relaxed);
+    sh->sense.store(my, std::memory_order_release);
+  } else {
+    int spins = 0;
+    while (sh->sense.load(std::memory_order_acquire) != my)
+      if (++spins > 2000) { std::this_thread::yield(); spins = 0; }
+  }
+}
+static unsigned long long tl_single[1];
+const unsigned long long* exchange_begin(unsigned long long v) {
+  Shared* sh = tl_sh;
+  if (!sh || sh->n == 1) { tl_single[0] = v; return tl_single; }
+  sh->slots[tl_rank] = v;
+  barrier();
+  return sh->slots;
+}
+void exchange_end() { barrier(); }
+}  // namespace hostlanes
+namespace backend {
+template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>*, int S) {
+  const int N = THOR_HOSTSIM_LANES;
+  for (int s = 0; s < S; s++) {
+    const FrameJob<PIX>& J = jobs[s];
+    for (int k = 0; k < J.sb_rows; k++)
+      for (int l = 0; l < J.sb_cols; l++) {
+        const int sbi = k * J.sb_cols + l;
+        hostlanes::Shared sh;
+        sh.n = N;
+        std::vector<std::thread> th;
+        for (int r = 0; r < N; r++)
+          th.emplace_back([&, r]() {
+            hostlanes::tl_sh = &sh; hostlanes::tl_rank = r; hostlanes::tl_sense = 0;
+            Team t{r, N};
+            TeamWs<PIX> wsv = make_ws((SmallWs<PIX>*)(J.scratch + sizeof(BigWs<PIX>)), (BigWs<PIX>*)J.scratch);
+            BitSink out;
+            out.buf = J.sb_bits + (size_t)sbi * J.sb_words; out.pos = 0; out.cap = J.sb_words * 32; out.emit = 1; out.ovf = 0;
+            process_sb(t, J, &wsv, k * kMaxSb, l * kMaxSb, out);
+            if (r == 0) { J.sb_nbits[sbi] = out.pos; J.sb_status[sbi] = out.ovf; }
+          });
+        for (auto& x : th) x.join();
+      }
+  }
+}
+#else
 template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>*, int S) {
   Team t{0, 1};
   for (int s = 0; s < S; s++) {
@@ -38,6 +112,7 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
       }
   }
 }
+#endif
 template <typename PIX> void run_deblock(const FrameJob<PIX>* jobs, const FrameJob<PIX>*, int S) {
   for (int s = 0; s < S; s++) {
     const FrameJob<PIX>& J = jobs[s];

@@ -33,3 +33,14 @@ def test_engine_host_simulation_matches_golden(name):
     bits, rec = run_encoder(build_hostsim(), golden_clip(c['clip']), c['w'], c['h'], c['n'], c['qp'], c['extra'], cfg=c.get('cfg'))
     assert md5(bits) == c['bit_md5'], 'stream differs from the reference'
     assert md5(rec) == c['rec_md5'], 'reconstruction differs from the reference'
+
+
+@pytest.mark.parametrize('name', ['192x128_n3_q32', '192x128_n6_q32_ldb_low', '208x120_n4_q30_ldb_medium'])
+def test_engine_multi_lane_host_simulation_matches_golden(name):
+    """The same engine sources with 8-lane teams (one OS thread per lane; ballots, shuffles, reductions and barriers go
+    through a publish/read exchange, tests/hostsim/hostsim.cpp): exercises the lane-parallel logic - work distribution,
+    reductions, ballot automata, uniformity assumptions (tk_uniform aborts if lanes disagree) - without a GPU."""
+    c = G[name]
+    bits, rec = run_encoder(build_hostsim(lanes=8), golden_clip(c['clip']), c['w'], c['h'], c['n'], c['qp'], c['extra'], cfg=c.get('cfg'))
+    assert md5(bits) == c['bit_md5'], 'stream differs from the reference'
+    assert md5(rec) == c['rec_md5'], 'reconstruction differs from the reference'

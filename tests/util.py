@@ -44,14 +44,15 @@ def build_oracle_c():
     return C.CDLL(out)
 
 
-def build_hostsim():
-    """1-lane host simulation of the engine sources (tests only)."""
-    out = os.path.join(ROOT, 'tests', 'hostsim', 'hostsim')
+def build_hostsim(lanes=1):
+    """Host simulation of the engine sources (tests only): 1-lane teams, or `lanes` OS threads per team."""
+    out = os.path.join(ROOT, 'tests', 'hostsim', 'hostsim' if lanes == 1 else f'hostsim_l{lanes}')
     src = os.path.join(ROOT, 'tests', 'hostsim', 'hostsim.cpp')
     csrc = os.path.join(ROOT, 'thor_amd', 'csrc')
     newest = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc)])
     if not os.path.exists(out) or os.path.getmtime(out) < newest:
-        subprocess.check_call(['g++', '-std=c++17', '-O2', '-DTHOR_HOSTSIM', '-ffp-contract=off', '-o', out, src])
+        extra = [] if lanes == 1 else [f'-DTHOR_HOSTSIM_LANES={lanes}', '-pthread']
+        subprocess.check_call(['g++', '-std=c++17', '-O2', '-DTHOR_HOSTSIM', '-ffp-contract=off'] + extra + ['-o', out, src])
     return out
 
 

@@ -333,8 +333,10 @@ TK_DEV BlkParam uniform_blk(const BlkParam& a) {
 TK_DEVNI int bs_block(BitSink& b, const SynCtx& s_in, const BlkParam& p_in, const int16_t* cy, const int16_t* cu,
                     const int16_t* cv, const Team* tm, const int* ybits = nullptr) {
 #ifdef THOR_EXP_UNIFORM
-  const SynCtx s = uniform_syn(s_in);
-  const BlkParam p = uniform_blk(p_in);
+  // only in cooperative counting mode: the emitting call is made by one lane alone
+  const bool coop = !b.emit && tm != nullptr;
+  const SynCtx s = coop ? uniform_syn(s_in) : s_in;
+  const BlkParam p = coop ? uniform_blk(p_in) : p_in;
 #else
   const SynCtx& s = s_in;
   const BlkParam& p = p_in;

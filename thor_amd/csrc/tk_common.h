@@ -36,6 +36,22 @@
 
 namespace tk {
 
+#if TK_HOST && defined(THOR_HOSTSIM_LANES)
+// Multi-lane host simulation (tests/hostsim built with -DTHOR_HOSTSIM_LANES): every lane of a team is an OS thread;
+// the cross-lane primitives below are implemented with one exchange operation (every lane publishes a 64-bit value,
+// all lanes read the published values) provided by tests/hostsim/hostsim.cpp.  Test infrastructure only.
+namespace hostlanes {
+void barrier();
+const unsigned long long* exchange_begin(unsigned long long v);  // slots[lane] of every lane, valid until exchange_end()
+void exchange_end();
+int lanes();
+int rank();
+}  // namespace hostlanes
+#define TK_LANES 1
+#else
+#define TK_LANES 0
+#endif
+
 // ---------------------------------------------------------------------------------
 // Team: the cooperating lane group.
 // ---------------------------------------------------------------------------------
@@ -46,7 +62,9 @@ struct Team {
   // On the device it points into LDS (XformWs::izz) so the per-coefficient lookups of quantisation and bit
   // counting do not take a global-memory round trip each; unused (nullptr) on the host simulation.
   const int16_t* izz = nullptr;
-#if TK_HOST
+#if TK_LANES
+  inline void sync() const { hostlanes::barrier(); }
+#elif TK_HOST
   inline void sync() const {}
 #else
   __device__ __forceinline__ void sync() const { __syncthreads(); }  // one wave per workgroup
@@ -54,21 +72,27 @@ struct Team {
 };
 
 TK_DEV void team_add(int* p, int v) {
-#if TK_HOST
+#if TK_LANES
+  __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST);
+#elif TK_HOST
   *p += v;
 #else
   atomicAdd(p, v);
 #endif
 }
 TK_DEV void team_add64(unsigned long long* p, unsigned long long v) {
-#if TK_HOST
+#if TK_LANES
+  __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST);
+#elif TK_HOST
   *p += v;
 #else
   atomicAdd(p, v);
 #endif
 }
 TK_DEV void team_or(unsigned* p, unsigned v) {
-#if TK_HOST
+#if TK_LANES
+  __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST);
+#elif TK_HOST
   *p |= v;
 #else
   atomicOr(p, v);
@@ -78,7 +102,13 @@ TK_DEV void team_or(unsigned* p, unsigned v) {
 // Cross-lane helpers.  A team of 1 lane (host simulation) degenerates to the identity, so code
 // written against them is also the serial algorithm.
 TK_DEV unsigned long long team_ballot(const Team t, int pred) {
-#if TK_HOST
+#if TK_LANES
+  const unsigned long long* g = hostlanes::exchange_begin(pred ? 1ull : 0ull);
+  unsigned long long m = 0;
+  for (int l = 0; l < t.size; l++) m |= g[l] << l;
+  hostlanes::exchange_end();
+  return m;
+#elif TK_HOST
   (void)t;
   return pred ? 1ull : 0ull;
 #else
@@ -87,7 +117,13 @@ TK_DEV unsigned long long team_ballot(const Team t, int pred) {
 #endif
 }
 TK_DEV int team_sum(const Team t, int v) {
-#if TK_HOST
+#if TK_LANES
+  const unsigned long long* g = hostlanes::exchange_begin((unsigned long long)(long long)v);
+  int r = 0;
+  for (int l = 0; l < t.size; l++) r += (int)(long long)g[l];
+  hostlanes::exchange_end();
+  return r;
+#elif TK_HOST
   (void)t;
   return v;
 #else
@@ -97,7 +133,13 @@ TK_DEV int team_sum(const Team t, int v) {
 #endif
 }
 TK_DEV int team_max(const Team t, int v) {
-#if TK_HOST
+#if TK_LANES
+  const unsigned long long* g = hostlanes::exchange_begin((unsigned long long)(long long)v);
+  int r = v;
+  for (int l = 0; l < t.size; l++) r = (int)(long long)g[l] > r ? (int)(long long)g[l] : r;
+  hostlanes::exchange_end();
+  return r;
+#elif TK_HOST
   (void)t;
   return v;
 #else
@@ -107,7 +149,13 @@ TK_DEV int team_max(const Team t, int v) {
 #endif
 }
 TK_DEV int team_shfl_xor(const Team t, int v, int d) {
-#if TK_HOST
+#if TK_LANES
+  const unsigned long long* g = hostlanes::exchange_begin((unsigned long long)(long long)v);
+  const int src = t.rank ^ d;
+  const int r = src < t.size ? (int)(long long)g[src] : v;
+  hostlanes::exchange_end();
+  return r;
+#elif TK_HOST
   (void)t; (void)d;
   return v;
 #else
@@ -116,7 +164,13 @@ TK_DEV int team_shfl_xor(const Team t, int v, int d) {
 #endif
 }
 TK_DEV unsigned long long team_min64(const Team t, unsigned long long v) {
-#if TK_HOST
+#if TK_LANES
+  const unsigned long long* g = hostlanes::exchange_begin(v);
+  unsigned long long r = v;
+  for (int l = 0; l < t.size; l++) r = g[l] < r ? g[l] : r;
+  hostlanes::exchange_end();
+  return r;
+#elif TK_HOST
   (void)t;
   return v;
 #else
@@ -132,7 +186,13 @@ TK_DEV unsigned long long team_min64(const Team t, unsigned long long v) {
 // selects / branches on it are scalar instead of exec-mask juggling (the compiler cannot prove uniformity of values
 // that went through memory or shuffles).
 TK_DEV int tk_uniform(int v) {
-#if TK_HOST
+#if TK_LANES
+  const unsigned long long* g = hostlanes::exchange_begin((unsigned long long)(long long)v);
+  for (int l = 0; l < hostlanes::lanes(); l++)
+    if ((int)(long long)g[l] != v) { fprintf(stderr, "tk_uniform: value differs between lanes (%d vs %d)\n", v, (int)(long long)g[l]); abort(); }
+  hostlanes::exchange_end();
+  return v;
+#elif TK_HOST
   return v;
 #else
   return __builtin_amdgcn_readfirstlane(v);
@@ -141,7 +201,13 @@ TK_DEV int tk_uniform(int v) {
 // EXPERIMENTAL (-DTHOR_EXP_UNIFORM, off by default, not yet measured on the GPU): scalarise more wave-uniform values
 // of the motion search.  TKU*/tk_uniform* are identities when the flag is off, so the default build is unchanged.
 TK_DEV unsigned long long tk_uniform64(unsigned long long v) {
-#if TK_HOST
+#if TK_LANES
+  const unsigned long long* g = hostlanes::exchange_begin(v);
+  for (int l = 0; l < hostlanes::lanes(); l++)
+    if (g[l] != v) { fprintf(stderr, "tk_uniform64: value differs between lanes\n"); abort(); }
+  hostlanes::exchange_end();
+  return v;
+#elif TK_HOST
   return v;
 #else
   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
@@ -165,7 +231,13 @@ TK_DEV double tk_uniform_f64(double d) {
 #endif
 // sum over the team, result in every lane (xor-shuffle butterfly; identity for a 1-lane team)
 TK_DEV unsigned long long team_sum64(const Team t, unsigned long long v) {
-#if TK_HOST
+#if TK_LANES
+  const unsigned long long* g = hostlanes::exchange_begin(v);
+  unsigned long long r = 0;
+  for (int l = 0; l < t.size; l++) r += g[l];
+  hostlanes::exchange_end();
+  return r;
+#elif TK_HOST
   (void)t;
   return v;
 #else
