@@ -170,6 +170,9 @@ struct BlkParam {  // block_param_t without the coefficient arrays (common/types
 // automaton (zero -> run mode, |c| > 1 -> level mode, |c| == 1 keeps the mode), so ballots give each
 // position its mode, its adaptive-VLC flag and its run length.  With W = 1 this is the serial loop.
 TK_DEV int coeff_bits_team(const Team t, const int16_t* coeff, int size, int type) {
+#ifdef THOR_EXP_UNIFORM
+  coeff = tk_uniform_ptr(coeff); size = tk_uniform(size); type = tk_uniform(type);
+#endif
   const int qsize = size < kMaxQuant ? size : kMaxQuant;
   const int N = qsize * qsize;
   const IzzRef izzr = izz_ref(t, qsize);

@@ -198,6 +198,9 @@ TK_DEV void find_contexts(const DbCell* cells, int cs, int ypos, int xpos, int f
 // ---------------------------------------------------------------------------------
 template <typename PIX>
 TK_DEV void ssd_acc(const Team t, unsigned long long* acc, const PIX* a, int as, const PIX* b, int bs, int w, int h) {
+#ifdef THOR_EXP_UNIFORM
+  acc = tk_uniform_ptr(acc); a = tk_uniform_ptr(a); b = tk_uniform_ptr(b); as = tk_uniform(as); bs = tk_uniform(bs); w = tk_uniform(w); h = tk_uniform(h);
+#endif
   unsigned long long local = 0;
   if ((w & (w - 1)) == 0) {  // every width except the frame-edge rectangles
     const Pow2 pw = mk_pow2(w);

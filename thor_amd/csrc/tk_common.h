@@ -222,6 +222,7 @@ TK_DEV double tk_uniform_f64(double d) {
   __builtin_memcpy(&d, &b, 8);
   return d;
 }
+template <class T> TK_DEV T* tk_uniform_ptr(T* p) { return (T*)(uintptr_t)tk_uniform64((unsigned long long)(uintptr_t)p); }
 #ifdef THOR_EXP_UNIFORM
 #define TKU(x) tk_uniform(x)
 #define TKU64(x) tk_uniform64(x)

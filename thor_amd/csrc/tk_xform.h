@@ -255,6 +255,9 @@ TK_DEV void inv_transform_recon(const Team t, XformWs* ws, const PIX* pred, int 
 
 template <typename PIX>
 TK_DEV void copy_block(const Team t, PIX* dst, int dstride, const PIX* src, int sstride, int w, int h) {
+#ifdef THOR_EXP_UNIFORM
+  dst = tk_uniform_ptr(dst); src = tk_uniform_ptr(src); dstride = tk_uniform(dstride); sstride = tk_uniform(sstride); w = tk_uniform(w); h = tk_uniform(h);
+#endif
   if ((w & (w - 1)) == 0) {
     const Pow2 pw = mk_pow2(w);
     for (int k = t.rank; k < w * h; k += t.size) {
@@ -275,6 +278,11 @@ TK_DEV void copy_block(const Team t, PIX* dst, int dstride, const PIX* src, int 
 template <typename PIX>
 TK_DEVNI int code_tu(const Team t, XformWs* ws, const PIX* org, int ostride, const PIX* pred, int pstride, PIX* rec,
                    int rstride, int size, int qp, int coeff_type, int fast, int16_t* coefq, int bitdepth) {
+#ifdef THOR_EXP_UNIFORM
+  org = tk_uniform_ptr(org); pred = tk_uniform_ptr(pred); rec = tk_uniform_ptr(rec); coefq = tk_uniform_ptr(coefq); ws = tk_uniform_ptr(ws);
+  ostride = tk_uniform(ostride); pstride = tk_uniform(pstride); rstride = tk_uniform(rstride); size = tk_uniform(size);
+  qp = tk_uniform(qp); coeff_type = tk_uniform(coeff_type); fast = tk_uniform(fast); bitdepth = tk_uniform(bitdepth);
+#endif
   TK_PROF_T0();
   fwd_transform(t, ws, org, ostride, pred, pstride, size, fast, bitdepth);
   TK_PROF_ADD(ws, 30);
