@@ -44,3 +44,23 @@ def test_engine_multi_lane_host_simulation_matches_golden(name):
     bits, rec = run_encoder(build_hostsim(lanes=8), golden_clip(c['clip']), c['w'], c['h'], c['n'], c['qp'], c['extra'], cfg=c.get('cfg'))
     assert md5(bits) == c['bit_md5'], 'stream differs from the reference'
     assert md5(rec) == c['rec_md5'], 'reconstruction differs from the reference'
+
+
+@needs_ref
+def test_host_simulation_two_random_access_streams_equal_reference_chunks():
+    """Two closed RA streams (hierarchical B + interpolated references, host-threaded interpolation) in lock step ==
+    the reference run on each chunk with -skip/-n."""
+    import subprocess, tempfile
+    from util import ROOT
+    clip = golden_clip('gen:128,96,18,5,2.5')
+    cfg = os.path.join(ROOT, 'configs', 'ra_high_efficiency.cfg')
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, 'in.yuv'), 'wb').write(clip)
+        base = ['-cf', cfg, '-if', os.path.join(d, 'in.yuv'), '-width', '128', '-height', '96', '-qp', '32', '-f', '30', '-n', '9']
+        subprocess.run([build_hostsim()] + base + ['-streams', '2', '-of', os.path.join(d, 'm.bit'), '-rf', os.path.join(d, 'm.yuv')],
+                       check=True, stdout=subprocess.DEVNULL)
+        for s in range(2):
+            subprocess.run([REF_ENC] + base + ['-skip', str(9 * s), '-of', os.path.join(d, 'r.bit'), '-rf', os.path.join(d, 'r.yuv')],
+                           check=True, stdout=subprocess.DEVNULL)
+            assert open(os.path.join(d, 'r.bit'), 'rb').read() == open(os.path.join(d, f'm.bit.{s}'), 'rb').read(), s
+            assert open(os.path.join(d, 'r.yuv'), 'rb').read() == open(os.path.join(d, f'm.yuv.{s}'), 'rb').read(), s

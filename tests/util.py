@@ -51,7 +51,7 @@ def build_hostsim(lanes=1):
     csrc = os.path.join(ROOT, 'thor_amd', 'csrc')
     newest = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc)])
     if not os.path.exists(out) or os.path.getmtime(out) < newest:
-        extra = [] if lanes == 1 else [f'-DTHOR_HOSTSIM_LANES={lanes}', '-pthread']
+        extra = ['-pthread'] + ([] if lanes == 1 else [f'-DTHOR_HOSTSIM_LANES={lanes}'])
         subprocess.check_call(['g++', '-std=c++17', '-O2', '-DTHOR_HOSTSIM', '-ffp-contract=off'] + extra + ['-o', out, src])
     return out
 

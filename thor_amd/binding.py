@@ -22,7 +22,7 @@ def build_native(force=False):
     newest = max(os.path.getmtime(h) for h in hdrs)
     if force or not os.path.exists(out) or os.path.getmtime(out) < newest:
         hipcc = '/opt/rocm/bin/hipcc' if os.path.exists('/opt/rocm/bin/hipcc') else 'hipcc'
-        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
+        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-pthread',
                                '-o', out, src])
     tool = os.path.join(REPO_ROOT, 'tools', 'thorenc_hip')
     tsrc = tool + '.c'

@@ -9,6 +9,7 @@
 #pragma once
 #include <vector>
 #include <string>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <cmath>
@@ -483,23 +484,49 @@ template <typename PIX> class Engine {
   // Temporally interpolated reference (enc/mainenc.c:350-355): normative CPU-side step between frames in the
   // reference too; the two padded window frames are read back, interpolated on the host (tk_interp.h), padded
   // and uploaded as the stream's `interp` frame.
-  void make_interp_frame(Stream<PIX>& q, const FrameParams& f) {
+  // All streams whose frame uses the interpolated reference: device copies stay on the calling thread, the
+  // interpolation itself (29 ms per 1080p frame on one core) runs on up to 64 host threads, one stream each.
+  void make_interp_frames(const std::vector<FrameParams>& fp) {
+    std::vector<int> todo;
+    for (int s = 0; s < S; s++)
+      if (fp[s].interp_ref) todo.push_back(s);
+    if (todo.empty()) return;
     const int w = sp.width, h = sp.height;
-    interp::HFrame<PIX> a, b, o;
-    a.alloc(w, h, kPadY); b.alloc(w, h, kPadY); o.alloc(w, h, kPadY);
-    const DevFrame<PIX>& ra = q.ring[f.interp_src[0]];
-    const DevFrame<PIX>& rb = q.ring[f.interp_src[1]];
-    backend::d2h(a.by.data(), ra.base_y, a.by.size() * sizeof(PIX)); backend::d2h(a.bc.data(), ra.base_c, a.bc.size() * sizeof(PIX));
-    backend::d2h(b.by.data(), rb.base_y, b.by.size() * sizeof(PIX)); backend::d2h(b.bc.data(), rb.base_c, b.bc.size() * sizeof(PIX));
-    interp::interpolate_frames(o, a, b, 2, 1);
-    o.pad_all();
-    backend::h2d(q.interp.base_y, o.by.data(), o.by.size() * sizeof(PIX));
-    backend::h2d(q.interp.base_c, o.bc.data(), o.bc.size() * sizeof(PIX));
-    q.interp.frame_num = f.frame_num;
+    unsigned hc = std::thread::hardware_concurrency();
+    const size_t nthr = hc < 1 ? 1 : (hc > 64 ? 64 : hc);
+    struct Work { interp::HFrame<PIX> a, b, o; };
+    for (size_t base = 0; base < todo.size(); base += nthr) {
+      const size_t n = todo.size() - base < nthr ? todo.size() - base : nthr;
+      std::vector<Work> wk(n);
+      for (size_t i = 0; i < n; i++) {
+        Stream<PIX>& q = st[todo[base + i]];
+        const FrameParams& f = fp[todo[base + i]];
+        Work& W = wk[i];
+        W.a.alloc(w, h, kPadY); W.b.alloc(w, h, kPadY); W.o.alloc(w, h, kPadY);
+        const DevFrame<PIX>& ra = q.ring[f.interp_src[0]];
+        const DevFrame<PIX>& rb = q.ring[f.interp_src[1]];
+        backend::d2h(W.a.by.data(), ra.base_y, W.a.by.size() * sizeof(PIX)); backend::d2h(W.a.bc.data(), ra.base_c, W.a.bc.size() * sizeof(PIX));
+        backend::d2h(W.b.by.data(), rb.base_y, W.b.by.size() * sizeof(PIX)); backend::d2h(W.b.bc.data(), rb.base_c, W.b.bc.size() * sizeof(PIX));
+      }
+      auto job = [&](size_t i) { interp::interpolate_frames(wk[i].o, wk[i].a, wk[i].b, 2, 1); wk[i].o.pad_all(); };
+      if (n == 1) job(0);
+      else {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < n; i++) th.emplace_back(job, i);
+        for (auto& t : th) t.join();
+      }
+      for (size_t i = 0; i < n; i++) {
+        Stream<PIX>& q = st[todo[base + i]];
+        backend::h2d(q.interp.base_y, wk[i].o.by.data(), wk[i].o.by.size() * sizeof(PIX));
+        backend::h2d(q.interp.base_c, wk[i].o.bc.data(), wk[i].o.bc.size() * sizeof(PIX));
+        q.interp.frame_num = fp[todo[base + i]].frame_num;
+      }
+    }
   }
 
   // Encode one frame per stream (origs already uploaded). Appends to st[s].out.
   void encode_frames(const std::vector<FrameParams>& fp) {
+    if (!external_interp) make_interp_frames(fp);
     for (int s = 0; s < S; s++) {
       Stream<PIX>& q = st[s];
       const FrameParams& f = fp[s];
@@ -516,7 +543,6 @@ template <typename PIX> class Engine {
       J.lambda = f.lambda_coeff * kSquaredLambdaQP[f.qp];
       J.sqrt_lambda = sqrt(J.lambda);
       J.orig = q.orig.p; J.rec = q.rec.p;
-      if (f.interp_ref && !external_interp) make_interp_frame(q, f);
       for (int r = 0; r < f.num_ref; r++) {
         const DevFrame<PIX>& rf = f.ref_array[r] < 0 ? q.interp : q.ring[f.ref_array[r]];
         J.ref[r] = rf.p;

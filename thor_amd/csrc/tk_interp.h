@@ -9,6 +9,7 @@
 // block_avg_simd :38, sad_calc_simd_unaligned :68 - all numerically equal to the scalar code).
 #pragma once
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
