@@ -63,10 +63,18 @@ typedef struct thor_hip_encoder thor_hip_encoder;
  * file ("-name value" tokens, ';' comments).  cfg_path may be NULL. Returns 0 on success. */
 int thor_hip_params_from_config(thor_hip_params* p, const char* cfg_path);
 
-/* Apply one "-name value" option (same names as enc/strings.c:287-356) on top of *p. Returns 0 if known. */
+/* Apply one "-name value" option (same names as enc/strings.c:287-356) on top of *p.  Returns 0 when the option is
+ * honoured; 1 = not an option of the reference's table; 2 = known, but the value is not implemented by this path
+ * (quantisation matrices, delta-QP / rate control, sync, subsampling other than 4:2:0, SB size other than 128: they
+ * change the bitstream, so they are rejected instead of ignored); 3 = front-end option (-if/-of/-rf/-n/-skip).
+ * thor_hip_params_from_config applies the same rule to every token of the file (returns non-zero). */
 int thor_hip_params_set(thor_hip_params* p, const char* name, const char* value);
 
 int thor_hip_device_count(void);
+/* One process drives ONE GPU from ONE thread (the reference's encode_frame is neither re-entrant nor threaded,
+ * SURVEY.md 8b): the first thor_hip_open binds the process to `device`; NULL is returned - with a message on stderr -
+ * for a device index the node does not have, for a second device in the same process, and for parameter sets this
+ * path cannot encode bit-exactly.  Multi-GPU = one process per GPU (bench.py under torch.distributed.run). */
 thor_hip_encoder* thor_hip_open(const thor_hip_params* p, int num_streams, int device);
 void thor_hip_close(thor_hip_encoder* e);
 

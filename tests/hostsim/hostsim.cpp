@@ -23,6 +23,7 @@ void h2d(void* d, const void* h, size_t n) { memcpy(d, h, n); }
 void d2h(void* h, const void* d, size_t n) { memcpy(h, d, n); }
 void dev_memset(void* d, int v, size_t n) { memset(d, v, n); }
 void dev_sync() {}
+void release_superblocks(const void*) {}
 size_t team_ws_bytes(int pix_bytes) {
   return pix_bytes == 1 ? sizeof(BigWs<uint8_t>) + sizeof(SmallWs<uint8_t>) : sizeof(BigWs<uint16_t>) + sizeof(SmallWs<uint16_t>);
 }

@@ -28,12 +28,33 @@ def golden_streams():
 
 
 def golden_clip(name):
-    """Committed clip, or 'gen:w,h,frames,seed,sigma' = the seeded synthetic generator (thor_amd/synth.py)."""
+    """Committed clip, 'gen:w,h,frames,seed,sigma[,bits]' = the seeded synthetic generator (thor_amd/synth.py), or
+    'stream:w,h,frames,seed,sigma,sid,extra' = stream `sid` of the multi-stream workload of bench.py
+    (synth.make_stream_frames over a base clip of frames+extra frames)."""
     if name.startswith('gen:'):
         from thor_amd import synth as gen_clip
-        w, h, n, seed, sigma = name[4:].split(',')
-        return b''.join(p.tobytes() for fr in gen_clip.make_clip(int(w), int(h), int(n), int(seed), float(sigma)) for p in fr)
+        a = name[4:].split(',')
+        w, h, n, seed, sigma = a[:5]
+        bits = int(a[5]) if len(a) > 5 else 8
+        return b''.join(p.tobytes() for fr in gen_clip.make_clip(int(w), int(h), int(n), int(seed), float(sigma), bits) for p in fr)
+    if name.startswith('stream:'):
+        from thor_amd import synth
+        w, h, n, seed, sigma, sid, extra = name[7:].split(',')
+        base = _base_clip(int(w), int(h), int(n) + int(extra), int(seed), float(sigma))
+        return b''.join(f.tobytes() for f in synth.make_stream_frames(base, int(sid), int(n)))
     return gzip.open(os.path.join(GOLD, name)).read()
+
+
+_BASE = {}
+
+
+def _base_clip(w, h, n, seed, sigma):
+    from thor_amd import synth
+    k = (w, h, n, seed, sigma)
+    if k not in _BASE:
+        _BASE.clear()
+        _BASE[k] = synth.make_clip(w, h, n, seed, sigma)
+    return _BASE[k]
 
 
 def build_oracle_c():

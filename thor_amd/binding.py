@@ -79,9 +79,13 @@ def lib():
 def load_config(cfg_path=None, **overrides):
     """ThorParams from a Thorenc-style config file plus "-name value" overrides (width=..., qp=...)."""
     p = ThorParams()
-    lib().thor_hip_params_from_config(C.byref(p), cfg_path.encode() if cfg_path else None)
+    rc = lib().thor_hip_params_from_config(C.byref(p), cfg_path.encode() if cfg_path else None)
+    if rc:
+        raise ValueError(f'{cfg_path}: unknown or unsupported option (rc={rc}); this path rejects what it cannot encode bit-exactly')
     for k, v in overrides.items():
-        lib().thor_hip_params_set(C.byref(p), ('-' + k).encode(), str(v).encode())
+        rc = lib().thor_hip_params_set(C.byref(p), ('-' + k).encode(), str(v).encode())
+        if rc:
+            raise ValueError(f'option -{k} {v}: ' + {1: 'unknown', 2: 'not implemented by this path', 3: 'front-end option, not an encoder parameter'}.get(rc, f'rc={rc}'))
     return p
 
 

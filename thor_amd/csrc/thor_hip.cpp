@@ -238,19 +238,30 @@ struct KernelClock {
 static KernelClock g_clk;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_sb_events, g_filt_events;
 
-static void ensure_init(int device) {
-  if (g_inited) return;
+// The backend is one-device-per-process and single-threaded by design (one process per GPU, include/thor_hip.h): the
+// first call fixes the device; a later request for another device, or a device index the node does not have, is an
+// error (returns false) - never a silent fall-back to device 0.
+static int g_device = -1;
+static bool ensure_init(int device) {
+  if (g_inited) {
+    if (device != g_device) { fprintf(stderr, "thor_hip: this process is bound to HIP device %d (requested %d); use one process per GPU\n", g_device, device); return false; }
+    HIPCHECK(hipSetDevice(g_device));  // hipSetDevice is per thread
+    return true;
+  }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
     fprintf(stderr, "Run-time error...\nthor_hip: no HIP device available - this library has no CPU path\n...now exiting to system...\n");
     abort();
   }
-  HIPCHECK(hipSetDevice(device < n ? device : 0));
+  if (device < 0 || device >= n) { fprintf(stderr, "thor_hip: HIP device %d requested but only %d visible (check LOCAL_RANK / HIP_VISIBLE_DEVICES)\n", device, n); return false; }
+  g_device = device;
+  HIPCHECK(hipSetDevice(device));
   HIPCHECK(hipStreamCreate(&g_stream));
   static Tables h;
   init_tables(&h);
   HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tab), &h, sizeof(h)));
   g_inited = true;
+  return true;
 }
 
 namespace backend {
@@ -296,6 +307,7 @@ struct DfState {  // per engine (keyed by its device job array)
   uint8_t* pool = nullptr;
   unsigned long long* times = nullptr;
   int S = 0, nsb = 0, wgs = 0;
+  size_t slot = 0;
   int frame = 0;
 };
 static std::map<const void*, DfState> g_df;
@@ -305,10 +317,10 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
   const size_t total = (size_t)S * nsb;
   DfState& D = g_df[jobs];
   const size_t slot = (sizeof(BigWs<PIX>) + 255) & ~(size_t)255;
-  if (D.S != S || D.nsb != nsb) {
+  if (D.S != S || D.nsb != nsb || D.slot != slot) {
     if (D.ctl) { HIPCHECK(hipFree(D.ctl)); HIPCHECK(hipFree(D.queue)); HIPCHECK(hipFree(D.cnt)); HIPCHECK(hipFree(D.pool)); if (D.times) HIPCHECK(hipFree(D.times)); }
     D = DfState();
-    D.S = S; D.nsb = nsb;
+    D.S = S; D.nsb = nsb; D.slot = slot;
     int per_cu = 0;
     HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_superblocks<PIX>, 64, 0));
     hipDeviceProp_t prop;
@@ -361,6 +373,15 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
     if (f) { int hdr[4] = {D.frame, S, nsb, cols}; fwrite(hdr, 4, 4, f); fwrite(h.data(), 8, h.size(), f); fclose(f); }
   }
   D.frame++;
+}
+// Engine::close: the scheduler state belongs to the engine that owns `jobs`; without this a later engine whose job
+// array lands on the same device address would inherit a pool sized for another sample type.
+void release_superblocks(const void* jobs) {
+  auto it = g_df.find(jobs);
+  if (it == g_df.end()) return;
+  DfState& D = it->second;
+  if (D.ctl) { HIPCHECK(hipFree(D.ctl)); HIPCHECK(hipFree(D.queue)); HIPCHECK(hipFree(D.cnt)); HIPCHECK(hipFree(D.pool)); if (D.times) HIPCHECK(hipFree(D.times)); }
+  g_df.erase(it);
 }
 template <typename PIX> void run_deblock(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S) {
   const int items = (hjobs[0].cfg.width / 8) * (hjobs[0].cfg.height / 8);
@@ -503,6 +524,16 @@ static int unsupported(const SeqParams& s) {
   if (s.encoder_speed < 0 || s.encoder_speed > 2) return fprintf(stderr, "thor_hip: encoder_speed must be 0, 1 or 2\n"), 1;
   if (s.width % 8 || s.height % 8 || s.width < 16 || s.height < 16) return fprintf(stderr, "thor_hip: bad geometry\n"), 1;
   if (s.max_num_ref < 1 || s.max_num_ref > 4) return fprintf(stderr, "thor_hip: max_num_ref out of range\n"), 1;
+  // remaining guards of check_parameters (enc/strings.c:470-555) that matter without rate control / qmtx
+  if (s.HQperiod < 1 || s.HQperiod >= 33) return fprintf(stderr, "thor_hip: HQperiod must be in 1..32\n"), 1;
+  if (s.num_reorder_pics > 0 && s.HQperiod > 1 && (s.HQperiod % (s.num_reorder_pics + 1)) != 0)
+    return fprintf(stderr, "thor_hip: sub-GOP length (num_reorder_pics+1) must divide HQperiod\n"), 1;
+  if (s.num_reorder_pics > 0 && s.max_num_ref < 2) return fprintf(stderr, "thor_hip: reordered pictures need more than one reference frame\n"), 1;
+  if (s.intra_period < 0 || (s.intra_period % (s.num_reorder_pics + 1)) != 0)
+    return fprintf(stderr, "thor_hip: intra_period must be a multiple of the sub-GOP size\n"), 1;
+  if (s.qp < 0 || s.qp > 51) return fprintf(stderr, "thor_hip: qp out of range\n"), 1;
+  if (s.cdef < 0 || s.cdef > 3 || s.clpf < 0 || s.clpf > 2) return fprintf(stderr, "thor_hip: cdef / clpf out of range\n"), 1;
+  if (s.log2_sb_size != 7) return fprintf(stderr, "thor_hip: only 128x128 superblocks are implemented\n"), 1;
   return 0;
 }
 
@@ -516,6 +547,8 @@ int thor_hip_params_from_config(thor_hip_params* p, const char* cfg_path) {
     cli_apply(a, t);
   }
   from_seq(p, a.sp);
+  if (!a.unknown.empty()) return fprintf(stderr, "thor_hip: unknown option %s in %s\n", a.unknown.c_str(), cfg_path), 1;
+  if (!a.unsupported.empty()) return fprintf(stderr, "thor_hip: %s (in %s) is not implemented by this path\n", a.unsupported.c_str(), cfg_path), 2;
   return 0;
 }
 
@@ -526,6 +559,9 @@ int thor_hip_params_set(thor_hip_params* p, const char* name, const char* value)
   std::vector<std::string> t = {name, value};
   cli_apply(a, t);
   from_seq(p, a.sp);
+  if (!a.unknown.empty()) return 1;      // not an option of the reference's table
+  if (!a.unsupported.empty()) return 2;  // known, but this value is not implemented (qmtx, rate control, 4:4:4 ...)
+  if (!a.infile.empty() || !a.outfile.empty() || !a.recfile.empty() || a.num_frames != 600 || a.skip != 0 || a.streams != 1) return 3;  // front-end option, not an encoder parameter
   return 0;
 }
 
@@ -539,7 +575,7 @@ thor_hip_encoder* thor_hip_open(const thor_hip_params* p, int num_streams, int d
   if (!p || num_streams < 1) return nullptr;
   SeqParams s = to_seq(*p);
   if (unsupported(s)) return nullptr;
-  ensure_init(device);
+  if (!ensure_init(device)) return nullptr;
   thor_hip_encoder* e = new thor_hip_encoder;
   e->sp = s;
   e->S = num_streams;
@@ -632,8 +668,14 @@ int thor_hip_encode_frame(thor_hip_encoder* e, const void* const* yuv) {
   return 0;
 }
 
-size_t thor_hip_stream_bytes(const thor_hip_encoder* e, int stream) { return e->hbd ? e->e16->eng.st[stream].out.size() : e->e8->eng.st[stream].out.size(); }
-const uint8_t* thor_hip_stream_data(const thor_hip_encoder* e, int stream) { return e->hbd ? e->e16->eng.st[stream].out.data() : e->e8->eng.st[stream].out.data(); }
+size_t thor_hip_stream_bytes(const thor_hip_encoder* e, int stream) {
+  if (!e || stream < 0 || stream >= e->S) return 0;
+  return e->hbd ? e->e16->eng.st[stream].out.size() : e->e8->eng.st[stream].out.size();
+}
+const uint8_t* thor_hip_stream_data(const thor_hip_encoder* e, int stream) {
+  if (!e || stream < 0 || stream >= e->S) return nullptr;
+  return e->hbd ? e->e16->eng.st[stream].out.data() : e->e8->eng.st[stream].out.data();
+}
 int thor_hip_get_recon(thor_hip_encoder* e, int stream, void* yuv_out) {
   if (!e || stream < 0 || stream >= e->S || !yuv_out) return 1;
   ENC_DISPATCH(e, { E.eng.download_rec(stream, (PIXT*)yuv_out); });
@@ -644,7 +686,7 @@ void thor_hip_kernel_time(thor_hip_encoder*, double* sb_ms, long* sb_launches, d
   if (sb_launches) *sb_launches = g_clk.sb_launches;
   if (filter_ms) *filter_ms = g_clk.filt_ms;
 }
-void thor_hip_read_prof(thor_hip_encoder* e, long long out[32]) { ENC_DISPATCH(e, { backend::d2h(out, E.eng.d_prof, 32 * sizeof(long long)); }); }
+void thor_hip_read_prof(thor_hip_encoder* e, long long out[32]) { if (!e || !out) return; ENC_DISPATCH(e, { backend::d2h(out, E.eng.d_prof, 32 * sizeof(long long)); }); }
 void thor_hip_kernel_time_reset(thor_hip_encoder*) { g_clk.sb_ms = g_clk.filt_ms = 0; g_clk.sb_launches = 0; }
 
 }  // extern "C"
@@ -660,15 +702,21 @@ static void seam_fatal(const char* msg) {  // fatalerror() convention, common/gl
   abort();
 }
 
-static void stream_put1(thor_stream* s, unsigned bit) {  // putbits(1, bit) of enc/putbits.c:109-128
-  if (s->bitrest == 0) {
+// putbits(n, val) of enc/putbits.c:109-128 for 1 <= n <= 16 (same lazy flush: a full accumulator is only written out
+// by the next put, so the caller's (bitbuf, bitrest, bytepos) end up exactly as if the reference had written the bits)
+static void stream_put(thor_stream* s, unsigned n, unsigned val) {
+  val &= (1u << n) - 1u;
+  if (n <= s->bitrest) {
+    s->bitbuf |= val << (s->bitrest - n);
+    s->bitrest -= n;
+  } else {
+    const unsigned rest = n - s->bitrest;
+    s->bitbuf |= val >> rest;
     if (s->bytepos + 4 > s->bytesize) seam_fatal("Run out of bits in stream buffer.");
     for (int i = 3; i >= 0; --i) s->bitstream[s->bytepos++] = (uint8_t)((s->bitbuf >> (8 * i)) & 0xff);
-    s->bitbuf = 0;
-    s->bitrest = 32;
+    s->bitbuf = (val & ((1u << rest) - 1u)) << (32 - rest);
+    s->bitrest = 32 - rest;
   }
-  s->bitbuf |= (bit & 1u) << (s->bitrest - 1);
-  s->bitrest -= 1;
 }
 
 template <typename PIX> struct SeamState {
@@ -700,7 +748,7 @@ template <typename PIX> static void encode_frame_impl(struct thor_encoder_info* 
     if (ep.subsample != 420 || ep.log2_sb_size != 7 || ep.qmtx || ep.max_delta_qp || ep.bitrate || ep.sync)
       seam_fatal("thor_hip: unsupported encoder parameters (need 4:2:0, 128x128 SB, no qmtx / delta-QP / rate control / sync)");
     if (unsupported(s)) seam_fatal("thor_hip: unsupported encoder parameters");
-    ensure_init(0);
+    if (!ensure_init(getenv("THOR_HIP_DEVICE") ? atoi(getenv("THOR_HIP_DEVICE")) : 0)) seam_fatal("thor_hip: HIP device not usable");
     st = new SeamState<PIX>;
     st->eng.raw_frames = true;
     st->eng.external_interp = true;  // the caller interpolates (enc/mainenc.c:353) and hands the frame over
@@ -742,11 +790,16 @@ template <typename PIX> static void encode_frame_impl(struct thor_encoder_info* 
   const thor_yuv_frame& o = *ei->orig;
   eng.upload_planes(0, (const PIX*)o.y, o.stride_y, (const PIX*)o.u, (const PIX*)o.v, o.stride_c);
   eng.st[0].num_encoded = fi.frame_num;  // only used for bookkeeping
+  eng.st[0].bit_phase = (8 * (int)ei->stream->bytepos + (32 - (int)ei->stream->bitrest)) & 31;  // get_bit_pos() of the caller's stream
   std::vector<FrameParams> fp(1, f);
   eng.encode_frames(fp);
   // bits -> caller's stream (the caller flushes: enc/mainenc.c:595)
   HostBits& b = eng.st[0].bits;
-  for (int i = 0; i < b.nbits; i++) stream_put1(ei->stream, (unsigned)b.get(i));
+  {
+    int i = 0;
+    for (; i + 16 <= b.nbits; i += 16) stream_put(ei->stream, 16, (b.w[i >> 5] >> (16 - (i & 16))) & 0xffffu);
+    for (; i < b.nbits; i++) stream_put(ei->stream, 1, (unsigned)b.get(i));
+  }
   b.clear();
   // reconstruction -> caller's rec frame
   {
@@ -839,7 +892,7 @@ extern "C" int thor_hip_sad_batch(const uint8_t* org, int w, int h, const uint8_
     int x = bx + cand[2 * i], y = by + cand[2 * i + 1];
     if (x < 0 || y < 0 || x + w > plane_w || y + h > plane_h) return 2;
   }
-  ensure_init(0);
+  if (!ensure_init(g_inited ? g_device : 0)) return 3;
   uint8_t* d_org = to_dev(org, (size_t)w * h);
   uint8_t* d_ref = to_dev(ref_plane, (size_t)rstride * plane_h);
   int* d_c = to_dev(cand, (size_t)2 * n);
@@ -854,7 +907,7 @@ extern "C" int thor_hip_sad_batch(const uint8_t* org, int w, int h, const uint8_
 extern "C" int thor_hip_interp_luma(const uint8_t* ref_plane, int plane_w, int plane_h, int rstride, int pad, int bx, int by, int w,
                                     int h, const int16_t* mv, int n, int bipred, uint8_t* out) {
   if (!ref_plane || !mv || !out || n <= 0) return 1;
-  ensure_init(0);
+  if (!ensure_init(g_inited ? g_device : 0)) return 3;
   const size_t total = (size_t)rstride * (plane_h + 2 * pad);
   uint8_t* d_ref = to_dev(ref_plane, total);
   int16_t* d_mv = to_dev(mv, (size_t)2 * n);
@@ -871,7 +924,7 @@ extern "C" int thor_hip_code_tu_batch(const uint8_t* org, const uint8_t* pred, i
                                       int16_t* coefq, uint8_t* rec, int* cbp) {
   if (!org || !pred || !coefq || !rec || !cbp || n <= 0) return 1;
   if (size != 4 && size != 8 && size != 16 && size != 32 && size != 64 && size != 128) return 2;
-  ensure_init(0);
+  if (!ensure_init(g_inited ? g_device : 0)) return 3;
   const size_t px = (size_t)n * size * size;
   const int qs = size < 16 ? size : 16;
   uint8_t* d_org = to_dev(org, px);

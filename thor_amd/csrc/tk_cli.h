@@ -17,6 +17,11 @@ struct CliArgs {
   SeqParams sp;
   std::string infile, outfile, recfile;
   int num_frames = 600, skip = 0, streams = 1;
+  // Options of the reference's table (enc/strings.c:287-356) this path does not implement.  A value other than
+  // the reference's default would change the bitstream, so it is recorded here and rejected by the caller
+  // (thor_hip_params_set / thor_hip_params_from_config return non-zero, the CLI tools exit) - never ignored.
+  std::string unsupported;   // first "-name value" that cannot be honoured
+  std::string unknown;       // first option that is not in the reference's table at all
 };
 
 static inline void cli_tokens_from_file(const std::string& path, std::vector<std::string>& out) {
@@ -91,8 +96,23 @@ static inline void cli_apply(CliArgs& a, const std::vector<std::string>& t) {
     else if (k == "-enable_cfl_inter") p.cfl_inter = I();
     else if (k == "-bitdepth") p.bitdepth = I();
     else if (k == "-input_bitdepth") p.input_bitdepth = I();
-    // anything else (B-frame QP tables etc.) is accepted and ignored by this path
+    else {
+      // the rest of the reference's table: harmless at their defaults (or never read by the block path), fatal otherwise
+      struct Opt { const char* name; const char* dflt; };  // dflt == nullptr: any value is fine (I/O and reporting options)
+      static const Opt rest[] = {{"-ph", "0"}, {"-fh", "0"}, {"-stat", nullptr}, {"-snrcalc", nullptr}, {"-log2_sb_size", "7"},
+                                 {"-max_delta_qp", "0"}, {"-delta_qp_step", nullptr}, {"-sync", "0"}, {"-bitrate", "0"},
+                                 {"-max_qp", nullptr}, {"-min_qp", nullptr}, {"-max_qpI", nullptr}, {"-min_qpI", nullptr},
+                                 {"-qmtx", "0"}, {"-qmtx_offset", nullptr}, {"-subsample", "420"}, {"-frame_bitdepth", nullptr}};
+      bool found = false;
+      for (const Opt& o : rest)
+        if (k == o.name) {
+          found = true;
+          if (o.dflt && atoi(v.c_str()) != atoi(o.dflt) && a.unsupported.empty()) a.unsupported = k + " " + v;
+        }
+      if (!found && a.unknown.empty()) a.unknown = k;
+    }
   }
+  if (t.size() & 1) { if (a.unknown.empty()) a.unknown = t.back() + " (no value)"; }
 }
 
 static inline CliArgs cli_parse(int argc, char** argv) {
@@ -107,6 +127,8 @@ static inline CliArgs cli_parse(int argc, char** argv) {
   }
   cli_apply(a, files);
   cli_apply(a, rest);
+  if (!a.unknown.empty()) { fprintf(stderr, "Run-time error...\nunknown option %s\n...now exiting to system...\n", a.unknown.c_str()); exit(2); }
+  if (!a.unsupported.empty()) { fprintf(stderr, "Run-time error...\noption %s is not implemented by this path (it changes the bitstream)\n...now exiting to system...\n", a.unsupported.c_str()); exit(2); }
   return a;
 }
 

@@ -41,6 +41,7 @@ template <typename PIX> void run_cdef(const CdefJob<PIX>* cjobs, const CdefJob<P
 // bit-level concatenation of per-SB bit strings: item i copies nbits[i] bits from src[i] to bit offset dst_bit[i] of dst
 struct GatherItem { const uint32_t* src; int nbits; long long dst_bit; };
 void run_gather(const GatherItem* d_items, int n, uint32_t* dst);
+void release_superblocks(const void* jobs);  // frees the scheduler state run_superblocks keeps for this job array
 }  // namespace backend
 
 // ---- parameters -------------------------------------------------------------------------
@@ -275,7 +276,7 @@ struct CdefHeader {
   int damping = 5, bits = 0;
   int strengths[8] = {0}, uv_strengths[8] = {0};
 };
-inline void write_cdef_params(HostBits& b, int pos_or_minus1, int cdef_on, const CdefHeader& h) {  // write_bits.c:83-97
+inline void write_cdef_params(HostBits& b, int pos_or_minus1, int cdef_on, const CdefHeader& h, int phase = 0) {  // write_bits.c:83-97
   HostBits tmp;
   if (cdef_on) {
     tmp.put(2, h.damping - 3); tmp.put(2, h.bits);
@@ -288,7 +289,9 @@ inline void write_cdef_params(HostBits& b, int pos_or_minus1, int cdef_on, const
     // back to the saved header position, rewrite, write_stream_pos() forward again.  The forward move restores
     // the saved 32-bit accumulator of the CURRENT position, so patched bits that fall into the stream's last,
     // not yet flushed word are lost and the originally written bits stay (visible on tiny frames).
-    const int unflushed = (b.nbits >> 5) << 5;
+    // `phase`: bit position (mod 32) of b's bit 0 in the stream the reference would be writing to (0 unless the bits
+    // are appended to a caller's stream that already holds unflushed bits - drop-in seam, frame 0 after the sequence header).
+    const int unflushed = (((b.nbits + phase) >> 5) << 5) - phase;
     for (int i = 0; i < tmp.nbits; i++)
       if (pos_or_minus1 + i < unflushed) b.overwrite(pos_or_minus1 + i, 1, (uint32_t)tmp.get(i));
   }
@@ -330,6 +333,7 @@ template <typename PIX> struct Stream {
   FrameParams cur;           // frame returned by the last schedule()
   int cur_abs = 0;           // its absolute input frame index
   HostBits bits;             // bits of the frame being assembled (sequence header rides on frame 0)
+  int bit_phase = 0;         // raw_frames mode: bit position mod 32 of the caller's stream at frame start
   std::vector<uint8_t> out;  // finished stream bytes (4-byte big-endian length + payload per frame)
 };
 
@@ -421,6 +425,7 @@ template <typename PIX> class Engine {
     st.clear();
     backend::dev_free(d_nbits_all); backend::dev_free(d_status_all); backend::dev_free(d_items); backend::dev_free(d_payload);
     d_nbits_all = d_status_all = nullptr; d_items = nullptr; d_payload = nullptr; payload_words = 0;
+    backend::release_superblocks(d_jobs);
     backend::dev_free(d_jobs); d_jobs = nullptr;
     backend::dev_free(d_cjobs); d_cjobs = nullptr;
     backend::dev_free(d_ljobs); d_ljobs = nullptr;
@@ -686,7 +691,7 @@ template <typename PIX> class Engine {
         }
         ch.bits = R.nb_bits;
         for (int i = 0; i < 8; i++) { ch.strengths[i] = R.strengths[i]; ch.uv_strengths[i] = R.uv_strengths[i]; }
-        write_cdef_params(b, cdef_pos, 1, ch);
+        write_cdef_params(b, cdef_pos, 1, ch, raw_frames ? q.bit_phase : 0);
       }
       if (sp.clpf)
         for (auto& pr : lplan[s].bits) b.put(pr.first, pr.second);

@@ -67,6 +67,24 @@ def make_clip(w, h, frames, seed, sigma=2.0, bits=8):
     return out
 
 
+def make_stream_frames(base, sid, nframes):
+    """Frames of stream `sid` of a multi-stream run (bench.py, tests): a window of the seeded base clip, flipped /
+    offset per stream so that streams do not do identical work.  Returns nframes flat planar 4:2:0 uint8 frames."""
+    off = sid % max(1, len(base) - nframes + 1)
+    mode = (sid // 3) % 4
+    out = []
+    for f in range(nframes):
+        Y, U, V = base[off + f]
+        if mode & 1:
+            Y, U, V = Y[:, ::-1], U[:, ::-1], V[:, ::-1]
+        if mode & 2:
+            Y, U, V = Y[::-1], U[::-1], V[::-1]
+        d = sid % 5
+        Y = np.clip(Y.astype(np.int16) + d, 0, 255).astype(np.uint8)
+        out.append(np.concatenate([np.ascontiguousarray(Y).ravel(), np.ascontiguousarray(U).ravel(), np.ascontiguousarray(V).ravel()]))
+    return out
+
+
 def write_clip(path, clip):
     with open(path, 'wb') as f:
         for (Y, U, V) in clip:

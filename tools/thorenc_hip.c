@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
   thor_hip_params_from_config(&p, NULL);
   /* config files first, explicit options afterwards (same precedence as the reference) */
   for (i = 1; i + 1 < argc; i += 2)
-    if (!strcmp(argv[i], "-cf")) thor_hip_params_from_config(&p, argv[i + 1]);
+    if (!strcmp(argv[i], "-cf") && thor_hip_params_from_config(&p, argv[i + 1])) return 2;
   for (i = 1; i + 1 < argc; i += 2) {
     const char *k = argv[i], *v = argv[i + 1];
     if (!strcmp(k, "-cf")) continue;
@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(k, "-skip")) skip = atoi(v);
     else if (!strcmp(k, "-streams")) S = atoi(v);
     else if (!strcmp(k, "-wrap")) wrap = atoi(v); /* clip length: frame index taken modulo this (throughput tests) */
-    else thor_hip_params_set(&p, k, v);
+    else if (thor_hip_params_set(&p, k, v)) { fprintf(stderr, "Run-time error...\noption %s %s is unknown or not implemented by this path\n...now exiting to system...\n", k, v); return 2; }
   }
   if (!inf) { fprintf(stderr, "usage: %s -cf cfg -if in.yuv -width W -height H -qp Q -n N ...\n", argv[0]); return 2; }
   FILE* fi = fopen(inf, "rb");
