@@ -90,6 +90,11 @@ int thor_hip_next_frame(thor_hip_encoder* e, int stream, int* display_index);
 /* Copy one planar 4:2:0 frame (bitdepth 8: bytes; >8: little-endian uint16) of stream `stream`
  * into HBM staging slot `slot` (slots are allocated on demand). */
 int thor_hip_stage_frame(thor_hip_encoder* e, int stream, int slot, const void* yuv);
+/* Same, for a frame that is already in HBM (`dev_yuv` is a device pointer to the same contiguous planar layout):
+ * device-to-device copy on the library's stream, synchronous at return.  The caller must have finished writing the
+ * source (e.g. torch.cuda.synchronize()).  Used by bench.py: rank 0 broadcasts the clip over RCCL and every rank cuts
+ * its chunks' frames out of it without a host round trip. */
+int thor_hip_stage_frame_device(thor_hip_encoder* e, int stream, int slot, const void* dev_yuv);
 /* Encode the next frame of every stream from staging slot slots[stream] (inputs already resident
  * in HBM).  Blocks until the bits of all streams are assembled on the host. */
 int thor_hip_encode_staged(thor_hip_encoder* e, const int* slots);

@@ -24,8 +24,15 @@ void d2h(void* h, const void* d, size_t n) { memcpy(h, d, n); }
 void dev_memset(void* d, int v, size_t n) { memset(d, v, n); }
 void dev_sync() {}
 void release_superblocks(const void*) {}
-size_t team_ws_bytes(int pix_bytes) {
-  return pix_bytes == 1 ? sizeof(BigWs<uint8_t>) + sizeof(SmallWs<uint8_t>) : sizeof(BigWs<uint16_t>) + sizeof(SmallWs<uint16_t>);
+size_t team_ws_bytes(int pix_bytes) {  // one workgroup: shared state + kWaves x (BigWs + SmallWs)
+  return sizeof(WgShared) + 64 + (size_t)kWaves * (pix_bytes == 1 ? sizeof(BigWs<uint8_t>) + sizeof(SmallWs<uint8_t>) + 128 : sizeof(BigWs<uint16_t>) + sizeof(SmallWs<uint16_t>) + 128);
+}
+// carve the workgroup's scratch arena: [WgShared][wave 0: BigWs SmallWs][wave 1: ...]
+template <typename PIX> static TeamWs<PIX> wave_ws(uint8_t* base, int wave) {
+  auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+  WgShared* sh = (WgShared*)base;
+  uint8_t* p = base + al(sizeof(WgShared)) + (size_t)wave * (al(sizeof(BigWs<PIX>)) + al(sizeof(SmallWs<PIX>)));
+  return make_ws((SmallWs<PIX>*)(p + al(sizeof(BigWs<PIX>))), sh, (BigWs<PIX>*)p);
 }
 
 #ifdef THOR_HOSTSIM_LANES
@@ -84,30 +91,92 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
         for (int r = 0; r < N; r++)
           th.emplace_back([&, r]() {
             hostlanes::tl_sh = &sh; hostlanes::tl_rank = r; hostlanes::tl_sense = 0;
-            Team t{r, N};
-            TeamWs<PIX> wsv = make_ws((SmallWs<PIX>*)(J.scratch + sizeof(BigWs<PIX>)), (BigWs<PIX>*)J.scratch);
+            TeamWs<PIX> wsv = wave_ws<PIX>(J.scratch, 0);
+            Team t{r, N, wsv.sh->tabs.izz};
+            xform_tables_fill(&wsv.sh->tabs, r, N);
+            t.sync();
             BitSink out;
             out.buf = J.sb_bits + (size_t)sbi * J.sb_words; out.pos = 0; out.cap = J.sb_words * 32; out.emit = 1; out.ovf = 0;
-            process_sb(t, J, &wsv, k * kMaxSb, l * kMaxSb, out);
+            process_sb(Wg{0, 1}, t, J, &wsv, k * kMaxSb, l * kMaxSb, out);
             if (r == 0) { J.sb_nbits[sbi] = out.pos; J.sb_status[sbi] = out.ovf; }
           });
         for (auto& x : th) x.join();
       }
   }
 }
-#else
+#elif defined(THOR_HOSTSIM_WAVES)
+}  // namespace backend
+}  // namespace tk
+#include <atomic>
+#include <thread>
+#include <vector>
+// Multi-wave workgroups: every wavefront of a workgroup is an OS thread with a 1-lane team; the workgroup barrier is a
+// sense-reversing thread barrier and the shared state is accessed with the same atomics as on the device.  This runs
+// the fork/join protocol, the work queue and the key-based pruning of mode_decision_par under real concurrency.
+namespace tk {
+namespace hostwaves {
+struct Bar { int n; std::atomic<int> count{0}; std::atomic<int> sense{0}; };
+static thread_local Bar* tl_bar = nullptr;
+static thread_local int tl_sense = 0;
+void barrier() {
+  Bar* b = tl_bar;
+  if (!b || b->n == 1) return;
+  const int my = tl_sense ^= 1;
+  if (b->count.fetch_add(1, std::memory_order_acq_rel) == b->n - 1) {
+    b->count.store(0, std::memory_order_relaxed);
+    b->sense.store(my, std::memory_order_release);
+  } else {
+    int spins = 0;
+    while (b->sense.load(std::memory_order_acquire) != my)
+      if (++spins > 200) { std::this_thread::yield(); spins = 0; }
+  }
+}
+}  // namespace hostwaves
+namespace backend {
 template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>*, int S) {
-  Team t{0, 1};
+  const int NW = kWaves;
   for (int s = 0; s < S; s++) {
     const FrameJob<PIX>& J = jobs[s];
+    hostwaves::Bar bar;
+    bar.n = NW;
+    xform_tables_fill(&((WgShared*)J.scratch)->tabs, 0, 1);
+    std::vector<std::thread> th;
+    for (int w = 0; w < NW; w++)
+      th.emplace_back([&, w]() {
+        hostwaves::tl_bar = &bar; hostwaves::tl_sense = 0;
+        const Wg wg{w, NW};
+        TeamWs<PIX> wsv = wave_ws<PIX>(J.scratch, w);
+        const Team t{0, 1, wsv.sh->tabs.izz};
+        for (int k = 0; k < J.sb_rows; k++)
+          for (int l = 0; l < J.sb_cols; l++) {
+            const int sbi = k * J.sb_cols + l;
+            if (w == 0) {
+              BitSink out;
+              out.buf = J.sb_bits + (size_t)sbi * J.sb_words; out.pos = 0; out.cap = J.sb_words * 32; out.emit = 1; out.ovf = 0;
+              process_sb(wg, t, J, &wsv, k * kMaxSb, l * kMaxSb, out);
+              J.sb_nbits[sbi] = out.pos;
+              J.sb_status[sbi] = out.ovf;
+            } else
+              wg_helper_loop(wg, t, J, &wsv);
+          }
+      });
+    for (auto& x : th) x.join();
+  }
+}
+#else
+template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>*, int S) {
+  for (int s = 0; s < S; s++) {
+    const FrameJob<PIX>& J = jobs[s];
+    TeamWs<PIX> wsv = wave_ws<PIX>(J.scratch, 0);
+    TeamWs<PIX>* ws = &wsv;
+    xform_tables_fill(&ws->sh->tabs, 0, 1);
+    const Team t{0, 1, ws->sh->tabs.izz};
     for (int k = 0; k < J.sb_rows; k++)
       for (int l = 0; l < J.sb_cols; l++) {
         const int sbi = k * J.sb_cols + l;
-        TeamWs<PIX> wsv = make_ws((SmallWs<PIX>*)(J.scratch + sizeof(BigWs<PIX>)), (BigWs<PIX>*)J.scratch);
-        TeamWs<PIX>* ws = &wsv;
         BitSink out;
         out.buf = J.sb_bits + (size_t)sbi * J.sb_words; out.pos = 0; out.cap = J.sb_words * 32; out.emit = 1; out.ovf = 0;
-        process_sb(t, J, ws, k * kMaxSb, l * kMaxSb, out);
+        process_sb(Wg{0, 1}, t, J, ws, k * kMaxSb, l * kMaxSb, out);
         J.sb_nbits[sbi] = out.pos;
         J.sb_status[sbi] = out.ovf;
       }

@@ -16,8 +16,14 @@ class _FakeEncoder:
         self.S = num_streams
         self.calls = 0
 
-    def stage(self, stream, slot, frame):
-        assert frame.nbytes == 64 * 64 * 3 // 2
+    def stage_device(self, stream, slot, ptr):
+        assert ptr != 0 and 0 <= stream < self.S
+
+    def bitstream(self, stream):
+        return b'\x00\x00\x00\x01\xff' * (stream + 1)
+
+    def recon(self, stream):
+        raise AssertionError('recon is only fetched for verification')
 
     def encode_staged(self, slots):
         assert len(slots) == self.S
@@ -37,7 +43,7 @@ def test_bench_prints_one_contract_line(monkeypatch):
     import thor_amd
     import bench
     monkeypatch.setattr(thor_amd, 'Encoder', _FakeEncoder)
-    monkeypatch.setattr(sys, 'argv', ['bench.py', '--streams', '3', '--width', '64', '--height', '64', '--steps', '2', '--warmup', '1'])
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--streams', '3', '--width', '64', '--height', '64', '--steps', '2', '--warmup', '1', '--no-verify'])
     monkeypatch.delenv('WORLD_SIZE', raising=False)
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
@@ -50,7 +56,8 @@ def test_bench_prints_one_contract_line(monkeypatch):
         assert k in d, k
     assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['higher_is_better'] is True
     assert d['scaling'] == 'weak' and d['vs_baseline'] is None and d['dtype'] == 'u8' and d['data'] == 'synthetic'
-    assert 'workload' in d['config'] and 'model' not in d['config']
+    assert 'workload' in d['config'] and 'model' not in d['config'] and '64x64' in d['config']['workload']
+    assert d['bit_exact'] is None and d['io']['stream_bytes_total'] == 5 * (1 + 2 + 3)
     r = d['roofline']
     for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert k in r, k

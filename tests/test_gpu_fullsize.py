@@ -1,0 +1,56 @@
+"""Full-size parity (-m gpu): the BASELINE.json configurations at their real geometry against golden stream / recon hashes
+recorded from the reference encoder (tests/golden/gen_streams_big.py -> streams_big.json; the reference needs minutes to
+an hour of CPU for these, so they are not run live).  Clips come from the seeded generator (thor_amd/synth.py).
+  * 3840x2160 LDB_high_efficiency I+P (30x17 superblocks, 112-px last row, strides 4160/2080)  - config 4 unit / north star
+  * 3840x2160 RA_high_efficiency qp 27, 9 frames = I, P + a full hierarchical-B sub-GOP with interpolated refs - config 3
+  * 3840x2160 10-bit through the uint16 path (I P P) + a full 16-frame HDB16 sub-GOP at 416x240 10-bit   - config 5
+  * 1920x1080 I+4P: all four references + bi-prediction over them                                         - config 2
+  * 64 closed 1080p streams in one lock-step run, every stream against its own per-chunk reference run     - 8e / the bench regime
+"""
+import json
+import os
+import numpy as np
+import pytest
+from util import ROOT, GOLD, golden_clip, md5
+
+pytestmark = pytest.mark.gpu
+BIG = json.load(open(os.path.join(GOLD, 'streams_big.json')))
+
+
+def _encode(c, clips):
+    import thor_amd
+    over = {}
+    ex = list(c['extra'])
+    while ex:
+        k, v = ex.pop(0), ex.pop(0)
+        over[k[1:]] = v
+    p = thor_amd.load_config(os.path.join(ROOT, 'configs', c['cfg']), width=c['w'], height=c['h'], qp=c['qp'], f=30, **over)
+    with thor_amd.Encoder(p, len(clips)) as enc:
+        bits, recs = enc.encode_clips(clips)
+        return bits, [b''.join(r.tobytes() for r in rs if r is not None) for rs in recs]
+
+
+def _frames(c):
+    raw = np.frombuffer(golden_clip(c['clip']), dtype=np.uint8)
+    fsz = len(raw) // c['n']
+    return [raw[f * fsz:(f + 1) * fsz] for f in range(c['n'])]
+
+
+@pytest.mark.parametrize('name', [n for n in ('1080p_ldb_n5_q32', '4k_ldb_n2_q32', '4k_hdb16_10bit_n3_q32', 'hdb16_416x240_10bit_n17_q32',
+                                              '4k_ra_n9_q27') if n in BIG])
+def test_full_size_configuration_matches_reference_golden(name):
+    c = BIG[name]
+    bits, rec = _encode(c, [_frames(c)])
+    assert len(bits[0]) == c['bit_bytes']
+    assert md5(bits[0]) == c['bit_md5'], 'bitstream differs from the reference'
+    assert md5(rec[0]) == c['rec_md5'], 'reconstruction differs from the reference'
+
+
+def test_64_streams_1080p_each_equals_its_reference_chunk():
+    """The regime bench.py times (many closed streams through the dependency FIFO in one launch per frame): 64 different
+    1080p streams, I + P, each hashed against the reference run on exactly its frames."""
+    names = ['1080p_stream%02d_n2_q32' % s for s in range(64)]
+    c0 = BIG[names[0]]
+    bits, rec = _encode(c0, [_frames(BIG[n]) for n in names])
+    bad = [n for i, n in enumerate(names) if md5(bits[i]) != BIG[n]['bit_md5'] or md5(rec[i]) != BIG[n]['rec_md5']]
+    assert not bad, f'{len(bad)} of 64 streams differ from their reference chunk: {bad[:4]}'

@@ -46,6 +46,19 @@ def test_engine_multi_lane_host_simulation_matches_golden(name):
     assert md5(rec) == c['rec_md5'], 'reconstruction differs from the reference'
 
 
+@pytest.mark.parametrize('name', ['192x128_n6_q32', '208x120_n4_q32', '128x96_n9_q32_ra', '192x128_n6_q30_ra_gop4', '192x128_n4_q32_10bit',
+                                  '192x128_n5_q32_hdb16_gop4_10bit', '208x120_n4_q30_ldb_medium'])
+def test_engine_multi_wave_host_simulation_matches_golden(name):
+    """Workgroups of 4 wavefronts (one OS thread each): the block decision of the encoder_speed 0 operating points is
+    spread over the waves through a work queue (tk_block.h:mode_decision_par) - fork/join barriers, atomics on the shared
+    state and key-based pruning run under real concurrency; the result must not depend on the interleaving."""
+    c = G[name]
+    for _ in range(2):
+        bits, rec = run_encoder(build_hostsim(waves=4), golden_clip(c['clip']), c['w'], c['h'], c['n'], c['qp'], c['extra'], cfg=c.get('cfg'))
+        assert md5(bits) == c['bit_md5'], 'stream differs from the reference'
+        assert md5(rec) == c['rec_md5'], 'reconstruction differs from the reference'
+
+
 @needs_ref
 def test_host_simulation_two_random_access_streams_equal_reference_chunks():
     """Two closed RA streams (hierarchical B + interpolated references, host-threaded interpolation) in lock step ==

@@ -65,14 +65,16 @@ def build_oracle_c():
     return C.CDLL(out)
 
 
-def build_hostsim(lanes=1):
-    """Host simulation of the engine sources (tests only): 1-lane teams, or `lanes` OS threads per team."""
-    out = os.path.join(ROOT, 'tests', 'hostsim', 'hostsim' if lanes == 1 else f'hostsim_l{lanes}')
+def build_hostsim(lanes=1, waves=1):
+    """Host simulation of the engine sources (tests only): 1-lane teams, `lanes` OS threads per team, or `waves`
+    wavefronts (OS threads, 1-lane teams) per workgroup."""
+    assert lanes == 1 or waves == 1
+    out = os.path.join(ROOT, 'tests', 'hostsim', f'hostsim_w{waves}' if waves > 1 else ('hostsim' if lanes == 1 else f'hostsim_l{lanes}'))
     src = os.path.join(ROOT, 'tests', 'hostsim', 'hostsim.cpp')
     csrc = os.path.join(ROOT, 'thor_amd', 'csrc')
     newest = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc)])
     if not os.path.exists(out) or os.path.getmtime(out) < newest:
-        extra = ['-pthread'] + ([] if lanes == 1 else [f'-DTHOR_HOSTSIM_LANES={lanes}'])
+        extra = ['-pthread'] + ([] if lanes == 1 else [f'-DTHOR_HOSTSIM_LANES={lanes}']) + ([] if waves == 1 else [f'-DTHOR_HOSTSIM_WAVES={waves}'])
         subprocess.check_call(['g++', '-std=c++17', '-O2', '-DTHOR_HOSTSIM', '-ffp-contract=off'] + extra + ['-o', out, src])
     return out
 

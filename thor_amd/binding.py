@@ -61,6 +61,7 @@ def lib():
         L.thor_hip_begin_sequence.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.thor_hip_next_frame.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.thor_hip_stage_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.thor_hip_stage_frame_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.thor_hip_encode_staged.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.thor_hip_encode_frame.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.thor_hip_stream_bytes.restype = C.c_size_t
@@ -112,6 +113,12 @@ class Encoder:
         rc = lib().thor_hip_stage_frame(self.h, stream, slot, frame.ctypes.data_as(C.c_void_p))
         if rc:
             raise RuntimeError(f'thor_hip_stage_frame rc={rc}')
+
+    def stage_device(self, stream, slot, dev_ptr):
+        """Stage a frame that already lives in HBM (device pointer to a contiguous planar 4:2:0 frame)."""
+        rc = lib().thor_hip_stage_frame_device(self.h, stream, slot, C.c_void_p(dev_ptr))
+        if rc:
+            raise RuntimeError(f'thor_hip_stage_frame_device rc={rc}')
 
     def begin_sequence(self, stream, skip, num_frames, file_frames):
         """Fix the chunk [skip, skip+num_frames) of a file_frames-long input (thor_hip_begin_sequence)."""

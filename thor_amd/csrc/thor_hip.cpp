@@ -1,6 +1,6 @@
 // thor_hip.cpp - libthor_hip.so: gfx950 kernels, device backend and the C ABI (include/thor_hip.h).
-// One 64-lane wavefront (= one workgroup) encodes one 128x128 superblock at a time; one persistent,
-// dependency-driven launch per frame covers every superblock of every stream (SB(k,l) needs (k,l-1) and
+// One workgroup of 4 wavefronts encodes one 128x128 superblock at a time (wave 0 walks the quadtree, all four share the
+// trials of each block decision); one persistent, dependency-driven launch per frame covers every superblock of every stream (SB(k,l) needs (k,l-1) and
 // (k-1,l+1)).  There is NO CPU path in this library: every entry point aborts if no
 // HIP device is usable.
 #include <hip/hip_runtime.h>
@@ -83,15 +83,23 @@ __device__ inline void df_done_dep(const DfArgs& A, unsigned base, int k, int l)
   }
 }
 
-template <typename PIX> __global__ __launch_bounds__(64, 3) void k_superblocks(const FrameJob<PIX>* jobs, DfArgs A) {
+// Workgroup = kWaves wavefronts on one superblock: wave 0 walks the quadtree (process_sb), the others are parked on
+// the workgroup barrier and take work items of the block decisions (tk_block.h:mode_decision_par).  3 workgroups of
+// 4 waves per CU = 3 waves per SIMD (168 VGPRs each), 768 workgroups resident on the chip.
+enum { kWgThreads = 64 * kWaves };
+template <typename PIX> __global__ __launch_bounds__(kWgThreads, 3) void k_superblocks(const FrameJob<PIX>* jobs, DfArgs A) {
   __shared__ FrameJob<PIX> sJ;
-  __shared__ SmallWs<PIX> sws;
+  __shared__ WgShared sh;
+  __shared__ SmallWs<PIX> sws[kWaves];
   __shared__ unsigned s_task;
   const FrameJob<PIX>& J = sJ;
   const unsigned total = (unsigned)A.S * (unsigned)A.nsb;
-  TeamWs<PIX> wsv = make_ws(&sws, (BigWs<PIX>*)(A.pool + (size_t)blockIdx.x * A.slot_bytes));
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+  const Wg wg{wave, kWaves};
+  TeamWs<PIX> wsv = make_ws(&sws[wave], &sh, (BigWs<PIX>*)(A.pool + ((size_t)blockIdx.x * kWaves + wave) * A.slot_bytes));
   TeamWs<PIX>* ws = &wsv;
-  Team t{(int)threadIdx.x, 64, sws.xf.izz};  // scan tables: filled by process_sb (xform_tables_init)
+  const Team t{lane, 64, sh.tabs.izz};
+  xform_tables_fill(&sh.tabs, (int)threadIdx.x, kWgThreads);  // constant: once per workgroup
   for (;;) {
     __syncthreads();
     unsigned long long tpop = 0;
@@ -109,27 +117,30 @@ template <typename PIX> __global__ __launch_bounds__(64, 3) void k_superblocks(c
     {
       const uint32_t* src = (const uint32_t*)&jobs[sidx];
       uint32_t* dst = (uint32_t*)&sJ;
-      for (int i = threadIdx.x; i < (int)(sizeof(FrameJob<PIX>) / 4); i += 64) dst[i] = src[i];
+      for (int i = threadIdx.x; i < (int)(sizeof(FrameJob<PIX>) / 4); i += kWgThreads) dst[i] = src[i];
     }
 #ifdef THOR_PROF
-    if (threadIdx.x < kProfSlots) sws.prof[threadIdx.x] = 0;
+    if (lane < kProfSlots) sws[wave].prof[lane] = 0;
 #endif
     __syncthreads();
-    if (A.times && threadIdx.x == 0) { A.times[3 * (size_t)task] = tpop; A.times[3 * (size_t)task + 1] = wall_clock64(); }
-    BitSink out;
-    out.buf = J.sb_bits + (size_t)sb * J.sb_words;
-    out.pos = 0;
-    out.cap = J.sb_words * 32;
-    out.emit = 1;
-    out.ovf = 0;
-    process_sb(t, J, ws, k * kMaxSb, l * kMaxSb, out);
-    if (threadIdx.x == 0) {
-      J.sb_nbits[sb] = out.pos;
-      J.sb_status[sb] = out.ovf;
-    }
+    if (wave == 0) {
+      if (A.times && lane == 0) { A.times[3 * (size_t)task] = tpop; A.times[3 * (size_t)task + 1] = wall_clock64(); }
+      BitSink out;
+      out.buf = J.sb_bits + (size_t)sb * J.sb_words;
+      out.pos = 0;
+      out.cap = J.sb_words * 32;
+      out.emit = 1;
+      out.ovf = 0;
+      process_sb(wg, t, J, ws, k * kMaxSb, l * kMaxSb, out);
+      if (lane == 0) {
+        J.sb_nbits[sb] = out.pos;
+        J.sb_status[sb] = out.ovf;
+      }
+    } else
+      wg_helper_loop(wg, t, J, ws);
 #ifdef THOR_PROF
     __syncthreads();
-    if (J.prof && threadIdx.x < kProfSlots) atomicAdd((unsigned long long*)&J.prof[threadIdx.x], (unsigned long long)sws.prof[threadIdx.x]);
+    if (J.prof && lane < kProfSlots) atomicAdd((unsigned long long*)&J.prof[lane], (unsigned long long)sws[wave].prof[lane]);
 #endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
@@ -322,7 +333,7 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
     D = DfState();
     D.S = S; D.nsb = nsb; D.slot = slot;
     int per_cu = 0;
-    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_superblocks<PIX>, 64, 0));
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_superblocks<PIX>, kWgThreads, 0));
     hipDeviceProp_t prop;
     int dev = 0;
     HIPCHECK(hipGetDevice(&dev));
@@ -333,7 +344,7 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
     HIPCHECK(hipMalloc(&D.ctl, sizeof(DfCtl)));
     HIPCHECK(hipMalloc(&D.queue, sizeof(unsigned) * total));
     HIPCHECK(hipMalloc(&D.cnt, sizeof(unsigned) * total));
-    HIPCHECK(hipMalloc(&D.pool, slot * (size_t)D.wgs));
+    HIPCHECK(hipMalloc(&D.pool, slot * (size_t)D.wgs * kWaves));  // one BigWs slot per wavefront
     if (getenv("THOR_SBTIMES")) { HIPCHECK(hipMalloc(&D.times, sizeof(unsigned long long) * 3 * total)); }
   }
   // frame start: only SB(0,0) of every stream is ready
@@ -354,7 +365,7 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
   if (const char* e = getenv("THOR_HIP_SPIN_TIMEOUT_S")) lim_s = atof(e);
   A.spin_limit = (unsigned long long)(lim_s * 1e8);
   auto ev = ev_begin();
-  hipLaunchKernelGGL(k_superblocks<PIX>, dim3(D.wgs), dim3(64), 0, g_stream, jobs, A);
+  hipLaunchKernelGGL(k_superblocks<PIX>, dim3(D.wgs), dim3(kWgThreads), 0, g_stream, jobs, A);
   g_clk.sb_launches++;
   HIPCHECK(hipEventRecord(ev.second, g_stream));
   g_sb_events.push_back(ev);
@@ -630,6 +641,29 @@ int thor_hip_stage_frame(thor_hip_encoder* e, int stream, int slot, const void* 
   return 0;
 }
 
+// Same as thor_hip_stage_frame for a frame that already lives in HBM (e.g. a torch CUDA tensor the caller derived from a
+// clip broadcast over RCCL): three device-to-device 2-D copies on the library's stream; the source may be released
+// when the call returns.
+int thor_hip_stage_frame_device(thor_hip_encoder* e, int stream, int slot, const void* dev_yuv) {
+  if (!e || stream < 0 || stream >= e->S || slot < 0 || !dev_yuv) return 1;
+  ENC_DISPATCH(e, {
+    auto& v = E.staged[stream];
+    if ((int)v.size() <= slot) v.resize(slot + 1);
+    if (!v[slot].base_y) v[slot].alloc(e->sp.width, e->sp.height, 0);
+    const int w = e->sp.width;
+    const int h = e->sp.height;
+    const PIXT* src = (const PIXT*)dev_yuv;
+    const Plane3<PIXT>& d = v[slot].p;
+    HIPCHECK(hipMemcpy2DAsync(d.y, (size_t)d.sy * sizeof(PIXT), src, (size_t)w * sizeof(PIXT), (size_t)w * sizeof(PIXT), h, hipMemcpyDeviceToDevice, g_stream));
+    src += (size_t)w * h;
+    HIPCHECK(hipMemcpy2DAsync(d.u, (size_t)d.sc * sizeof(PIXT), src, (size_t)(w / 2) * sizeof(PIXT), (size_t)(w / 2) * sizeof(PIXT), h / 2, hipMemcpyDeviceToDevice, g_stream));
+    src += (size_t)(w / 2) * (h / 2);
+    HIPCHECK(hipMemcpy2DAsync(d.v, (size_t)d.sc * sizeof(PIXT), src, (size_t)(w / 2) * sizeof(PIXT), (size_t)(w / 2) * sizeof(PIXT), h / 2, hipMemcpyDeviceToDevice, g_stream));
+    HIPCHECK(hipStreamSynchronize(g_stream));
+  });
+  return 0;
+}
+
 int thor_hip_encode_staged(thor_hip_encoder* e, const int* slots) {
   if (!e || !slots) return 1;
   int rc = 0;
@@ -867,10 +901,13 @@ __global__ __launch_bounds__(64) void k_kat_interp(const uint8_t* ref0, int rstr
 __global__ __launch_bounds__(64) void k_kat_tu(const uint8_t* org, const uint8_t* pred, int size, int qp, int coeff_type, int fast,
                                               int16_t* coefq, uint8_t* rec, int* cbp) {
   __shared__ XformWs xf;
+  __shared__ XformTabs tabs;
   __shared__ int16_t cq[256];
-  Team t{(int)threadIdx.x, 64, xf.izz};
+  Team t{(int)threadIdx.x, 64, tabs.izz};
   xf.prof = nullptr;
-  xform_tables_init(t, &xf);
+  xf.tabs = &tabs;
+  xform_tables_fill(&tabs, (int)threadIdx.x, 64);
+  t.sync();
   const int i = blockIdx.x, qs = size < 16 ? size : 16;
   const size_t o = (size_t)i * size * size;
   int c = code_tu(t, &xf, org + o, size, pred + o, size, rec + o, size, size, qp, coeff_type, fast, cq, 8);

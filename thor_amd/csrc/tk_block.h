@@ -29,10 +29,32 @@ struct Node {
   BlkParam best;
 };
 
-// Per-team working set.  The small, latency-critical part (transform tiles, candidate tables,
-// coefficient buffers, the recursion stack) lives in LDS on the GPU; the sample blocks (up to
-// 128x128) live in a per-team global scratch arena that stays L1/L2 resident.
+// Working set.  Per workgroup (= per superblock in flight): WgShared - constant tables, the per-SB candidate
+// lists, the recursion stack of the master wave and the fork/join state of the parallel block decision.  Per
+// wavefront: SmallWs (LDS: transform tiles, ME scratch, coefficient buffers, intra edges) and BigWs (sample blocks
+// up to 128x128 in a global scratch arena that stays L1/L2 resident).
 enum { kProfSlots = 32 };
+enum { kMdMaxItems = 32 };
+enum { MD_SKIP = 0, MD_MERGE, MD_REF, MD_INTRA, MD_BIPRED };
+enum { WG_CMD_EXIT = 0, WG_CMD_MD = 1 };
+struct MdItem { int8_t kind, a, b, pad; };
+struct WgShared {
+  XformTabs tabs;
+  MeLists lists;
+  Node stack[5];
+  // ---- parallel block decision (mode_decision_par)
+  int cmd;                       // what the parked waves do after the next workgroup barrier
+  int next_item, n_items;        // work queue cursor (atomic) / length
+  int refs_done, n_ref_items;    // reference searches finished (atomic) / expected; the last one triggers the bipred item
+  int do_bipred;
+  int node;                      // index of the node being decided in `stack`
+  mv_t mvp;
+  mv_t mv_center[kMaxRefs];
+  unsigned long long bestkey;    // min over finished trials of (cost << 32 | evaluation order), atomic
+  unsigned long long wkey[kWaves];
+  BlkParam wbest[kWaves];
+  MdItem items[kMdMaxItems];
+};
 template <typename PIX> struct SmallWs {
   XformWs xf;
   MeWs me;
@@ -42,7 +64,6 @@ template <typename PIX> struct SmallWs {
   // use the BigWs buffers instead.
   int16_t coef_y[4 * 256], coef_u[256], coef_v[256];
   unsigned long long acc[12];
-  Node stack[5];
 #if defined(THOR_PROF)
   long long prof[kProfSlots];
 #else
@@ -64,16 +85,18 @@ template <typename PIX> struct TeamWs {  // view (lives in registers)
   int16_t *coef_y, *coef_u, *coef_v;          // current (may point at the big chroma buffers)
   int16_t *coef_u_small, *coef_v_small, *coef_u_big, *coef_v_big;
   unsigned long long* acc;
+  WgShared* sh;
   Node* stack;
   long long* prof;
   PIX *pred_y, *pred_u, *pred_v, *p0_y, *p0_u, *p0_v, *p1_y, *p1_u, *p1_v, *rec_y, *rec_u, *rec_v, *org8;
 };
-template <typename PIX> TK_DEV TeamWs<PIX> make_ws(SmallWs<PIX>* s, BigWs<PIX>* g) {
+template <typename PIX> TK_DEV TeamWs<PIX> make_ws(SmallWs<PIX>* s, WgShared* sh, BigWs<PIX>* g) {
   TeamWs<PIX> w;
   w.xfp = &s->xf; w.mep = &s->me; w.edgep = &s->edge;
+  w.sh = sh; s->xf.tabs = &sh->tabs; s->me.lists = &sh->lists;
   w.coef_y = s->coef_y; w.coef_u = s->coef_u; w.coef_v = s->coef_v;
   w.coef_u_small = s->coef_u; w.coef_v_small = s->coef_v; w.coef_u_big = g->coef_u_big; w.coef_v_big = g->coef_v_big;
-  w.acc = s->acc; w.stack = s->stack; w.prof = s->prof;
+  w.acc = s->acc; w.stack = sh->stack; w.prof = s->prof;
   s->xf.prof = s->prof; s->me.prof = s->prof;
   w.pred_y = g->pred_y; w.pred_u = g->pred_u; w.pred_v = g->pred_v;
   w.p0_y = g->p0_y; w.p0_u = g->p0_u; w.p0_v = g->p0_v;
@@ -350,8 +373,15 @@ TK_DEV void predict_inter(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
 // term, so once the luma planes are coded, SSD_Y + (unsigned)(lambda * luma coefficient bits + 0.5) is a lower
 // bound of the final cost: if it already reaches the threshold the chroma transform units, CfL, the bit count
 // and the cost evaluation are skipped and the trial is reported as "not better" - results are unchanged.
+// Parallel decision (mode_decision_par): the trials of one block run on several wavefronts in no particular order,
+// so the threshold is the shared minimum over all FINISHED trials of the key (cost << 32 | evaluation order) - the
+// winner is the trial with the smallest key, which is exactly the reference's "first strictly smaller cost in
+// evaluation order".  A trial whose lower-bound key (lb << 32 | its order) already exceeds that minimum cannot have
+// the smallest key, whatever the timing: pruning stays exact and only the amount of skipped work varies.
 struct PruneCtx {
   unsigned thr;       // prune when the lower bound is >= thr (0xffffffff: never)
+  const unsigned long long* bestkey;  // parallel decision: shared minimum key (nullptr: use thr)
+  unsigned order;                     // evaluation order of this trial
   double lambda;
   long long ssd_y;    // out: luma SSD of the trial (reused by rd_cost), -1 if not computed
   int ybits[4];       // out: luma coefficient bits per TU
@@ -363,10 +393,16 @@ struct PruneCtx {
 
 // tb-split luma: call after quadrant `tu` (0..3, size s2 at (i,j) of the block) has been coded.  The first three
 // quadrants give an early lower bound; after the fourth the accumulated values are the block's luma SSD / bits.
+TK_DEV int prune_active(const PruneCtx* pc) { return pc && (pc->bestkey || pc->thr != 0xffffffffu); }
+TK_DEV int prune_hit(const PruneCtx* pc, unsigned long long lb) {
+  if (pc->bestkey) return ((lb << 32) | (unsigned long long)pc->order) > wg_load64(pc->bestkey);
+  return lb >= (unsigned long long)pc->thr;
+}
+
 template <typename PIX>
 TK_DEV int prune_after_quadrant(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int intra, int tu, int i, int j,
                                 int s2, int bit, const int16_t* coef, PruneCtx* pc) {
-  if (!pc || pc->thr == 0xffffffffu) return 0;
+  if (!prune_active(pc)) return 0;
   t.sync();
   if (t.rank == 0) ws->acc[1] = 0;
   t.sync();
@@ -380,16 +416,16 @@ TK_DEV int prune_after_quadrant(const Team t, const FrameJob<PIX>& J, TeamWs<PIX
   unsigned long long lb = ((unsigned long long)pc->ssd_part >> (J.cfg.bitdepth * 2 - 16)) + (unsigned long long)(long long)mul_add_nofma(pc->lambda, (double)pc->bits_part, 0.5);
   if (lb > (1ull << 30)) lb = 1ull << 30;
 #if TK_HOST
-  { extern long long g_prune_stat[8]; g_prune_stat[4] += 1; if (lb >= (unsigned long long)pc->thr) g_prune_stat[5 + (tu == 3)] += 1; }
+  { extern long long g_prune_stat[8]; g_prune_stat[4] += 1; if (prune_hit(pc, lb)) g_prune_stat[5 + (tu == 3)] += 1; }
 #endif
-  if (lb >= (unsigned long long)pc->thr) { pc->pruned = 1; return 1; }
+  if (team_bcast0(t, prune_hit(pc, lb))) { pc->pruned = 1; return 1; }  // one lane's reading decides for the wave
   return 0;
 }
 
 template <typename PIX>
 TK_DEV int prune_after_luma(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, const BlkParam& p, int cbp_y,
                             int tb_split, PruneCtx* pc) {
-  if (!pc || pc->thr == 0xffffffffu) return 0;
+  if (!prune_active(pc)) return 0;
   if (pc->pruned) return 1;
   if (pc->have_ybits) return 0;  // tb-split luma: bound already evaluated quadrant by quadrant
   const int size = nd.size;
@@ -417,9 +453,9 @@ TK_DEV int prune_after_luma(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* w
   unsigned long long lb = (ssd >> (J.cfg.bitdepth * 2 - 16)) + (unsigned long long)(long long)mul_add_nofma(pc->lambda, (double)bits, 0.5);
   if (lb > (1ull << 30)) lb = 1ull << 30;
 #if TK_HOST
-  { extern long long g_prune_stat[8]; g_prune_stat[p.mode == M_INTRA ? 0 : 2] += 1; if (lb >= (unsigned long long)pc->thr) g_prune_stat[p.mode == M_INTRA ? 1 : 3] += 1; }
+  { extern long long g_prune_stat[8]; g_prune_stat[p.mode == M_INTRA ? 0 : 2] += 1; if (prune_hit(pc, lb)) g_prune_stat[p.mode == M_INTRA ? 1 : 3] += 1; }
 #endif
-  if (lb >= (unsigned long long)pc->thr) { pc->pruned = 1; return 1; }
+  if (team_bcast0(t, prune_hit(pc, lb))) { pc->pruned = 1; return 1; }  // one lane's reading decides for the wave
   return 0;
 }
 
@@ -566,17 +602,18 @@ TK_DEVNI int encode_block(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
 // One RDO trial: count bits, evaluate cost, keep `best` (copy_best_parameters, :1615-1677).
 template <typename PIX>
 TK_DEV unsigned rdo_trial(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BlkParam& p, double lambda,
-                          int reuse_pred = 0, unsigned prune_thr = 0xffffffffu) {
+                          int reuse_pred = 0, unsigned prune_thr = 0xffffffffu, const unsigned long long* bestkey = nullptr,
+                          unsigned order = 0) {
   BitSink cnt;
   cnt.buf = nullptr; cnt.pos = 0; cnt.cap = 0; cnt.emit = 0; cnt.ovf = 0;
   PruneCtx pc;
-  pc.thr = prune_thr; pc.lambda = lambda; pc.ssd_y = -1; pc.have_ybits = 0; pc.pruned = 0; pc.ssd_part = 0; pc.bits_part = 0;
+  pc.thr = prune_thr; pc.bestkey = bestkey; pc.order = order; pc.lambda = lambda; pc.ssd_y = -1; pc.have_ybits = 0; pc.pruned = 0; pc.ssd_part = 0; pc.bits_part = 0;
   int nbits = encode_block(t, J, ws, nd, p, cnt, reuse_pred, &pc);
   if (pc.pruned) return kCostInit;  // lower bound >= threshold: cannot be selected
   return rd_cost(t, J, ws, nd, nbits, lambda, pc.ssd_y);
 }
 
-TK_DEV void keep_best(Node& nd, const BlkParam& p) {
+TK_DEV BlkParam normalize_best(const Node& nd, const BlkParam& p) {
   BlkParam b = p;
   if (p.mode == M_SKIP || p.mode == M_MERGE) {
     const InterPred& c = (p.mode == M_SKIP) ? nd.skip[p.skip_idx] : nd.merge[p.skip_idx];
@@ -587,8 +624,9 @@ TK_DEV void keep_best(Node& nd, const BlkParam& p) {
     for (int i = 0; i < 4; i++) { b.mv0[i] = mk_mv(0, 0); b.mv1[i] = mk_mv(0, 0); }
   } else if (p.mode == M_INTER) b.dir = 0;
   else b.dir = 2;
-  nd.best = b;
+  return b;
 }
+TK_DEV void keep_best(Node& nd, const BlkParam& p) { nd.best = normalize_best(nd, p); }
 
 TK_DEV void set_cand(BlkParam& p, const InterPred& c, int idx, int mode) {
   p.mode = (int8_t)mode;
@@ -790,7 +828,7 @@ TK_DEVNI unsigned mode_decision(const Team t, const FrameJob<PIX>& J, TeamWs<PIX
       const PIX* oy = J.orig.y + nd.ypos * J.orig.sy + nd.xpos;
       int min_idx = 0, max_idx = J.num_ref - 1;
       {
-        const int br = ws->mep->best_ref;
+        const int br = ws->mep->lists->best_ref;
         if (!(br < 0 || c.encoder_speed < 2 || c.enable_bipred)) min_idx = max_idx = br;
       }
       if (J.frame_type == F_B && J.interp_ref > 2) min_idx = 1;
@@ -834,7 +872,7 @@ TK_DEVNI unsigned mode_decision(const Team t, const FrameJob<PIX>& J, TeamWs<PIX
       // is never updated in the reference, encode_block.c:1868/2018-2019); uint32 wrap-around as in C.
       if (worst_cost && worst_cost * 3u > best_cost * 4u) {
         t.sync();
-        if (t.rank == 0) ws->mep->best_ref = 0;
+        if (t.rank == 0) ws->mep->lists->best_ref = 0;
         t.sync();
       }
       TK_PROF_ACC(ws, 27, pu0_);
@@ -917,6 +955,229 @@ TK_DEVNI unsigned mode_decision(const Team t, const FrameJob<PIX>& J, TeamWs<PIX
     TK_PROF_ACC(ws, 26, pi0_);
   }
   return min_cost;
+}
+
+// ---------------------------------------------------------------------------------
+// mode_decision_rdo for the encoder_speed 0 operating points, spread over the wavefronts of the workgroup.
+//
+// The reference walks the trials of a block one after the other and keeps the first strictly smaller cost
+// (encode_block.c:1885-2114).  Given the entry state most of them are independent:
+//   * the uni-prediction search of each reference (its candidate list mvcand[r] is private to the reference) and the
+//     12 RDO trials that follow it,
+//   * the skip / merge candidates,
+//   * the 10 intra modes x 2 transform splits,
+// and only the bi-prediction search needs something from the others (the PART_NONE vector of every reference).
+// Every such unit is a work item in a queue in LDS; the waves pop items until the queue is empty; the wave that
+// finishes the LAST reference search runs the bi-prediction item.  Every trial has the index of its position in the
+// reference's evaluation order, the winner is the trial with the smallest (cost << 32 | order) - the very trial the
+// sequential strict-'<' scan would keep - and pruning compares lower-bound keys with the shared minimum (PruneCtx).
+// With a single wave the queue is simply processed in the reference's order.
+// Evaluation order indices: skip k: k | merge k, tb: 2+2k+tb | inter r, part, tb: 6+12r+3part+(tb+1) |
+// bipred tb: 54+tb, joint (B frames): 56 | intra m, tb: 57+2m+tb.
+// ---------------------------------------------------------------------------------
+TK_DEV BlkParam blank_param() {
+  BlkParam p;
+  p.mode = M_SKIP; p.intra_mode = 0; p.skip_idx = 0; p.pb_part = P_NONE; p.ref0 = p.ref1 = 0; p.dir = 0;
+  p.tb_param = 0; p.tb_split = 0; p.cbp_y = p.cbp_u = p.cbp_v = 0;
+  for (int i = 0; i < 4; i++) { p.mv0[i] = mk_mv(0, 0); p.mv1[i] = mk_mv(0, 0); }
+  return p;
+}
+
+template <typename PIX> struct MdCtx {
+  Wg wg;
+  WgShared* sh;
+  Node* nd;
+  unsigned long long mykey;  // best key among this wave's trials
+};
+
+template <typename PIX>
+TK_DEV void par_trial(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, MdCtx<PIX>& M, BlkParam& p, unsigned order, int reuse_pred) {
+  const unsigned cost = rdo_trial(t, J, ws, *M.nd, p, J.lambda, reuse_pred, 0xffffffffu, &M.sh->bestkey, order);
+  if (cost == (unsigned)kCostInit) return;  // pruned: cannot have the smallest key
+  const unsigned long long key = ((unsigned long long)cost << 32) | order;
+  if (key < M.mykey) {
+    M.mykey = key;
+    if (t.rank == 0) {
+      M.sh->wbest[M.wg.wave] = normalize_best(*M.nd, p);
+      M.sh->wkey[M.wg.wave] = key;
+      wg_min64(&M.sh->bestkey, key);
+    }
+    t.sync();
+  }
+}
+
+template <typename PIX>
+TK_DEVNI void md_item_bipred(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, MdCtx<PIX>& M) {
+  const EncCfg& c = J.cfg;
+  Node& nd = *M.nd;
+  const int size = nd.size;
+  const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
+  const mv_t mvp = M.sh->mvp;
+  mv_t mv_center[kMaxRefs];
+  for (int r = 0; r < kMaxRefs; r++) mv_center[r] = M.sh->mv_center[r];
+  int r0, r1;
+  mv_t a0[4], a1[4];
+  search_bipred(t, J, ws, nd, 0, mv_center, mvp, &r0, &r1, a0, a1);
+  BlkParam p = blank_param();
+  p.mode = M_BIPRED; p.pb_part = P_NONE;
+  p.ref0 = (int8_t)r0; p.ref1 = (int8_t)r1;
+  for (int i = 0; i < 4; i++) { p.mv0[i] = a0[i]; p.mv1[i] = a1[i]; }
+  for (int tb = 0; tb <= max_tb - 1; tb++) {
+    p.tb_param = (int8_t)tb;
+    par_trial(t, J, ws, M, p, 54u + (unsigned)tb, tb > 0);
+  }
+  if (J.frame_type == F_B) {
+    // joint +mv / -mv search (search_bipred_prediction_params me_mode 1, encode_block.c:1708-1737, 2052-2068)
+    const int ri0 = J.interp_ref ? 1 : 0, ri1 = J.interp_ref ? 2 : 1;
+    const Plane3<PIX>& f0 = J.ref[ri0];
+    const Plane3<PIX>& f1 = J.ref[ri1];
+    const PIX* oy = J.orig.y + nd.ypos * J.orig.sy + nd.xpos;
+    MeArgs a;
+    a.cb_size = size; a.ostride = J.orig.sy; a.width = size; a.height = size; a.rstride = f0.sy; a.sign = 0;
+    a.fwidth = c.width; a.fheight = c.height; a.xpos = nd.xpos; a.ypos = nd.ypos; a.enable_bipred = 1;
+    a.bitdepth = c.bitdepth; a.lam = J.sqrt_lambda; a.speed = c.encoder_speed;
+    mv_t mvb;
+    motion_estimate_bi(t, ws->mep, oy, f0.y + nd.ypos * f0.sy + nd.xpos, f1.y + nd.ypos * f1.sy + nd.xpos, a, mv_center[ri0], mvp, ri0, &mvb);
+    p.mode = M_BIPRED; p.pb_part = P_NONE;
+    p.ref0 = (int8_t)ri0; p.ref1 = (int8_t)ri1;
+    for (int i = 0; i < 4; i++) { p.mv0[i] = mvb; p.mv1[i] = mvb; }
+    p.tb_param = 0;
+    par_trial(t, J, ws, M, p, 56u, 0);
+  }
+}
+
+template <typename PIX>
+TK_DEVNI void md_item_ref(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, MdCtx<PIX>& M, int r) {
+  const EncCfg& c = J.cfg;
+  Node& nd = *M.nd;
+  const int size = nd.size;
+  const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
+  const int max_pb = c.enable_pb_split ? 4 : 1;
+  const mv_t mvp = M.sh->mvp;
+  const PIX* oy = J.orig.y + nd.ypos * J.orig.sy + nd.xpos;
+  if (t.rank == 0) add_mvcand(ws->mep, r, mvp);
+  t.sync();
+  mv_t mv_center = mvp;
+  mv_t mv_all[4][4];
+  for (int part = 0; part < max_pb; part++) {
+    search_inter(t, J, ws, nd.ypos, nd.xpos, size, oy, J.orig.sy, r, mv_center, mvp, mv_all[part], part, J.sign[r]);
+    add_cands4(t, ws, r, mv_all[part]);
+    mv_center = mv_all[0][0];
+  }
+  if (t.rank == 0) M.sh->mv_center[r] = mv_center;
+  BlkParam p = blank_param();
+  p.mode = M_INTER;
+  p.ref0 = p.ref1 = (int8_t)r;
+  for (int part = 0; part < max_pb; part++) {
+    p.pb_part = (int8_t)part;
+    for (int i = 0; i < 4; i++) { p.mv0[i] = mv_all[part][i]; p.mv1[i] = mv_all[part][i]; }
+    for (int tb = -1; tb <= max_tb - 1; tb++) {
+      p.tb_param = (int8_t)tb;
+      par_trial(t, J, ws, M, p, 6u + 12u * (unsigned)r + 3u * (unsigned)part + (unsigned)(tb + 1), tb > -1);
+    }
+  }
+}
+
+// Executed by every wave of the workgroup between the fork and the join barrier.
+template <typename PIX>
+TK_DEVNI void md_worker(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws) {
+  WgShared* sh = ws->sh;
+  MdCtx<PIX> M;
+  M.wg = wg; M.sh = sh; M.nd = &sh->stack[sh->node]; M.mykey = ~0ull;
+  const EncCfg& c = J.cfg;
+  const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
+  const int n_items = sh->n_items;
+  for (;;) {
+    int i = 0;
+    if (t.rank == 0) i = wg_fetch_add(&sh->next_item, 1);
+    i = team_bcast0(t, i);
+    if (i >= n_items) break;
+    const MdItem it = sh->items[i];
+    const int kind = team_bcast0(t, it.kind), ia = team_bcast0(t, it.a), ib = team_bcast0(t, it.b);
+    if (kind == MD_SKIP) {
+      BlkParam p = blank_param();
+      set_cand(p, M.nd->skip[ia], ia, M_SKIP);
+      par_trial(t, J, ws, M, p, (unsigned)ia, 0);
+    } else if (kind == MD_MERGE) {
+      BlkParam p = blank_param();
+      set_cand(p, M.nd->merge[ia], ia, M_MERGE);
+      for (int tb = 0; tb <= max_tb - 1; tb++) {
+        p.tb_param = (int8_t)tb;
+        par_trial(t, J, ws, M, p, 2u + 2u * (unsigned)ia + (unsigned)tb, tb > 0);
+      }
+    } else if (kind == MD_INTRA) {
+      BlkParam p = blank_param();
+      p.mode = M_INTRA; p.intra_mode = (int8_t)ia; p.tb_param = (int8_t)ib;
+      par_trial(t, J, ws, M, p, 57u + 2u * (unsigned)ia + (unsigned)ib, 0);
+    } else if (kind == MD_REF) {
+      md_item_ref(t, J, ws, M, ia);
+      t.sync();
+      int done = 0;
+      if (t.rank == 0) done = wg_fetch_add(&sh->refs_done, 1) + 1;
+      done = team_bcast0(t, done);
+      if (done == sh->n_ref_items && sh->do_bipred) md_item_bipred(t, J, ws, M);
+    }
+  }
+}
+
+// Parked waves: woken by the master at every fork until it posts WG_CMD_EXIT at the end of the superblock.
+template <typename PIX>
+TK_DEV void wg_helper_loop(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws) {
+  for (;;) {
+    wg.barrier();
+    const int cmd = team_bcast0(t, ws->sh->cmd);
+    if (cmd == WG_CMD_EXIT) { wg.barrier(); break; }  // second barrier: every wave has read the command before the master reuses it
+    md_worker(wg, t, J, ws);
+    t.sync();
+    wg.barrier();
+  }
+}
+
+// Master side.  Result in nd.best; returns min cost.
+template <typename PIX>
+TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, int node) {
+  const EncCfg& c = J.cfg;
+  WgShared* sh = ws->sh;
+  Node& nd = sh->stack[node];
+  const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
+  const int inter = J.frame_type != F_I;
+  mv_t mvp = mk_mv(0, 0);
+  if (inter) mvp = get_mv_pred(J.cells, J.cell_stride, nd.ypos, nd.xpos, c.width, c.height, nd.size, kMaxSb);
+  t.sync();
+  if (t.rank == 0) {
+    int n = 0;
+    auto push = [&](int kind, int a, int b) { MdItem it; it.kind = (int8_t)kind; it.a = (int8_t)a; it.b = (int8_t)b; it.pad = 0; sh->items[n++] = it; };
+    if (inter) {
+      for (int k = 0; k < nd.syn.num_skip; k++) push(MD_SKIP, k, 0);
+      for (int k = 0; k < nd.syn.num_merge; k++) push(MD_MERGE, k, 0);
+      for (int r = 0; r < J.num_ref; r++) push(MD_REF, r, 0);
+      nd.syn.mvp = mvp;
+    }
+    for (int m = 0; m < J.num_intra_modes; m++)
+      for (int tb = 0; tb <= max_tb - 1; tb++) push(MD_INTRA, m, tb);
+    sh->n_items = n; sh->next_item = 0;
+    sh->refs_done = 0; sh->n_ref_items = inter ? J.num_ref : 0;
+    sh->do_bipred = inter && J.num_ref > 1 && c.enable_bipred;
+    sh->node = node; sh->mvp = mvp;
+    sh->bestkey = ~0ull;
+    for (int w = 0; w < kWaves; w++) sh->wkey[w] = ~0ull;
+    sh->cmd = WG_CMD_MD;
+  }
+  t.sync();
+  wg.barrier();   // fork
+  md_worker(wg, t, J, ws);
+  t.sync();
+  wg.barrier();   // join
+  unsigned long long best = ~0ull;
+  int bw = 0;
+  for (int w = 0; w < wg.nwaves; w++) {
+    const unsigned long long k = sh->wkey[w];
+    if (k < best) { best = k; bw = w; }
+  }
+  if (best == ~0ull) return kCostInit;
+  if (t.rank == 0) nd.best = sh->wbest[bw];
+  t.sync();
+  return (unsigned)(best >> 32);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1079,14 +1340,16 @@ TK_DEVNI int final_encode(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
 // ---------------------------------------------------------------------------------
 // process_block (encode_block.c:2401-2566) as an explicit-stack traversal of one superblock.
 // ---------------------------------------------------------------------------------
+// Runs on the master wave (wg.wave == 0); the other waves of the workgroup sit in wg_helper_loop meanwhile.  The
+// shared tables (ws->sh->tabs) must have been filled (xform_tables_fill).
 template <typename PIX>
-TK_DEV void process_sb(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, int sb_y, int sb_x, BitSink& out) {
+TK_DEV void process_sb(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, int sb_y, int sb_x, BitSink& out) {
   TK_PROF_T0();
   const EncCfg& c = J.cfg;
   const int fw = c.width, fh = c.height;
   if (t.rank == 0)
-  { for (int r = 0; r < kMaxRefs; r++) { ws->mep->mvcand_num[r] = 0; ws->mep->mvcand_mask[r] = 0; } ws->mep->best_ref = -1; }
-  xform_tables_init(t, ws->xfp);
+  { MeLists* L = ws->mep->lists; for (int r = 0; r < kMaxRefs; r++) { L->mvcand_num[r] = 0; L->mvcand_mask[r] = 0; } L->best_ref = -1; }
+  t.sync();
   int sp = 0;
   unsigned ret = 0;  // value "returned" by the node that was just popped
   int have_ret = 0;
@@ -1208,7 +1471,9 @@ TK_DEV void process_sb(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, in
       unsigned cost = 1u << 28;
       if (nd.encode_this_size || nd.encode_rect) {
         if (!nd.md_done) {
-          cost = mode_decision(t, J, ws, nd);
+          const int rect = nd.bw != nd.size || nd.bh != nd.size;
+          if (c.encoder_speed == 0 && c.intra_rdo && !rect) cost = mode_decision_par(wg, t, J, ws, sp);
+          else cost = mode_decision(t, J, ws, nd);
           t.sync();
 #if TK_HOST
           if (getenv("THOR_DBG")) fprintf(stderr, "F %d y %d x %d s %d RDO mode %d cost %u small %u ref %d part %d tb %d mv %d %d\n", J.frame_num, nd.ypos, nd.xpos, nd.size, nd.best.mode, cost, nd.cost_small, nd.best.ref0, nd.best.pb_part, nd.best.tb_param, nd.best.mv0[0].x, nd.best.mv0[0].y);
@@ -1248,6 +1513,12 @@ TK_DEV void process_sb(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, in
       sp--;
     }
   }
+  // release the parked waves
+  t.sync();
+  if (t.rank == 0) ws->sh->cmd = WG_CMD_EXIT;
+  t.sync();
+  wg.barrier();
+  wg.barrier();  // all parked waves have seen WG_CMD_EXIT (see wg_helper_loop)
   TK_PROF_ADD(ws, PF_SB);
 }
 

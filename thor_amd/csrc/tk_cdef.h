@@ -283,7 +283,7 @@ template <typename PIX> TK_DEV void cdef_pass_select(const Team t, const CdefJob
       if (J.fb_compact[fb] >= 0) J.fb_compact[fb] = n++;
     R->sb_count = n;
   }
-  t.sync();
+  t.block_sync();
   const int sbc = R->sb_count;
   const unsigned long long* mse0 = J.mse;
   const unsigned long long* mse1 = J.mse + (size_t)nfb * kCdefMaxStr;
@@ -294,7 +294,7 @@ template <typename PIX> TK_DEV void cdef_pass_select(const Team t, const CdefJob
       R->strengths[0] = R->uv_strengths[0] = (pri << 2) + sec;
       R->nb_bits = 0;
     }
-    t.sync();
+    t.block_sync();
     return;
   }
   const int nb_strengths = 1 << J.cdef_bits;
@@ -306,12 +306,12 @@ template <typename PIX> TK_DEV void cdef_pass_select(const Team t, const CdefJob
     int nsel;
     if (call < nb_strengths) nsel = call;
     else {
-      t.sync();
+      t.block_sync();
       if (t.rank == 0)
         for (int j = 0; j < nb_strengths - 1; j++) { lev0[j] = lev0[j + 1]; lev1[j] = lev1[j + 1]; }
       nsel = nb_strengths - 1;
     }
-    t.sync();
+    t.block_sync();
     for (int jk = t.rank; jk < total * total; jk += t.size) {
       const int j = jk / total, k = jk - j * total;
       unsigned long long acc = 0;
@@ -329,7 +329,7 @@ template <typename PIX> TK_DEV void cdef_pass_select(const Team t, const CdefJob
       }
       J.tot[jk] = acc;
     }
-    t.sync();
+    t.block_sync();
     if (t.rank == 0) {
       unsigned long long bt = 1ull << 63;
       int b0 = 0, b1 = 0;
@@ -339,7 +339,7 @@ template <typename PIX> TK_DEV void cdef_pass_select(const Team t, const CdefJob
       lev0[nsel] = b0;
       lev1[nsel] = b1;
     }
-    t.sync();
+    t.block_sync();
   }
   if (t.rank == 0) {
     int nb_bits = J.cdef_bits;
@@ -386,7 +386,7 @@ template <typename PIX> TK_DEV void cdef_pass_select(const Team t, const CdefJob
     R->nb_bits = nb_bits;
     (void)sbc;
   }
-  t.sync();
+  t.block_sync();
 }
 
 // ---- pass 4: apply (cdef_frame, common_frame.c:826-1003); item = 8x8 luma-unit block --------

@@ -62,14 +62,81 @@ struct Team {
   // On the device it points into LDS (XformWs::izz) so the per-coefficient lookups of quantisation and bit
   // counting do not take a global-memory round trip each; unused (nullptr) on the host simulation.
   const int16_t* izz = nullptr;
+  // sync(): every lane of the TEAM has finished its earlier LDS / scratch accesses before any lane continues.  On the
+  // device a team is ONE wavefront, whose lanes run in lock step, so this is only a memory fence (outstanding LDS and
+  // vector-memory operations complete; no s_barrier): the workgroup holds several wavefronts that execute different
+  // code (Wg below) and a workgroup barrier here would dead-lock them.
+  // block_sync(): barrier over a whole thread block for the few kernels that use a block-wide team (CDEF selection).
 #if TK_LANES
   inline void sync() const { hostlanes::barrier(); }
+  inline void block_sync() const { hostlanes::barrier(); }
 #elif TK_HOST
   inline void sync() const {}
+  inline void block_sync() const {}
 #else
-  __device__ __forceinline__ void sync() const { __syncthreads(); }  // one wave per workgroup
+  __device__ __forceinline__ void sync() const {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  __device__ __forceinline__ void block_sync() const { __syncthreads(); }
 #endif
 };
+
+// ---------------------------------------------------------------------------------
+// Wg: the wavefronts of one workgroup that cooperate on one superblock.  Wave 0 (the "master") walks the quadtree;
+// the other waves are parked on the workgroup barrier and are woken for the parallel regions of a block decision
+// (tk_block.h:mode_decision_par).  The host simulation runs one OS thread per wave (-DTHOR_HOSTSIM_WAVES=N, 1-lane
+// teams) or a single wave (everything else).
+// ---------------------------------------------------------------------------------
+#ifndef TK_WAVES
+#if TK_HOST
+#ifdef THOR_HOSTSIM_WAVES
+#define TK_WAVES THOR_HOSTSIM_WAVES
+#else
+#define TK_WAVES 1
+#endif
+#else
+#define TK_WAVES 4
+#endif
+#endif
+enum { kWaves = TK_WAVES };
+#if TK_HOST && defined(THOR_HOSTSIM_WAVES)
+namespace hostwaves { void barrier(); }
+#endif
+struct Wg {
+  int wave, nwaves;
+#if !TK_HOST
+  __device__ __forceinline__ void barrier() const { __syncthreads(); }
+#elif defined(THOR_HOSTSIM_WAVES)
+  inline void barrier() const { hostwaves::barrier(); }
+#else
+  inline void barrier() const {}
+#endif
+};
+// Atomics on workgroup-shared state (always LDS on the device).  Call from ONE lane of a wave.
+TK_DEV int wg_fetch_add(int* p, int v) {
+#if TK_HOST
+  return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL);
+#else
+  return __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)p, v, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+TK_DEV void wg_min64(unsigned long long* p, unsigned long long v) {
+#if TK_HOST
+  unsigned long long cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (v < cur && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED)) {}
+#else
+  __hip_atomic_fetch_min((__attribute__((address_space(3))) unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+TK_DEV unsigned long long wg_load64(const unsigned long long* p) {
+#if TK_HOST
+  return __atomic_load_n(p, __ATOMIC_RELAXED);
+#else
+  return __hip_atomic_load((const __attribute__((address_space(3))) unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
 
 TK_DEV void team_add(int* p, int v) {
 #if TK_LANES
@@ -195,6 +262,22 @@ TK_DEV int tk_uniform(int v) {
 #elif TK_HOST
   return v;
 #else
+  return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+// value of lane 0 in every lane of the team
+TK_DEV int team_bcast0(const Team t, int v) {
+#if TK_LANES
+  const unsigned long long* g = hostlanes::exchange_begin((unsigned long long)(long long)v);
+  const int r = (int)(long long)g[0];
+  hostlanes::exchange_end();
+  (void)t;
+  return r;
+#elif TK_HOST
+  (void)t;
+  return v;
+#else
+  (void)t;
   return __builtin_amdgcn_readfirstlane(v);
 #endif
 }

@@ -14,14 +14,18 @@ namespace tk {
 
 enum { kMeWideChunk = 12, kMeMaxCand = kMeWideChunk * 5 };  // 5-offset SADs are evaluated 12 candidates at a time
 
-struct MeWs {
-  int sad[kMeMaxCand];
-  mv_t cmv[64];
-  // per-SB candidate lists (frame_info.mvcand[], enc/mainenc.h:146-148), reset per SB
+// per-SB candidate lists (frame_info.mvcand[], enc/mainenc.h:146-148), reset per SB.  One instance per workgroup:
+// the list of reference r is only ever touched by the wavefront that is searching reference r at that moment.
+struct MeLists {
   mv_t mvcand[kMaxRefs][64];
   int mvcand_num[kMaxRefs];
   unsigned long long mvcand_mask[kMaxRefs];
   int best_ref;  // frame_info.best_ref (enc/mainenc.h:143): per-SB state of the encoder_speed 2 reference shortcut
+};
+struct MeWs {  // per wavefront
+  int sad[kMeMaxCand];
+  mv_t cmv[64];
+  MeLists* lists;
   long long* prof;
 };
 
@@ -39,7 +43,8 @@ TK_DEV unsigned mv_cost(double lam, int dy, int dx) {
 }
 
 // add_mvcandidate (encode_block.c:69-82) - call from ONE lane.
-TK_DEV void add_mvcand(MeWs* w, int r, mv_t mv) {
+TK_DEV void add_mvcand(MeWs* w_, int r, mv_t mv) {
+  MeLists* w = w_->lists;
   mv_t imv = mk_mv((mv.x + 2) >> 2, (mv.y + 2) >> 2);
   unsigned long long m = 1ull << ((((int)imv.y << 3) ^ (int)imv.x) & 63);
   if (!(m & w->mvcand_mask[r])) {
@@ -421,11 +426,11 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
 #endif
   // --- candidate list (encode_block.c:564-581)
   {
-    const int n = TKU(w->mvcand_num[ref_idx]);
+    const int n = TKU(w->lists->mvcand_num[ref_idx]);
     if (n > 0) {
       const int wide = a.cb_size == 16;
       for (int c = t.rank; c < n; c += t.size) {
-        mv_t m = w->mvcand[ref_idx][c];
+        mv_t m = w->lists->mvcand[ref_idx][c];
         w->cmv[c] = clip_mv(mk_mv(m.x << 2, m.y << 2), a.ypos, a.xpos, a.fwidth, a.fheight, a.cb_size, a.cb_size, a.sign);
       }
       t.sync();
@@ -661,13 +666,13 @@ TK_DEVNI unsigned motion_estimate_bi(const Team t, MeWs* w, const PIX* org, cons
   // extra candidates (+ side effect on the shared list)
   t.sync();
   if (t.rank == 0) {
-    for (int idx = w->mvcand_num[r_idx0]; idx < 4; idx++) w->mvcand[r_idx0][idx] = mk_mv(0, 0);
-    w->mvcand[r_idx0][4] = mvp;
-    w->mvcand[r_idx0][5] = mk_mv(0, 0);
+    for (int idx = w->lists->mvcand_num[r_idx0]; idx < 4; idx++) w->lists->mvcand[r_idx0][idx] = mk_mv(0, 0);
+    w->lists->mvcand[r_idx0][4] = mvp;
+    w->lists->mvcand[r_idx0][5] = mk_mv(0, 0);
   }
   t.sync();
   {
-    auto cand = [&](int c) -> BI { return mk_bi(w->mvcand[r_idx0][c]); };
+    auto cand = [&](int c) -> BI { return mk_bi(w->lists->mvcand[r_idx0][c]); };
     unsigned long long k = eval_min(t, 6, size * size, cand, bi_item, bi_cost);
     if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = cand((int)(unsigned)k).mv; }
   }

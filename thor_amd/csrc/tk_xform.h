@@ -25,6 +25,13 @@
 
 namespace tk {
 
+// Constant tables of a workgroup (LDS on the GPU), shared by all of its wavefronts: the 32-point DCT basis (the
+// N-point basis is its rows 0, 32/N, 2*32/N, ... restricted to the first N columns - HEVC nesting property) and the
+// scan tables 4x4 | 8x8 | 16x16 (Team::izz points at `izz`).
+struct XformTabs {
+  int16_t dct32[1024];
+  int16_t izz[336];
+};
 struct XformWs {
   // `in`: (down-scaled) residual fed to the core transform, TRANSPOSED: in[col*size1 + row].  It is dead
   // after forward stage 1, so the inverse transform's stage-1 buffer (itmp, [coef col i][sample j],
@@ -34,19 +41,16 @@ struct XformWs {
   int16_t coef[16 * 16];  // forward coefficients, compact; reused for the de-quantised ones (rcoef)
   int flag;               // team-shared scalar result
   long long* prof;        // cycle counters (THOR_PROF builds)
-  // team-local copy of the 32-point DCT basis (LDS on the GPU); the N-point basis is its rows
-  // 0, 32/N, 2*32/N, ... restricted to the first N columns (HEVC nesting property).
-  int16_t dct32[1024];
-  int16_t izz[336];       // scan tables 4x4 | 8x8 | 16x16 (Team::izz points here)
+  const XformTabs* tabs;  // workgroup-shared constant tables
 };
 
 // entry (i, q) of the N-point basis, log2(32/N) = rs
-TK_DEV int dct_at(const XformWs* ws, int rs, int i, int q) { return ws->dct32[((i << rs) << 5) + q]; }
-// Fill the team-local table (call once per team before any transform).
-TK_DEV void xform_tables_init(const Team t, XformWs* ws) {
-  for (int k = t.rank; k < 1024; k += t.size) ws->dct32[k] = TK_TAB.dct32[k];
-  for (int k = t.rank; k < 336; k += t.size) ws->izz[k] = k < 16 ? TK_TAB.izz4[k] : (k < 80 ? TK_TAB.izz8[k - 16] : TK_TAB.izz16[k - 80]);
-  t.sync();
+TK_DEV int dct_at(const XformWs* ws, int rs, int i, int q) { return ws->tabs->dct32[((i << rs) << 5) + q]; }
+// Fill the shared tables: thread `rank` of `size` cooperating threads (the whole workgroup on the GPU; the caller
+// synchronises afterwards).  Once per workgroup - the tables never change.
+TK_DEV void xform_tables_fill(XformTabs* tb, int rank, int size) {
+  for (int k = rank; k < 1024; k += size) tb->dct32[k] = TK_TAB.dct32[k];
+  for (int k = rank; k < 336; k += size) tb->izz[k] = k < 16 ? TK_TAB.izz4[k] : (k < 80 ? TK_TAB.izz8[k - 16] : TK_TAB.izz16[k - 80]);
 }
 
 TK_DEV void fwd_core(const Team t, XformWs* ws, int size1, int qsize, int shift_1);
@@ -93,7 +97,7 @@ TK_DEV void fwd_core(const Team t, XformWs* ws, int size1, int qsize, int shift_
   const int shift_2 = ilog2(size1) + 5;
   const int add_2 = 1 << (shift_2 - 1);
   const lds_i16* const in = TK_LDS_PTR(ws->in);
-  const lds_i16* const dct = TK_LDS_PTR(ws->dct32);
+  const lds_i16* const dct = TK_LDS_PTR(ws->tabs->dct32);
   lds_i16* const tmp = TK_LDS_PTR(ws->tmp);
   lds_i16* const coef = TK_LDS_PTR(ws->coef);
   const Pow2 d1 = mk_pow2(size1), dq = mk_pow2(qsize);
@@ -212,7 +216,7 @@ TK_DEV void inv_transform_recon(const Team t, XformWs* ws, const PIX* pred, int 
   const int qsize = n < kMaxQuant ? n : kMaxQuant;
   const int rs = 5 - ilog2((unsigned)n);
   lds_i16* const itmp = TK_LDS_PTR(ws->in);  // aliases `in`
-  const lds_i16* const dct = TK_LDS_PTR(ws->dct32);
+  const lds_i16* const dct = TK_LDS_PTR(ws->tabs->dct32);
   const lds_i16* const rcoef = TK_LDS_PTR(ws->coef);
   const int shift_2 = 20 - bitdepth, add_2 = 1 << (shift_2 - 1);
   const int mstride = (1 << rs) << 5;  // basis row pitch in the 32-point table
