@@ -132,6 +132,17 @@ int thor_hip_interp_luma(const uint8_t* ref_plane, int plane_w, int plane_h, int
  * org/pred/rec: n*size*size samples; coefq: n*min(size,16)^2; cbp: n flags. */
 int thor_hip_code_tu_batch(const uint8_t* org, const uint8_t* pred, int size, int qp, int coeff_type, int fast, int n,
                            int16_t* coefq, uint8_t* rec, int* cbp);
+/* In-loop deblocking of one 8-bit planar 4:2:0 frame in place (deblock_frame_y + deblock_frame_uv,
+ * common/common_frame.c:47,354; chroma QP through chroma_qp[]).  cells: (height/4) x (width/4) records, the
+ * device-side compact form of deblock_data_t (common/types.h:178-187): mode = block_mode_t, size = CB size,
+ * tbpb = tb_split | pb_part << 1, cbp bit 0/1/2 = Y/U/V coefficients present. */
+typedef struct thor_hip_cell {
+  int16_t mv0x, mv0y, mv1x, mv1y;
+  uint8_t mode, size, tbpb, cbp;
+  int8_t ref0, ref1, dir;
+  uint8_t pad;
+} thor_hip_cell;
+int thor_hip_deblock_frame(uint8_t* yuv, int width, int height, int qp, const thor_hip_cell* cells);
 
 #ifdef __cplusplus
 }

@@ -243,6 +243,47 @@ template <typename PIX> void run_clpf_apply(const ClpfJob<PIX>* lj, const ClpfJo
     clpf_pass_apply(C, 0, 1);
   }
 }
+// temporal interpolation: the device phases as plain loops (1-lane teams, block rows in raster order)
+template <typename PIX> void run_interp(const idev::Job<PIX>* jobs, const idev::Job<PIX>*, int n) {
+  using namespace idev;
+  const Team t{0, 1};
+  for (int s = 0; s < n; s++) {
+    const Job<PIX>& J = jobs[s];
+    for (int l = 0; l < J.levels; l++) {
+      const Level<PIX>& L = J.lv[l];
+      const size_t cnt = (size_t)L.bw * L.bh + L.bw + 2;
+      memset(L.mv[0], 0, cnt * sizeof(imv)); memset(L.mv[1], 0, cnt * sizeof(imv));
+      memset(L.prog, 0, (size_t)(L.bh / kStep + 1) * sizeof(int));
+    }
+    for (int l = 1; l < J.levels; l++)
+      for (int r = 0; r < 2; r++) {
+        const PIX* in = l == 1 ? J.ref[r].y : J.dpic[r][l - 1];
+        const int in_s = l == 1 ? J.ref[r].sy : J.dstride[l - 1];
+        const int ow = J.width >> l, oh = J.height >> l;
+        for (int i = -32; i < oh + 32; i++)
+          for (int j = -32; j < ow + 32; j++) down2x2_item(in, in_s, J.dpic[r][l], J.dstride[l], ow, oh, i, j);
+      }
+    for (int lvl = J.levels - 1; lvl >= 0; --lvl) {
+      const Level<PIX>& L = J.lv[lvl];
+      for (int i = 0; i < L.bh; i += kStep)
+        for (int j = 0; j < L.bw; j += kStep) estimate_block(t, L, i, j);
+      for (int i = 0; i < L.bh; i++)
+        for (int j = 0; j < L.bw; j++) merge_block(t, L, i, j);
+      if (lvl > 0) {
+        const Level<PIX>& O = J.lv[lvl - 1];
+        for (int i = 0; i < O.bh; i++)
+          for (int j = 0; j < O.bw; j++) upscale_item(L.nmv[1], L.bw, O.gmv1, O.bw, i, j);
+      } else {
+        for (int yp = 0; yp < L.bh; yp++)
+          for (int xp = 0; xp < L.bw; xp++) mot_comp_unit(t, J, yp, xp);
+        const int rows = J.height + 2 * kPadY + 2 * (J.height / 2 + kPadY);
+        for (int it = 0; it < rows; it++) pad_item(J, it, 0, 1);
+      }
+    }
+  }
+}
+template void run_interp<uint8_t>(const idev::Job<uint8_t>*, const idev::Job<uint8_t>*, int);
+template void run_interp<uint16_t>(const idev::Job<uint16_t>*, const idev::Job<uint16_t>*, int);
 template void run_clpf_stats<uint8_t>(const ClpfJob<uint8_t>*, const ClpfJob<uint8_t>*, int);
 template void run_clpf_stats<uint16_t>(const ClpfJob<uint16_t>*, const ClpfJob<uint16_t>*, int);
 template void run_clpf_apply<uint8_t>(const ClpfJob<uint8_t>*, const ClpfJob<uint8_t>*, int);

@@ -76,3 +76,18 @@ def test_code_tu_random_edge_cases_vs_oracle_c():
                 cq = np.zeros((q, q), dtype=np.int16); rc = np.zeros((size, size), dtype=np.uint8)
                 c = O.orc_code_tu(vp(np.ascontiguousarray(org[i])), vp(np.ascontiguousarray(pred[i])), size, qp, ctype, 0, vp(cq), vp(rc))
                 assert c == cbp[i] and (cq == coefq[i]).all() and (rc == rec[i]).all(), (size, qp, i)
+
+
+def test_deblock_frame_matches_reference_kat():
+    """thor_hip_deblock_frame (the four k_deblock passes) against deblock_frame_y_lbd / deblock_frame_uv_lbd of the reference
+    (common/common_frame.c:47,354) on recorded random frames / block data (tests/golden/gen_kat3.py)."""
+    import thor_amd
+    K3 = np.load(os.path.join(GOLD, 'kat3.npz'))
+    k = 0
+    while f'db_par{k}' in K3:
+        w, h, qp = [int(v) for v in K3[f'db_par{k}']]
+        got = thor_amd.deblock_frame(K3[f'db_in{k}'], w, h, qp, K3[f'db_cells{k}'])
+        assert (got == K3[f'db_out{k}']).all(), (k, int((got != K3[f'db_out{k}']).sum()))
+        assert (got != K3[f'db_in{k}']).sum() > 100  # the filter did something
+        k += 1
+    assert k == 5

@@ -5,8 +5,8 @@ declared in include/thor_hip.h (sequence API + kernel-level entry points).  Ther
 fallback: importing works anywhere, but every call that computes requires the HIP library and a
 gfx950 device and fails loudly otherwise.
 """
-from .binding import (ThorParams, Encoder, lib, lib_path, load_config, sad_batch, interp_luma, code_tu_batch,
+from .binding import (ThorParams, Encoder, lib, lib_path, load_config, sad_batch, interp_luma, code_tu_batch, deblock_frame,
                       build_native, REPO_ROOT)
 
-__all__ = ['ThorParams', 'Encoder', 'lib', 'lib_path', 'load_config', 'sad_batch', 'interp_luma', 'code_tu_batch',
+__all__ = ['ThorParams', 'Encoder', 'lib', 'lib_path', 'load_config', 'sad_batch', 'interp_luma', 'code_tu_batch', 'deblock_frame',
            'build_native', 'REPO_ROOT']

@@ -71,6 +71,7 @@ def lib():
         L.thor_hip_get_recon.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.thor_hip_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]
         L.thor_hip_kernel_time_reset.argtypes = [C.c_void_p]
+        L.thor_hip_deblock_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.thor_hip_params_from_config.argtypes = [C.POINTER(ThorParams), C.c_char_p]
         L.thor_hip_params_set.argtypes = [C.POINTER(ThorParams), C.c_char_p, C.c_char_p]
         _LIB = L
@@ -218,3 +219,14 @@ def code_tu_batch(org, pred, qp, coeff_type, fast):
     if rc:
         raise RuntimeError(f'thor_hip_code_tu_batch rc={rc}')
     return coefq, rec, cbp
+
+
+def deblock_frame(yuv, width, height, qp, cells):
+    """In-loop deblocking of one 8-bit planar frame (thor_hip_deblock_frame); cells: (h/4, w/4, 16) uint8 records."""
+    yuv = np.ascontiguousarray(yuv, dtype=np.uint8).copy()
+    cells = np.ascontiguousarray(cells, dtype=np.uint8)
+    assert yuv.size == width * height * 3 // 2 and cells.size == (width // 4) * (height // 4) * 16
+    rc = lib().thor_hip_deblock_frame(_vp(yuv), width, height, qp, _vp(cells))
+    if rc:
+        raise RuntimeError(f'thor_hip_deblock_frame rc={rc}')
+    return yuv

@@ -236,6 +236,79 @@ template <typename PIX> __global__ __launch_bounds__(1024) void k_cdef_select(co
   cdef_pass_select(t, cj[blockIdx.x]);
 }
 
+// ---- temporally interpolated reference (tk_interp_dev.h) -----------------------------------------------------------
+template <typename PIX> __global__ void k_interp_clear(const idev::Job<PIX>* jobs) {
+  const idev::Job<PIX>& J = jobs[blockIdx.y];
+  const int gid = (int)(blockIdx.x * blockDim.x + threadIdx.x), gsz = (int)(gridDim.x * blockDim.x);
+  for (int l = 0; l < J.levels; l++) {
+    const idev::Level<PIX>& L = J.lv[l];
+    const int cnt = L.bw * L.bh + L.bw + 2;
+    uint32_t* a = (uint32_t*)L.mv[0];
+    uint32_t* b = (uint32_t*)L.mv[1];
+    for (int k = gid; k < cnt; k += gsz) { a[k] = 0; b[k] = 0; }
+    for (int k = gid; k < L.bh / idev::kStep + 1; k += gsz) L.prog[k] = 0;
+  }
+}
+template <typename PIX> __global__ void k_interp_down(const idev::Job<PIX>* jobs, int l) {
+  const idev::Job<PIX>& J = jobs[blockIdx.y];
+  if (l >= J.levels) return;
+  const int ow = J.width >> l, oh = J.height >> l, pw = ow + 64;
+  const int total = (oh + 64) * pw;
+  for (int k = (int)(blockIdx.x * blockDim.x + threadIdx.x); k < total; k += (int)(gridDim.x * blockDim.x)) {
+    const int i = k / pw - 32, j = k % pw - 32;
+    for (int r = 0; r < 2; r++)
+      idev::down2x2_item(l == 1 ? J.ref[r].y : J.dpic[r][l - 1], l == 1 ? J.ref[r].sy : J.dstride[l - 1], J.dpic[r][l], J.dstride[l], ow, oh, i, j);
+  }
+}
+// One wavefront per 16x16-block row.  Rows are handed out by a ticket, so the row above a wave's row was always taken by
+// a wave that started earlier: the wave waits until that row is two blocks ahead (or finished) and never dead-locks.
+template <typename PIX> __global__ __launch_bounds__(64) void k_interp_estimate(const idev::Job<PIX>* jobs, int lvl) {
+  const idev::Job<PIX>& J = jobs[blockIdx.y];
+  if (lvl >= J.levels) return;
+  const idev::Level<PIX>& L = J.lv[lvl];
+  const Team t{(int)threadIdx.x, 64};
+  int row = 0;
+  if (threadIdx.x == 0) row = (int)atomicAdd((unsigned*)L.ticket, 1u);
+  row = __builtin_amdgcn_readfirstlane(row);
+  const int nrows = L.bh / idev::kStep, ncols = L.bw / idev::kStep;
+  if (row >= nrows) return;
+  for (int c = 0; c < ncols; c++) {
+    if (row > 0) {
+      const int need = c + 2 < ncols ? c + 2 : ncols;
+      while (__hip_atomic_load(&L.prog[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    idev::estimate_block(t, L, row * idev::kStep, c * idev::kStep);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (threadIdx.x == 0) __hip_atomic_store(&L.prog[row], c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+template <typename PIX> __global__ __launch_bounds__(64) void k_interp_merge(const idev::Job<PIX>* jobs, int lvl) {
+  const idev::Job<PIX>& J = jobs[blockIdx.y];
+  if (lvl >= J.levels) return;
+  const idev::Level<PIX>& L = J.lv[lvl];
+  const Team t{(int)threadIdx.x, 64};
+  for (int k = blockIdx.x; k < L.bw * L.bh; k += gridDim.x) idev::merge_block(t, L, k / L.bw, k % L.bw);
+}
+template <typename PIX> __global__ void k_interp_upscale(const idev::Job<PIX>* jobs, int lvl) {  // level lvl -> guide of lvl-1
+  const idev::Job<PIX>& J = jobs[blockIdx.y];
+  if (lvl >= J.levels || lvl < 1) return;
+  const idev::Level<PIX>& L = J.lv[lvl];
+  const idev::Level<PIX>& O = J.lv[lvl - 1];
+  for (int k = (int)(blockIdx.x * blockDim.x + threadIdx.x); k < O.bw * O.bh; k += (int)(gridDim.x * blockDim.x))
+    idev::upscale_item(L.nmv[1], L.bw, O.gmv1, O.bw, k / O.bw, k % O.bw);
+}
+template <typename PIX> __global__ __launch_bounds__(64) void k_interp_mc(const idev::Job<PIX>* jobs) {
+  const idev::Job<PIX>& J = jobs[blockIdx.y];
+  const idev::Level<PIX>& L = J.lv[0];
+  const Team t{(int)threadIdx.x, 64};
+  for (int k = blockIdx.x; k < L.bw * L.bh; k += gridDim.x) idev::mot_comp_unit(t, J, k / L.bw, k % L.bw);
+}
+template <typename PIX> __global__ void k_interp_pad(const idev::Job<PIX>* jobs) {
+  const idev::Job<PIX>& J = jobs[blockIdx.y];
+  idev::pad_item(J, (int)blockIdx.x, (int)threadIdx.x, (int)blockDim.x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // backend
 // ---------------------------------------------------------------------------------------------
@@ -449,6 +522,34 @@ template <typename PIX> void run_clpf_apply(const ClpfJob<PIX>* lj, const ClpfJo
   g_filt_events.push_back(ev);
   HIPCHECK(hipGetLastError());
 }
+template <typename PIX> void run_interp(const idev::Job<PIX>* jobs, const idev::Job<PIX>* hjobs, int n) {
+  const idev::Job<PIX>& H = hjobs[0];  // all streams share the geometry
+  auto ev = ev_begin();
+  hipLaunchKernelGGL(k_interp_clear<PIX>, dim3(64, n), dim3(256), 0, g_stream, jobs);
+  for (int l = 1; l < H.levels; l++) {
+    const int total = ((H.height >> l) + 64) * ((H.width >> l) + 64);
+    hipLaunchKernelGGL(k_interp_down<PIX>, dim3((total + 255) / 256, n), dim3(256), 0, g_stream, jobs, l);
+  }
+  for (int lvl = H.levels - 1; lvl >= 0; --lvl) {
+    const idev::Level<PIX>& L = H.lv[lvl];
+    hipLaunchKernelGGL(k_interp_estimate<PIX>, dim3(L.bh / idev::kStep, n), dim3(64), 0, g_stream, jobs, lvl);
+    const int units = L.bw * L.bh;
+    hipLaunchKernelGGL(k_interp_merge<PIX>, dim3(units < 16384 ? units : 16384, n), dim3(64), 0, g_stream, jobs, lvl);
+    if (lvl > 0) {
+      const int fine = H.lv[lvl - 1].bw * H.lv[lvl - 1].bh;
+      hipLaunchKernelGGL(k_interp_upscale<PIX>, dim3((fine + 255) / 256, n), dim3(256), 0, g_stream, jobs, lvl);
+    } else {
+      hipLaunchKernelGGL(k_interp_mc<PIX>, dim3(units < 16384 ? units : 16384, n), dim3(64), 0, g_stream, jobs);
+      const int rows = H.height + 2 * kPadY + 2 * (H.height / 2 + kPadY);
+      hipLaunchKernelGGL(k_interp_pad<PIX>, dim3(rows, n), dim3(256), 0, g_stream, jobs);
+    }
+  }
+  HIPCHECK(hipEventRecord(ev.second, g_stream));
+  g_filt_events.push_back(ev);
+  HIPCHECK(hipGetLastError());
+}
+template void run_interp<uint8_t>(const idev::Job<uint8_t>*, const idev::Job<uint8_t>*, int);
+template void run_interp<uint16_t>(const idev::Job<uint16_t>*, const idev::Job<uint16_t>*, int);
 void run_gather(const GatherItem* d_items, int n, uint32_t* dst) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_gather_bits, dim3(n), dim3(64), 0, g_stream, d_items, n, dst);
@@ -975,5 +1076,33 @@ extern "C" int thor_hip_code_tu_batch(const uint8_t* org, const uint8_t* pred, i
   backend::d2h(rec, d_rec, px);
   backend::d2h(cbp, d_cbp, (size_t)n * 4);
   backend::dev_free(d_org); backend::dev_free(d_pred); backend::dev_free(d_rec); backend::dev_free(d_cq); backend::dev_free(d_cbp);
+  return 0;
+}
+
+extern "C" int thor_hip_deblock_frame(uint8_t* yuv, int width, int height, int qp, const thor_hip_cell* cells) {
+  static_assert(sizeof(thor_hip_cell) == sizeof(DbCell), "thor_hip_cell must mirror tk::DbCell");
+  if (!yuv || !cells || width % 8 || height % 8 || width < 16 || height < 16 || qp < 0 || qp > 51) return 1;
+  if (!ensure_init(g_inited ? g_device : 0)) return 3;
+  DevFrame<uint8_t> f;
+  f.alloc(width, height, 0);
+  const size_t ncell = (size_t)(width / 4) * (height / 4);
+  DbCell* d_cells = to_dev((const DbCell*)cells, ncell);
+  HIPCHECK(hipMemcpy2D(f.p.y, f.p.sy, yuv, width, width, height, hipMemcpyHostToDevice));
+  const uint8_t* hu = yuv + (size_t)width * height;
+  const uint8_t* hv = hu + (size_t)(width / 2) * (height / 2);
+  HIPCHECK(hipMemcpy2D(f.p.u, f.p.sc, hu, width / 2, width / 2, height / 2, hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy2D(f.p.v, f.p.sc, hv, width / 2, width / 2, height / 2, hipMemcpyHostToDevice));
+  FrameJob<uint8_t> J;
+  memset(&J, 0, sizeof(J));
+  J.cfg.width = width; J.cfg.height = height; J.cfg.bitdepth = 8;
+  J.qp = qp; J.rec = f.p; J.cells = d_cells; J.cell_stride = width / 4;
+  FrameJob<uint8_t>* d_job = to_dev(&J, 1);
+  backend::run_deblock<uint8_t>(d_job, &J, 1);
+  backend::dev_sync();
+  HIPCHECK(hipMemcpy2D(yuv, width, f.p.y, f.p.sy, width, height, hipMemcpyDeviceToHost));
+  HIPCHECK(hipMemcpy2D((uint8_t*)hu, width / 2, f.p.u, f.p.sc, width / 2, height / 2, hipMemcpyDeviceToHost));
+  HIPCHECK(hipMemcpy2D((uint8_t*)hv, width / 2, f.p.v, f.p.sc, width / 2, height / 2, hipMemcpyDeviceToHost));
+  backend::dev_free(d_job); backend::dev_free(d_cells);
+  f.release();
   return 0;
 }

@@ -16,7 +16,7 @@
 #include "tk_common.h"
 #include "tk_tables.h"
 #include "tk_cdef.h"
-#include "tk_interp.h"
+#include "tk_interp_dev.h"
 #include "tk_clpf.h"
 
 namespace tk {
@@ -41,7 +41,10 @@ template <typename PIX> void run_cdef(const CdefJob<PIX>* cjobs, const CdefJob<P
 // bit-level concatenation of per-SB bit strings: item i copies nbits[i] bits from src[i] to bit offset dst_bit[i] of dst
 struct GatherItem { const uint32_t* src; int nbits; long long dst_bit; };
 void run_gather(const GatherItem* d_items, int n, uint32_t* dst);
-void release_superblocks(const void* jobs);  // frees the scheduler state run_superblocks keeps for this job array
+void release_superblocks(const void* jobs);
+// temporally interpolated reference frames of n streams (all phases: pyramid, block search per level, merge, upscale,
+// motion compensation, padding); jobs/hjobs: device/host arrays of n idev::Job
+template <typename PIX> void run_interp(const idev::Job<PIX>* jobs, const idev::Job<PIX>* hjobs, int n);  // frees the scheduler state run_superblocks keeps for this job array
 }  // namespace backend
 
 // ---- parameters -------------------------------------------------------------------------
@@ -328,6 +331,12 @@ template <typename PIX> struct Stream {
   int8_t* cdef_dir = nullptr; int* cdef_var = nullptr; int* cdef_fbc = nullptr; unsigned long long* cdef_mse = nullptr;
   int* cdef_sel = nullptr; int* cdef_fbsel = nullptr; CdefResult* cdef_res = nullptr; unsigned long long* cdef_tot = nullptr;
   uint32_t* clpf_stats = nullptr; uint8_t* clpf_fb_on = nullptr;   // CLPF: per-8x8 statistics, per-filter-block switches
+  // temporal interpolation (interp_ref = 1): pyramid planes and per-level vector fields, device resident
+  int ip_levels = 0;
+  PIX* ip_pic[2][idev::kMaxLevels] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};  // allocation bases
+  int ip_stride[idev::kMaxLevels] = {0, 0, 0, 0};
+  idev::imv* ip_mv[idev::kMaxLevels][5] = {};   // mv0, mv1, nmv0, nmv1, guide per level
+  int* ip_prog[idev::kMaxLevels] = {nullptr, nullptr, nullptr, nullptr};   // progress counters + ticket (last entry)
   int num_encoded = 0;
   GopScheduler gop;          // coding-order schedule (initialised by begin_sequence or lazily as open-ended low delay)
   FrameParams cur;           // frame returned by the last schedule()
@@ -357,6 +366,8 @@ template <typename PIX> class Engine {
   bool external_interp = false;  // drop-in mode: the caller uploads st[s].interp itself
   bool raw_frames = false;  // drop-in mode: no sequence header / framing; caller consumes st[s].bits
   long long* d_prof = nullptr;  // 32 cycle counters summed over all superblocks (THOR_PROF builds)
+  idev::Job<PIX>* d_ijobs = nullptr;
+  std::vector<idev::Job<PIX>> h_ijobs;
 
   void open(const SeqParams& p, int num_streams) {
     sp = p; S = num_streams;
@@ -385,6 +396,24 @@ template <typename PIX> class Engine {
       s.ring.resize(ring_size);
       for (auto& r : s.ring) r.alloc(p.width, p.height, kPadY);
       if (p.interp_ref) s.interp.alloc(p.width, p.height, kPadY);
+      if (p.interp_ref && !external_interp) {
+        const int mn = p.width < p.height ? p.width : p.height;
+        int lv = (int)(log10((double)mn) / log10(2.0) - 4.0);  // temporal_interp.c:913, evaluated in double as written
+        if (lv > idev::kMaxLevels) lv = idev::kMaxLevels;
+        if (lv < 1) { fprintf(stderr, "Run-time error...\nthor_hip: frame too small for interp_ref\n...now exiting to system...\n"); abort(); }
+        s.ip_levels = lv;
+        for (int l = 0; l < lv; l++) {
+          const int lw = p.width >> l, lh = p.height >> l;
+          const int bw = idev::kStep * ((lw + idev::kBbs - 1) / idev::kBbs), bh = idev::kStep * ((lh + idev::kBbs - 1) / idev::kBbs);
+          const size_t n = (size_t)bw * bh + bw + 2;
+          for (int k = 0; k < 5; k++) s.ip_mv[l][k] = (idev::imv*)backend::dev_alloc(n * sizeof(idev::imv));
+          s.ip_prog[l] = (int*)backend::dev_alloc((size_t)(bh / idev::kStep + 1) * sizeof(int));
+          if (l > 0) {
+            s.ip_stride[l] = (lw + 64 + 15) & ~15;
+            for (int k = 0; k < 2; k++) s.ip_pic[k][l] = (PIX*)backend::dev_alloc(((size_t)(lh + 64) * s.ip_stride[l] + 64) * sizeof(PIX));
+          }
+        }
+      }
       s.cells = (DbCell*)backend::dev_alloc((size_t)cw * chh * sizeof(DbCell));
       backend::dev_memset(s.cells, 0, (size_t)cw * chh * sizeof(DbCell));
       s.sb_bits = (uint32_t*)backend::dev_alloc((size_t)nsb * kSbWords * 4);
@@ -411,6 +440,7 @@ template <typename PIX> class Engine {
     d_cjobs = (CdefJob<PIX>*)backend::dev_alloc(sizeof(CdefJob<PIX>) * S);
     h_cjobs.resize(S);
     d_prof = (long long*)backend::dev_alloc(32 * sizeof(long long));
+    if (p.interp_ref && !external_interp) { d_ijobs = (idev::Job<PIX>*)backend::dev_alloc(sizeof(idev::Job<PIX>) * S); h_ijobs.resize(S); }
   }
   size_t clpf_stat_words() const { return 4 * ((size_t)(sp.width / 8) * (sp.height / 8) + 2 * (size_t)(sp.width / 16) * (sp.height / 16)); }
   void close() {
@@ -421,6 +451,10 @@ template <typename PIX> class Engine {
       backend::dev_free(s.cdef_sel); backend::dev_free(s.cdef_fbsel); backend::dev_free(s.cdef_res); backend::dev_free(s.cdef_tot);
       for (auto& r : s.ring) r.release();
       backend::dev_free(s.cells); backend::dev_free(s.sb_bits); backend::dev_free(s.scratch);
+      for (int l = 0; l < idev::kMaxLevels; l++) {
+        for (int k = 0; k < 5; k++) backend::dev_free(s.ip_mv[l][k]);
+        backend::dev_free(s.ip_prog[l]); backend::dev_free(s.ip_pic[0][l]); backend::dev_free(s.ip_pic[1][l]);
+      }
     }
     st.clear();
     backend::dev_free(d_nbits_all); backend::dev_free(d_status_all); backend::dev_free(d_items); backend::dev_free(d_payload);
@@ -430,6 +464,7 @@ template <typename PIX> class Engine {
     backend::dev_free(d_cjobs); d_cjobs = nullptr;
     backend::dev_free(d_ljobs); d_ljobs = nullptr;
     backend::dev_free(d_prof); d_prof = nullptr;
+    backend::dev_free(d_ijobs); d_ijobs = nullptr;
   }
 
   // planar 4:2:0 frame in host memory -> device `orig` of stream s
@@ -486,47 +521,48 @@ template <typename PIX> class Engine {
     return q.gop.next(q.cur, q.cur_abs, [&](int idx) { return q.ring[idx].frame_num; });
   }
 
-  // Temporally interpolated reference (enc/mainenc.c:350-355): normative CPU-side step between frames in the
-  // reference too; the two padded window frames are read back, interpolated on the host (tk_interp.h), padded
-  // and uploaded as the stream's `interp` frame.
-  // All streams whose frame uses the interpolated reference: device copies stay on the calling thread, the
-  // interpolation itself (29 ms per 1080p frame on one core) runs on up to 64 host threads, one stream each.
+  // Temporally interpolated reference (enc/mainenc.c:350-355, common/temporal_interp.c:909): built on the device from
+  // the two window frames of every stream whose frame uses it (tk_interp_dev.h) - no frame leaves HBM.
   void make_interp_frames(const std::vector<FrameParams>& fp) {
-    std::vector<int> todo;
-    for (int s = 0; s < S; s++)
-      if (fp[s].interp_ref) todo.push_back(s);
-    if (todo.empty()) return;
-    const int w = sp.width, h = sp.height;
-    unsigned hc = std::thread::hardware_concurrency();
-    const size_t nthr = hc < 1 ? 1 : (hc > 64 ? 64 : hc);
-    struct Work { interp::HFrame<PIX> a, b, o; };
-    for (size_t base = 0; base < todo.size(); base += nthr) {
-      const size_t n = todo.size() - base < nthr ? todo.size() - base : nthr;
-      std::vector<Work> wk(n);
-      for (size_t i = 0; i < n; i++) {
-        Stream<PIX>& q = st[todo[base + i]];
-        const FrameParams& f = fp[todo[base + i]];
-        Work& W = wk[i];
-        W.a.alloc(w, h, kPadY); W.b.alloc(w, h, kPadY); W.o.alloc(w, h, kPadY);
-        const DevFrame<PIX>& ra = q.ring[f.interp_src[0]];
-        const DevFrame<PIX>& rb = q.ring[f.interp_src[1]];
-        backend::d2h(W.a.by.data(), ra.base_y, W.a.by.size() * sizeof(PIX)); backend::d2h(W.a.bc.data(), ra.base_c, W.a.bc.size() * sizeof(PIX));
-        backend::d2h(W.b.by.data(), rb.base_y, W.b.by.size() * sizeof(PIX)); backend::d2h(W.b.bc.data(), rb.base_c, W.b.bc.size() * sizeof(PIX));
+    int n = 0;
+    for (int s = 0; s < S; s++) {
+      if (!fp[s].interp_ref) continue;
+      Stream<PIX>& q = st[s];
+      const FrameParams& f = fp[s];
+      idev::Job<PIX>& J = h_ijobs[n++];
+      memset(&J, 0, sizeof(J));
+      const int ratio = 2, k = 1;  // interpolate_frames(..., 2, 1): the frame half way between the two anchors (mainenc.c:353)
+      J.levels = q.ip_levels;
+      J.width = sp.width; J.height = sp.height;
+      J.ref[0] = q.ring[f.interp_src[0]].p; J.ref[1] = q.ring[f.interp_src[1]].p; J.out = q.interp.p;
+      const int reversed = k > ratio / 2;
+      const int wt0 = reversed ? k : ratio - k, wt1 = ratio - wt0;
+      for (int l = 0; l < J.levels; l++) {
+        idev::Level<PIX>& L = J.lv[l];
+        const int lw = sp.width >> l, lh = sp.height >> l;
+        const PIX* in[2];
+        int str[2];
+        if (l == 0) { in[0] = J.ref[0].y; in[1] = J.ref[1].y; str[0] = J.ref[0].sy; str[1] = J.ref[1].sy; L.pad = kPadY; }
+        else {
+          for (int r = 0; r < 2; r++) { J.dpic[r][l] = q.ip_pic[r][l] + (size_t)32 * q.ip_stride[l] + 32; in[r] = J.dpic[r][l]; str[r] = q.ip_stride[l]; }
+          J.dstride[l] = q.ip_stride[l];
+          L.pad = 32;
+        }
+        L.pic[0] = reversed ? in[1] : in[0]; L.pic[1] = reversed ? in[0] : in[1];
+        L.s[0] = reversed ? str[1] : str[0]; L.s[1] = reversed ? str[0] : str[1];
+        L.w = lw; L.h = lh;
+        L.mv[0] = q.ip_mv[l][0]; L.mv[1] = q.ip_mv[l][1]; L.nmv[0] = q.ip_mv[l][2]; L.nmv[1] = q.ip_mv[l][3]; L.gmv1 = q.ip_mv[l][4];
+        L.guide_mv1 = l == J.levels - 1 ? nullptr : L.gmv1;
+        L.guide_reversed = reversed; L.guide_wt0 = wt0;
+        L.wt[0] = wt0; L.wt[1] = wt1; L.reversed = reversed;
+        L.bw = idev::kStep * ((lw + idev::kBbs - 1) / idev::kBbs); L.bh = idev::kStep * ((lh + idev::kBbs - 1) / idev::kBbs);
+        L.prog = q.ip_prog[l]; L.ticket = q.ip_prog[l] + L.bh / idev::kStep;
       }
-      auto job = [&](size_t i) { interp::interpolate_frames(wk[i].o, wk[i].a, wk[i].b, 2, 1); wk[i].o.pad_all(); };
-      if (n == 1) job(0);
-      else {
-        std::vector<std::thread> th;
-        for (size_t i = 0; i < n; i++) th.emplace_back(job, i);
-        for (auto& t : th) t.join();
-      }
-      for (size_t i = 0; i < n; i++) {
-        Stream<PIX>& q = st[todo[base + i]];
-        backend::h2d(q.interp.base_y, wk[i].o.by.data(), wk[i].o.by.size() * sizeof(PIX));
-        backend::h2d(q.interp.base_c, wk[i].o.bc.data(), wk[i].o.bc.size() * sizeof(PIX));
-        q.interp.frame_num = fp[todo[base + i]].frame_num;
-      }
+      q.interp.frame_num = f.frame_num;
     }
+    if (!n) return;
+    backend::h2d(d_ijobs, h_ijobs.data(), sizeof(idev::Job<PIX>) * n);
+    backend::run_interp<PIX>(d_ijobs, h_ijobs.data(), n);
   }
 
   // Encode one frame per stream (origs already uploaded). Appends to st[s].out.
