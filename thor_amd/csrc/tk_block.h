@@ -230,7 +230,7 @@ TK_DEV void ssd_acc(const Team t, unsigned long long* acc, const PIX* a, int as,
     for (int k = t.rank; k < w * h; k += t.size) {
       int i, j;
       split2(pw, k, i, j);
-      int d = (int)a[i * as + j] - (int)b[i * bs + j];
+      int d = (int)gptr(a)[i * as + j] - (int)gptr(b)[i * bs + j];
       local += (unsigned long long)(d * d);
     }
   } else {
@@ -709,7 +709,7 @@ TK_DEVNI void search_bipred(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* w
       for (int k = t.rank; k < size * size; k += t.size) {
         int i, j;
         split2(mk_pow2(size), k, i, j);
-        ws->org8[k] = (PIX)sat_pix(2 * (int)oy[i * J.orig.sy + j] - (int)ws->pred_y[k], c.bitdepth);
+        gptr(ws->org8)[k] = (PIX)sat_pix(2 * (int)gptr(oy)[i * J.orig.sy + j] - (int)gptr(ws->pred_y)[k], c.bitdepth);
       }
       t.sync();
       int ref_start, ref_end;
@@ -760,7 +760,7 @@ TK_DEVNI unsigned intra_sad_search(const Team t, const FrameJob<PIX>& J, TeamWs<
     for (int k = t.rank; k < size * size; k += t.size) {
       int i, j;
       split2(mk_pow2(size), k, i, j);
-      local += iabs((int)oy[i * J.orig.sy + j] - (int)ws->pred_y[k]);
+      local += iabs((int)gptr(oy)[i * J.orig.sy + j] - (int)gptr(ws->pred_y)[k]);
     }
     const unsigned sad = (unsigned)team_sum(t, local) >> (bd - 8);
     t.sync();
@@ -1094,6 +1094,7 @@ TK_DEVNI void md_worker(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamW
     if (i >= n_items) break;
     const MdItem it = sh->items[i];
     const int kind = team_bcast0(t, it.kind), ia = team_bcast0(t, it.a), ib = team_bcast0(t, it.b);
+    TK_PROF_MARK(pit_);
     if (kind == MD_SKIP) {
       BlkParam p = blank_param();
       set_cand(p, M.nd->skip[ia], ia, M_SKIP);
@@ -1115,8 +1116,15 @@ TK_DEVNI void md_worker(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamW
       int done = 0;
       if (t.rank == 0) done = wg_fetch_add(&sh->refs_done, 1) + 1;
       done = team_bcast0(t, done);
-      if (done == sh->n_ref_items && sh->do_bipred) md_item_bipred(t, J, ws, M);
+      TK_PROF_ACC(ws, 27, pit_);
+      if (done == sh->n_ref_items && sh->do_bipred) {
+        TK_PROF_MARK(pbi_);
+        md_item_bipred(t, J, ws, M);
+        TK_PROF_ACC(ws, 28, pbi_);
+      }
     }
+    if (kind == MD_SKIP || kind == MD_MERGE) { TK_PROF_ACC(ws, 29, pit_); }
+    else if (kind == MD_INTRA) { TK_PROF_ACC(ws, 26, pit_); }
   }
 }
 
@@ -1164,10 +1172,12 @@ TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, const FrameJob<PI
     sh->cmd = WG_CMD_MD;
   }
   t.sync();
+  TK_PROF_MARK(ppar_);
   wg.barrier();   // fork
   md_worker(wg, t, J, ws);
   t.sync();
   wg.barrier();   // join
+  TK_PROF_ACC(ws, 5, ppar_);  // wall cycles of the parallel region (x kWaves = wave-cycles available to the items)
   unsigned long long best = ~0ull;
   int bw = 0;
   for (int w = 0; w < wg.nwaves; w++) {

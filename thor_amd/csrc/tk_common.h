@@ -13,6 +13,12 @@
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
+// Wave-uniform values (arguments of the hot callees, running minima, syntax parameters) are moved to scalar registers
+// with readfirstlane: +8 % on the MI355X (profiles/r02_ab_variants.md), bit-exact on the GPU parity suite.  The host
+// simulation checks the uniformity assumption (tk_uniform aborts when lanes disagree).  -DTHOR_NO_UNIFORM turns it off.
+#if !defined(THOR_NO_UNIFORM) && !defined(THOR_EXP_UNIFORM)
+#define THOR_EXP_UNIFORM 1
+#endif
 
 #if defined(THOR_HOSTSIM)
 #include <string.h>
@@ -281,8 +287,8 @@ TK_DEV int team_bcast0(const Team t, int v) {
   return __builtin_amdgcn_readfirstlane(v);
 #endif
 }
-// EXPERIMENTAL (-DTHOR_EXP_UNIFORM, off by default, not yet measured on the GPU): scalarise more wave-uniform values
-// of the motion search.  TKU*/tk_uniform* are identities when the flag is off, so the default build is unchanged.
+// THOR_EXP_UNIFORM (default on, see the top of this file): scalarise more wave-uniform values.  TKU*/tk_uniform* are
+// identities when it is off.
 TK_DEV unsigned long long tk_uniform64(unsigned long long v) {
 #if TK_LANES
   const unsigned long long* g = hostlanes::exchange_begin(v);
@@ -366,6 +372,21 @@ TK_DEV double mul_add_nofma(double a, double b, double c) {
 #endif
 typedef TK_LDS int16_t lds_i16;
 #define TK_LDS_PTR(p) ((lds_i16*)(p))
+// Same for data that always lives in global memory (frame planes, the per-wave BigWs sample blocks): pointers that come
+// out of FrameJob / TeamWs are generic to the compiler, which then emits flat_load/flat_store (they tick the LDS counter
+// as well as the vector-memory counter, so every LDS wait also waits for them); re-typed as address-space-1 pointers the
+// hot loops use global_load/global_store.
+#if TK_HOST
+#define TK_GLOBAL
+#else
+#define TK_GLOBAL __attribute__((address_space(1)))
+#endif
+template <class T> TK_DEV const TK_GLOBAL T* gptr(const T* p) { return (const TK_GLOBAL T*)p; }
+template <class T> TK_DEV TK_GLOBAL T* gptr(T* p) { return (TK_GLOBAL T*)p; }
+typedef uint32_t __attribute__((aligned(1), may_alias)) u32_unaligned;
+typedef unsigned long long __attribute__((aligned(1), may_alias)) u64_unaligned;
+TK_DEV uint32_t gload32(const void* p) { return *(const TK_GLOBAL u32_unaligned*)p; }
+TK_DEV unsigned long long gload64(const void* p) { return *(const TK_GLOBAL u64_unaligned*)p; }
 
 // scan index -> coefficient position for a qsize x qsize block (qsize 4, 8 or 16)
 struct IzzRef {

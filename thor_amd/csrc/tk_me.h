@@ -60,10 +60,7 @@ template <typename PIX> TK_DEV int sad4(const PIX* a, const PIX* b) {
 }
 #if !TK_HOST
 template <> __device__ __forceinline__ int sad4<uint8_t>(const uint8_t* a, const uint8_t* b) {
-  uint32_t va, vb;
-  __builtin_memcpy(&va, a, 4);
-  __builtin_memcpy(&vb, b, 4);
-  return (int)__builtin_amdgcn_sad_u8(va, vb, 0u);  // v_sad_u8: 4 byte-SADs per lane-op
+  return (int)__builtin_amdgcn_sad_u8(gload32(a), gload32(b), 0u);  // v_sad_u8: 4 byte-SADs per lane-op
 }
 #endif
 
@@ -128,9 +125,14 @@ TK_DEV unsigned long long eval_min(const Team t, int n, int nit, PrepF prep, Ite
 
 // 4-sample load helpers for the packed SAD
 template <typename PIX> struct Px4 { PIX v[4]; };
-template <typename PIX> TK_DEV Px4<PIX> ld4(const PIX* p) {
+template <typename PIX> TK_DEV Px4<PIX> ld4(const PIX* p) {  // p: global memory (frame plane / BigWs block)
   Px4<PIX> r;
+#if TK_HOST
   __builtin_memcpy(&r, p, sizeof(r));
+#else
+  if constexpr (sizeof(PIX) == 1) { const uint32_t v = gload32(p); __builtin_memcpy(&r, &v, 4); }
+  else { const unsigned long long v = gload64(p); __builtin_memcpy(&r, &v, 8); }
+#endif
   return r;
 }
 template <typename PIX> TK_DEV int sad4v(const Px4<PIX>& a, const Px4<PIX>& b) {
@@ -504,7 +506,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
     auto sub_item = [&](const SP& x, int r) -> int {
       int i, j;
       split2(dw, r, i, j);
-      return iabs((int)org[i * a.ostride + j] - luma_sample(ref, a.rstride, i, j, x.sp, a.enable_bipred, a.bitdepth));
+      return iabs((int)gptr(org)[i * a.ostride + j] - luma_sample(ref, a.rstride, i, j, x.sp, a.enable_bipred, a.bitdepth));
     };
     auto sub_cost = [&](int, const SP& x, int sad) -> unsigned {
       return ((unsigned)sad >> sh) + mv_cost(a.lam, x.mv.y - mvp.y, x.mv.x - mvp.x);
@@ -521,7 +523,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
       if (dy < 0 || dy > 2 || dx < 0 || dx > 2) in_window = 0;
     }
     unsigned long long k;
-    TK_PROF_ACC(w, 5, ps0_);
+    (void)0;
     TK_PROF_MARK(ps1_);
     if (in_window) {
       int sad8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -543,7 +545,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
         const PIX* p0 = ref + (i + ctr.ver_int - 3) * a.rstride + (j + ctr.hor_int - 3);
         WinRow<PIX> win[8];
         for (int q = 0; q < 8; q++) win_load(p0 + q * a.rstride, win[q]);
-        const int o = (int)org[i * a.ostride + j];
+        const int o = (int)gptr(org)[i * a.ostride + j];
         if constexpr (sizeof(PIX) == 1) {
           for (int q = 0; q < 8; q++) win[q] = win_bias(win[q]);
           for (int c = 0; c < 8; c++) {

@@ -64,14 +64,11 @@ TK_DEV SubPel luma_setup(mv_t mv, int sign, int width, int height, int pic_w, in
 // sixth: always inside the padded reference planes (160-sample borders + 64 samples of slack at the end).
 template <typename PIX> TK_DEV void load6(const PIX* p, int r[6]) {
   if (sizeof(PIX) == 1) {
-    unsigned long long v;
-    __builtin_memcpy(&v, p, 8);
+    const unsigned long long v = gload64(p);
     for (int m = 0; m < 6; m++) r[m] = (int)((v >> (8 * m)) & 0xffu);
   } else {
-    unsigned long long v0;
-    unsigned v1;
-    __builtin_memcpy(&v0, p, 8);
-    __builtin_memcpy(&v1, (const char*)p + 8, 4);
+    const unsigned long long v0 = gload64(p);
+    const unsigned v1 = gload32((const char*)p + 8);
     for (int m = 0; m < 4; m++) r[m] = (int)((v0 >> (16 * m)) & 0xffffu);
     r[4] = (int)(v1 & 0xffffu);
     r[5] = (int)(v1 >> 16);
@@ -80,12 +77,10 @@ template <typename PIX> TK_DEV void load6(const PIX* p, int r[6]) {
 
 template <typename PIX> TK_DEV void load4(const PIX* p, int r[4]) {
   if (sizeof(PIX) == 1) {
-    unsigned v;
-    __builtin_memcpy(&v, p, 4);
+    const unsigned v = gload32(p);
     for (int m = 0; m < 4; m++) r[m] = (int)((v >> (8 * m)) & 0xffu);
   } else {
-    unsigned long long v;
-    __builtin_memcpy(&v, p, 8);
+    const unsigned long long v = gload64(p);
     for (int m = 0; m < 4; m++) r[m] = (int)((v >> (16 * m)) & 0xffffu);
   }
 }
@@ -94,11 +89,11 @@ template <typename PIX> TK_DEV void load4(const PIX* p, int r[4]) {
 // displacement 0) is `ref`.
 template <typename PIX>
 TK_DEV int luma_sample(const PIX* ref, int stride, int i, int j, const SubPel& s, int bipred, int bitdepth) {
-  const PIX* p = ref + (i + s.ver_int) * stride + (j + s.hor_int);
+  const TK_GLOBAL PIX* p = gptr(ref) + (i + s.ver_int) * stride + (j + s.hor_int);
   if (s.ver_frac == 0 && s.hor_frac == 0) return p[0];
   if (s.ver_frac == 2 && s.hor_frac == 2 && bipred < 2) {
     int a[4], b[4], c[4], d[4];  // rows -1 .. 2, columns -1 .. 2
-    load4(p - stride - 1, a); load4(p - 1, b); load4(p + stride - 1, c); load4(p + 2 * stride - 1, d);
+    load4((const PIX*)(p - stride - 1), a); load4((const PIX*)(p - 1), b); load4((const PIX*)(p + stride - 1), c); load4((const PIX*)(p + 2 * stride - 1), d);
     int sum = a[1] + a[2] + b[0] + 2 * b[1] + 2 * b[2] + b[3] + c[0] + 2 * c[1] + 2 * c[2] + c[3] + d[1] + d[2];
     return sat_pix((sum + 8) >> 4, bitdepth);
   }
@@ -109,7 +104,7 @@ TK_DEV int luma_sample(const PIX* ref, int stride, int i, int j, const SubPel& s
   }
   if (s.ver_frac == 0) {
     int r[6];
-    load6(p - 2, r);
+    load6((const PIX*)(p - 2), r);
     int sum = 0;
     for (int m = 0; m < 6; m++) sum += s.th[m] * r[m];
     return sat_pix((sum * 64 + 2048) >> 12, bitdepth);
@@ -117,7 +112,7 @@ TK_DEV int luma_sample(const PIX* ref, int stride, int i, int j, const SubPel& s
   // 2-D: six rows of six samples; each row is fetched with one (u8) or two (u16) wide loads instead of six
   // narrow ones, and all rows are in flight before the first multiply
   int r[6][6];
-  for (int m = 0; m < 6; m++) load6(p + (m - 2) * stride - 2, r[m]);
+  for (int m = 0; m < 6; m++) load6((const PIX*)(p + (m - 2) * stride - 2), r[m]);
   int sum = 0;
   for (int n = 0; n < 6; n++) {
     int col = 0;
@@ -137,8 +132,8 @@ TK_DEV int luma_sample(const PIX* ref, int stride, int i, int j, const SubPel& s
 template <typename PIX> struct WinRow;
 template <> struct WinRow<uint8_t> { unsigned long long a; };
 template <> struct WinRow<uint16_t> { unsigned long long a, b; };
-TK_DEV void win_load(const uint8_t* p, WinRow<uint8_t>& r) { __builtin_memcpy(&r.a, p, 8); }
-TK_DEV void win_load(const uint16_t* p, WinRow<uint16_t>& r) { __builtin_memcpy(&r.a, p, 8); __builtin_memcpy(&r.b, p + 4, 8); }
+TK_DEV void win_load(const uint8_t* p, WinRow<uint8_t>& r) { r.a = gload64(p); }
+TK_DEV void win_load(const uint16_t* p, WinRow<uint16_t>& r) { r.a = gload64(p); r.b = gload64(p + 4); }
 // row selected by dy in {0,1,2} (uniform) out of three consecutive rows, then shifted right by dx samples
 TK_DEV WinRow<uint8_t> win_pick(const WinRow<uint8_t>& r0, const WinRow<uint8_t>& r1, const WinRow<uint8_t>& r2, int dy, int dx) {
   WinRow<uint8_t> o;
@@ -238,7 +233,7 @@ TK_DEV void pred_luma(const Team t, PIX* dst, int dstride, const PIX* ref, int r
   for (int k = t.rank; k < width * height; k += t.size) {
     int i, j;
     split2(pw, k, i, j);
-    dst[i * dstride + j] = (PIX)luma_sample(ref, rstride, i, j, s, bipred, bitdepth);
+    gptr(dst)[i * dstride + j] = (PIX)luma_sample(ref, rstride, i, j, s, bipred, bitdepth);
   }
 }
 
@@ -255,20 +250,20 @@ TK_DEV void pred_chroma(const Team t, PIX* dst, int dstride, const PIX* ref, int
   for (int k = t.rank; k < width * height; k += t.size) {
     int i, j;
     split2(mk_div(width), k, i, j);
-    const PIX* p = ref + (i + vi) * rstride + (j + hi);
+    const TK_GLOBAL PIX* p = gptr(ref) + (i + vi) * rstride + (j + hi);
     int v;
     if (vf == 0 && hf == 0) {
       v = p[0];
     } else {
       int sum = 0;
       for (int n = 0; n < 4; n++) {
-        const PIX* q = p + (n - 1) * rstride;
+        const TK_GLOBAL PIX* q = p + (n - 1) * rstride;
         int row = chroma_tap(hf, 0) * q[-1] + chroma_tap(hf, 1) * q[0] + chroma_tap(hf, 2) * q[1] + chroma_tap(hf, 3) * q[2];
         sum += chroma_tap(vf, n) * row;
       }
       v = sat_pix((sum + 2048) >> 12, bitdepth);
     }
-    dst[i * dstride + j] = (PIX)v;
+    gptr(dst)[i * dstride + j] = (PIX)v;
   }
 }
 
@@ -309,15 +304,15 @@ TK_DEV void average_yuv(const Team t, PIX* dy, PIX* du, PIX* dv, const PIX* ay, 
     int i, j;
     split2(mk_div(bw), k, i, j);
     int o = i * size + j;
-    dy[o] = (PIX)(((int)ay[o] + (int)by[o]) >> 1);
+    gptr(dy)[o] = (PIX)(((int)gptr(ay)[o] + (int)gptr(by)[o]) >> 1);
   }
   int cw = bw >> 1, ch = bh >> 1, cs = size >> 1;
   for (int k = t.rank; k < cw * ch; k += t.size) {
     int i, j;
     split2(mk_div(cw), k, i, j);
     int o = i * cs + j;
-    du[o] = (PIX)(((int)au[o] + (int)bu[o]) >> 1);
-    dv[o] = (PIX)(((int)av[o] + (int)bv[o]) >> 1);
+    gptr(du)[o] = (PIX)(((int)gptr(au)[o] + (int)gptr(bu)[o]) >> 1);
+    gptr(dv)[o] = (PIX)(((int)gptr(av)[o] + (int)gptr(bv)[o]) >> 1);
   }
 }
 
@@ -356,7 +351,9 @@ TK_DEV void make_edges(const Team t, IntraEdge<PIX>* e, const PIX* rec_frame, in
   const int toplen = upright ? size + 1 : size;
   const int top_from_block = tb_split && i != 0;
   const int left_from_block = tb_split && j != 0;
-  const PIX* trow = top_from_block ? (rblock - rbstride) : (rec_frame - fstride + j);
+  const TK_GLOBAL PIX* trow = gptr(top_from_block ? (rblock - rbstride) : (rec_frame - fstride + j));
+  const TK_GLOBAL PIX* const rblock_g = gptr(rblock);
+  const TK_GLOBAL PIX* const frame_g = gptr(rec_frame);
   // tb_split==0 => i==j==0 so (rec_frame - fstride + j) is the reference's &rec_frame[-fstride+j].
   const int top_dflt = (ypos + i == 0);
   const int left_dflt = (xpos + j == 0);
@@ -367,7 +364,7 @@ TK_DEV void make_edges(const Team t, IntraEdge<PIX>* e, const PIX* rec_frame, in
     if (left_dflt) lv = dflt;
     else {
       int kk = k < leftlen ? k : leftlen - 1;
-      lv = left_from_block ? rblock[kk * rbstride - 1] : rec_frame[(i + kk) * fstride - 1];
+      lv = left_from_block ? rblock_g[kk * rbstride - 1] : frame_g[(i + kk) * fstride - 1];
     }
     ((TK_LDS PIX*)e->top)[k] = tv;
     ((TK_LDS PIX*)e->left)[k] = lv;
@@ -375,11 +372,11 @@ TK_DEV void make_edges(const Team t, IntraEdge<PIX>* e, const PIX* rec_frame, in
   if (t.rank == 0) {
     PIX tl;
     if (top_dflt) {
-      tl = left_dflt ? dflt : (left_from_block ? rblock[-1] : rec_frame[i * fstride - 1]);  // = left[0]
+      tl = left_dflt ? dflt : (left_from_block ? rblock_g[-1] : frame_g[i * fstride - 1]);  // = left[0]
     } else if (!top_from_block) {
-      tl = xpos > 0 ? rec_frame[-fstride + j - 1] : trow[0];
+      tl = xpos > 0 ? frame_g[-fstride + j - 1] : trow[0];
     } else {
-      tl = xpos > 0 ? (j > 0 ? rblock[-rbstride - 1] : rec_frame[(i - 1) * fstride - 1]) : trow[0];
+      tl = xpos > 0 ? (j > 0 ? rblock_g[-rbstride - 1] : frame_g[(i - 1) * fstride - 1]) : trow[0];
     }
     e->top_left = tl;
   }
@@ -463,7 +460,7 @@ TK_DEV void pred_intra(const Team t, const IntraEdge<PIX>* e, int ypos, int xpos
       } break;
       default: v = dc; break;
     }
-    dst[i * dstride + j] = (PIX)v;
+    gptr(dst)[i * dstride + j] = (PIX)v;
   }
 }
 
