@@ -343,6 +343,17 @@ def main():
         alg_bytes_per_launch = (w * h * a.steps * S * bytes_per_px) / max(launches, 1)
         avg_launch_s = (sb_ms / 1e3) / max(launches, 1)
         achieved = alg_bytes_per_launch / max(avg_launch_s, 1e-12) / 1e9
+        # HBM traffic per launch from the committed PMC passes of this kernel (profiles/r02_pmc.json: FETCH_SIZE + WRITE_SIZE
+        # with the guide's gfx950 corrections, collected in their own runs on a saturated workload of the same operating
+        # point) scaled from bytes per luma pixel to the pixels one launch of THIS run covers; null if the file is missing.
+        traffic, traffic_src = None, None
+        try:
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc.json')))
+            traffic = round((pm['fetch_bytes_per_px'] + pm['write_bytes_per_px']) * w * h * S * a.steps / max(launches, 1))
+            traffic_src = 'profiles/r02_pmc.md (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE: %.0f + %.0f B per luma pixel on: %s)' % (
+                pm['fetch_bytes_per_px'], pm['write_bytes_per_px'], pm['workload'])
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             'metric': 'encoder Mpixels/s at fixed qp, bit-exact recon vs ref', 'value': round(value, 3), 'unit': 'Mpixels/s',
             'fps': round(value * 1e6 / (w * h), 3),
@@ -355,7 +366,8 @@ def main():
                        'streams_per_gpu': S, 'frames_timed_per_stream': a.steps, 'parallelism': f'stream-sharded x{world}',
                        'per_stream_fps': round(a.steps / dt, 4), 'per_stream_mpx_s': round(w * h * a.steps / dt / 1e6, 4)},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 4), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 8), 'traffic': None,
+                         'frac': round(achieved / HBM_PEAK_GBS, 8), 'traffic': traffic, 'traffic_unit': 'bytes per launch', 'traffic_source': traffic_src,
+                         'alg_bytes_per_launch': round(alg_bytes_per_launch),
                          'kernel': 'k_superblocks', 'launches': launches, 'avg_launch_ms': round(avg_launch_s * 1e3, 3),
                          'alg_bytes_per_px': round(bytes_per_px, 3),
                          'note': 'one persistent dependency-driven launch per frame; the path is latency/VALU-bound, not HBM-bound (SURVEY.md 0.7); '

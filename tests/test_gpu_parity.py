@@ -100,3 +100,21 @@ def test_live_reference_random_access_17_frames():
     rb, rr = run_encoder(REF_ENC, clip, 416, 240, 19, 30, cfg='ra_high_efficiency.cfg')
     bits, rec = run_encoder(os.path.join(ROOT, 'tools', 'thorenc_hip'), clip, 416, 240, 19, 30, cfg='ra_high_efficiency.cfg')
     assert bits == rb and rec == rr
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_HIPENC) and os.path.exists(REF_ENC)), reason='oracle/_ref binaries not in the snapshot')
+def test_dropin_tiny_all_skip_frames_header_backpatch():
+    """Tiny static clip through the drop-in seam: the P frames are all-skip and only a few words long, so the CDEF header
+    back-patch of the reference's stream writer (enc/encode_frame.c:776-782, putbits.c:130-144) partly lands in the
+    unflushed accumulator - and frame 0 starts behind the sequence header, i.e. at a non-zero bit phase of the caller's
+    stream.  Stream and reconstruction must still equal the all-reference encoder's."""
+    y = np.full((64, 64), 90, dtype=np.uint8)
+    y[16:48, 16:48] = 140
+    frame = np.concatenate([y.ravel(), np.full(32 * 32, 120, dtype=np.uint8), np.full(32 * 32, 130, dtype=np.uint8)]).tobytes()
+    clip = frame * 4
+    for qp in (32, 44):
+        rb, rr = run_encoder(REF_ENC, clip, 64, 64, 4, qp)
+        bits, rec = run_encoder(REF_HIPENC, clip, 64, 64, 4, qp)
+        assert bits == rb and rec == rr, qp
+        b2, r2 = encode_gpu(clip, 64, 64, 4, qp)
+        assert b2[0] == rb and r2[0] == rr, qp

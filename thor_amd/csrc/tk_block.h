@@ -35,6 +35,10 @@ struct Node {
 // up to 128x128 in a global scratch arena that stays L1/L2 resident).
 enum { kProfSlots = 32 };
 enum { kMdMaxItems = 32 };
+#ifndef TK_LDS_BLK
+#define TK_LDS_BLK 16
+#endif
+enum { kLdsBlk = TK_LDS_BLK };
 enum { MD_SKIP = 0, MD_MERGE, MD_REF, MD_INTRA, MD_BIPRED };
 enum { WG_CMD_EXIT = 0, WG_CMD_MD = 1 };
 struct MdItem { int8_t kind, a, b, pad; };
@@ -64,6 +68,9 @@ template <typename PIX> struct SmallWs {
   // use the BigWs buffers instead.
   int16_t coef_y[4 * 256], coef_u[256], coef_v[256];
   unsigned long long acc[12];
+  // sample blocks (prediction, the two bi-prediction inputs, reconstruction, 2*org-pred) of coding blocks up to
+  // kLdsBlk x kLdsBlk: the trials of the small blocks - the bulk of all trials - never round-trip through global memory
+  PIX lbuf[7 * kLdsBlk * kLdsBlk];
 #if defined(THOR_PROF)
   long long prof[kProfSlots];
 #else
@@ -88,8 +95,28 @@ template <typename PIX> struct TeamWs {  // view (lives in registers)
   WgShared* sh;
   Node* stack;
   long long* prof;
-  PIX *pred_y, *pred_u, *pred_v, *p0_y, *p0_u, *p0_v, *p1_y, *p1_u, *p1_v, *rec_y, *rec_u, *rec_v, *org8;
+  PIX *pred_y, *pred_u, *pred_v, *p0_y, *p0_u, *p0_v, *p1_y, *p1_u, *p1_v, *rec_y, *rec_u, *rec_v, *org8;  // current (ws_select)
+  BigWs<PIX>* big;
+  PIX* lbuf;
 };
+// Point the sample-block views at the LDS buffers (coding blocks up to kLdsBlk) or at the global scratch slot.
+template <typename PIX> TK_DEV void ws_select(TeamWs<PIX>* w, int size) {
+  if (size <= kLdsBlk) {
+    PIX* b = w->lbuf;
+    const int n = size * size, c = n >> 2;
+    w->pred_y = b; w->pred_u = b + n; w->pred_v = b + n + c; b += n + 2 * c;
+    w->p0_y = b; w->p0_u = b + n; w->p0_v = b + n + c; b += n + 2 * c;
+    w->p1_y = b; w->p1_u = b + n; w->p1_v = b + n + c; b += n + 2 * c;
+    w->rec_y = b; w->rec_u = b + n; w->rec_v = b + n + c; b += n + 2 * c;
+    w->org8 = b;
+  } else {
+    BigWs<PIX>* g = w->big;
+    w->pred_y = g->pred_y; w->pred_u = g->pred_u; w->pred_v = g->pred_v;
+    w->p0_y = g->p0_y; w->p0_u = g->p0_u; w->p0_v = g->p0_v;
+    w->p1_y = g->p1_y; w->p1_u = g->p1_u; w->p1_v = g->p1_v;
+    w->rec_y = g->rec_y; w->rec_u = g->rec_u; w->rec_v = g->rec_v; w->org8 = g->org8;
+  }
+}
 template <typename PIX> TK_DEV TeamWs<PIX> make_ws(SmallWs<PIX>* s, WgShared* sh, BigWs<PIX>* g) {
   TeamWs<PIX> w;
   w.xfp = &s->xf; w.mep = &s->me; w.edgep = &s->edge;
@@ -98,10 +125,8 @@ template <typename PIX> TK_DEV TeamWs<PIX> make_ws(SmallWs<PIX>* s, WgShared* sh
   w.coef_u_small = s->coef_u; w.coef_v_small = s->coef_v; w.coef_u_big = g->coef_u_big; w.coef_v_big = g->coef_v_big;
   w.acc = s->acc; w.stack = sh->stack; w.prof = s->prof;
   s->xf.prof = s->prof; s->me.prof = s->prof;
-  w.pred_y = g->pred_y; w.pred_u = g->pred_u; w.pred_v = g->pred_v;
-  w.p0_y = g->p0_y; w.p0_u = g->p0_u; w.p0_v = g->p0_v;
-  w.p1_y = g->p1_y; w.p1_u = g->p1_u; w.p1_v = g->p1_v;
-  w.rec_y = g->rec_y; w.rec_u = g->rec_u; w.rec_v = g->rec_v; w.org8 = g->org8;
+  w.big = g; w.lbuf = s->lbuf;
+  ws_select(&w, kMaxSb);
   return w;
 }
 
@@ -230,7 +255,7 @@ TK_DEV void ssd_acc(const Team t, unsigned long long* acc, const PIX* a, int as,
     for (int k = t.rank; k < w * h; k += t.size) {
       int i, j;
       split2(pw, k, i, j);
-      int d = (int)gptr(a)[i * as + j] - (int)gptr(b)[i * bs + j];
+      int d = (int)gptr(a)[i * as + j] - (int)b[i * bs + j];  // a: original frame plane, b: per-wave block
       local += (unsigned long long)(d * d);
     }
   } else {
@@ -709,7 +734,7 @@ TK_DEVNI void search_bipred(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* w
       for (int k = t.rank; k < size * size; k += t.size) {
         int i, j;
         split2(mk_pow2(size), k, i, j);
-        gptr(ws->org8)[k] = (PIX)sat_pix(2 * (int)gptr(oy)[i * J.orig.sy + j] - (int)gptr(ws->pred_y)[k], c.bitdepth);
+        ws->org8[k] = (PIX)sat_pix(2 * (int)gptr(oy)[i * J.orig.sy + j] - (int)ws->pred_y[k], c.bitdepth);
       }
       t.sync();
       int ref_start, ref_end;
@@ -760,7 +785,7 @@ TK_DEVNI unsigned intra_sad_search(const Team t, const FrameJob<PIX>& J, TeamWs<
     for (int k = t.rank; k < size * size; k += t.size) {
       int i, j;
       split2(mk_pow2(size), k, i, j);
-      local += iabs((int)gptr(oy)[i * J.orig.sy + j] - (int)gptr(ws->pred_y)[k]);
+      local += iabs((int)gptr(oy)[i * J.orig.sy + j] - (int)ws->pred_y[k]);
     }
     const unsigned sad = (unsigned)team_sum(t, local) >> (bd - 8);
     t.sync();
@@ -1084,6 +1109,7 @@ TK_DEVNI void md_worker(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamW
   WgShared* sh = ws->sh;
   MdCtx<PIX> M;
   M.wg = wg; M.sh = sh; M.nd = &sh->stack[sh->node]; M.mykey = ~0ull;
+  ws_select(ws, tk_uniform(M.nd->size));
   const EncCfg& c = J.cfg;
   const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
   const int n_items = sh->n_items;
@@ -1374,6 +1400,7 @@ TK_DEV void process_sb(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamWs
       // ---- entry
       const int size = nd.size, ypos = nd.ypos, xpos = nd.xpos;
       if (ypos + kMinBlk > fh || xpos + kMinBlk > fw) { ret = 0; have_ret = 1; sp--; continue; }
+      ws_select(ws, tk_uniform(size));
       t.sync();
       if (t.rank == 0) {
         nd.bw = tmin(size, fw - xpos);
@@ -1478,6 +1505,7 @@ TK_DEV void process_sb(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamWs
     }
     // ---- stage 2: decide this size
     {
+      ws_select(ws, tk_uniform(nd.size));
       unsigned cost = 1u << 28;
       if (nd.encode_this_size || nd.encode_rect) {
         if (!nd.md_done) {

@@ -60,7 +60,9 @@ template <typename PIX> TK_DEV int sad4(const PIX* a, const PIX* b) {
 }
 #if !TK_HOST
 template <> __device__ __forceinline__ int sad4<uint8_t>(const uint8_t* a, const uint8_t* b) {
-  return (int)__builtin_amdgcn_sad_u8(gload32(a), gload32(b), 0u);  // v_sad_u8: 4 byte-SADs per lane-op
+  uint32_t va;
+  __builtin_memcpy(&va, a, 4);  // a: original block (frame plane, or a per-wave block that may live in LDS); b: reference plane
+  return (int)__builtin_amdgcn_sad_u8(va, gload32(b), 0u);  // v_sad_u8: 4 byte-SADs per lane-op
 }
 #endif
 
@@ -125,7 +127,12 @@ TK_DEV unsigned long long eval_min(const Team t, int n, int nit, PrepF prep, Ite
 
 // 4-sample load helpers for the packed SAD
 template <typename PIX> struct Px4 { PIX v[4]; };
-template <typename PIX> TK_DEV Px4<PIX> ld4(const PIX* p) {  // p: global memory (frame plane / BigWs block)
+template <typename PIX> TK_DEV Px4<PIX> ld4(const PIX* p) {  // any address space (the original block may live in LDS)
+  Px4<PIX> r;
+  __builtin_memcpy(&r, p, sizeof(r));
+  return r;
+}
+template <typename PIX> TK_DEV Px4<PIX> ld4g(const PIX* p) {  // p: global memory (reference plane)
   Px4<PIX> r;
 #if TK_HOST
   __builtin_memcpy(&r, p, sizeof(r));
@@ -195,8 +202,8 @@ TK_DEV unsigned long long eval_fullpel(const Team t, int n, const PIX* org, int 
           if (k < cnt) {
             const int r = sub + (k0 + k) * G, i = r >> lg, g = r & (gpr - 1);
             if (!hoist) o[k] = ld4(org + i * ostride + 4 * g);
-            a[k] = ld4(xa.p + i * rstride + 4 * g);
-            if (vb) b[k] = ld4(xb.p + i * rstride + 4 * g);
+            a[k] = ld4g(xa.p + i * rstride + 4 * g);
+            if (vb) b[k] = ld4g(xb.p + i * rstride + 4 * g);
           }
 #if !TK_HOST
 #pragma unroll
@@ -506,7 +513,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
     auto sub_item = [&](const SP& x, int r) -> int {
       int i, j;
       split2(dw, r, i, j);
-      return iabs((int)gptr(org)[i * a.ostride + j] - luma_sample(ref, a.rstride, i, j, x.sp, a.enable_bipred, a.bitdepth));
+      return iabs((int)org[i * a.ostride + j] - luma_sample(ref, a.rstride, i, j, x.sp, a.enable_bipred, a.bitdepth));
     };
     auto sub_cost = [&](int, const SP& x, int sad) -> unsigned {
       return ((unsigned)sad >> sh) + mv_cost(a.lam, x.mv.y - mvp.y, x.mv.x - mvp.x);
@@ -545,7 +552,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
         const PIX* p0 = ref + (i + ctr.ver_int - 3) * a.rstride + (j + ctr.hor_int - 3);
         WinRow<PIX> win[8];
         for (int q = 0; q < 8; q++) win_load(p0 + q * a.rstride, win[q]);
-        const int o = (int)gptr(org)[i * a.ostride + j];
+        const int o = (int)org[i * a.ostride + j];
         if constexpr (sizeof(PIX) == 1) {
           for (int q = 0; q < 8; q++) win[q] = win_bias(win[q]);
           for (int c = 0; c < 8; c++) {

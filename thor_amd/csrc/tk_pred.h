@@ -233,7 +233,7 @@ TK_DEV void pred_luma(const Team t, PIX* dst, int dstride, const PIX* ref, int r
   for (int k = t.rank; k < width * height; k += t.size) {
     int i, j;
     split2(pw, k, i, j);
-    gptr(dst)[i * dstride + j] = (PIX)luma_sample(ref, rstride, i, j, s, bipred, bitdepth);
+    dst[i * dstride + j] = (PIX)luma_sample(ref, rstride, i, j, s, bipred, bitdepth);
   }
 }
 
@@ -263,7 +263,7 @@ TK_DEV void pred_chroma(const Team t, PIX* dst, int dstride, const PIX* ref, int
       }
       v = sat_pix((sum + 2048) >> 12, bitdepth);
     }
-    gptr(dst)[i * dstride + j] = (PIX)v;
+    dst[i * dstride + j] = (PIX)v;
   }
 }
 
@@ -304,15 +304,15 @@ TK_DEV void average_yuv(const Team t, PIX* dy, PIX* du, PIX* dv, const PIX* ay, 
     int i, j;
     split2(mk_div(bw), k, i, j);
     int o = i * size + j;
-    gptr(dy)[o] = (PIX)(((int)gptr(ay)[o] + (int)gptr(by)[o]) >> 1);
+    dy[o] = (PIX)(((int)ay[o] + (int)by[o]) >> 1);
   }
   int cw = bw >> 1, ch = bh >> 1, cs = size >> 1;
   for (int k = t.rank; k < cw * ch; k += t.size) {
     int i, j;
     split2(mk_div(cw), k, i, j);
     int o = i * cs + j;
-    gptr(du)[o] = (PIX)(((int)gptr(au)[o] + (int)gptr(bu)[o]) >> 1);
-    gptr(dv)[o] = (PIX)(((int)gptr(av)[o] + (int)gptr(bv)[o]) >> 1);
+    du[o] = (PIX)(((int)au[o] + (int)bu[o]) >> 1);
+    dv[o] = (PIX)(((int)av[o] + (int)bv[o]) >> 1);
   }
 }
 
@@ -351,8 +351,8 @@ TK_DEV void make_edges(const Team t, IntraEdge<PIX>* e, const PIX* rec_frame, in
   const int toplen = upright ? size + 1 : size;
   const int top_from_block = tb_split && i != 0;
   const int left_from_block = tb_split && j != 0;
-  const TK_GLOBAL PIX* trow = gptr(top_from_block ? (rblock - rbstride) : (rec_frame - fstride + j));
-  const TK_GLOBAL PIX* const rblock_g = gptr(rblock);
+  const PIX* trow = top_from_block ? (rblock - rbstride) : (rec_frame - fstride + j);
+  const PIX* const rblock_g = rblock;  // CB-local recon block: per-wave scratch, in LDS for small CBs
   const TK_GLOBAL PIX* const frame_g = gptr(rec_frame);
   // tb_split==0 => i==j==0 so (rec_frame - fstride + j) is the reference's &rec_frame[-fstride+j].
   const int top_dflt = (ypos + i == 0);
@@ -460,7 +460,7 @@ TK_DEV void pred_intra(const Team t, const IntraEdge<PIX>* e, int ypos, int xpos
       } break;
       default: v = dc; break;
     }
-    gptr(dst)[i * dstride + j] = (PIX)v;
+    dst[i * dstride + j] = (PIX)v;
   }
 }
 

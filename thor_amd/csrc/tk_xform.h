@@ -72,12 +72,12 @@ TK_DEV void fwd_transform(const Team t, XformWs* ws, const PIX* org, int ostride
     split2(mk_pow2(size1), k, i, j);
     int sum = 0;
     if (scale == 1) {
-      sum = (int16_t)((int)gptr(org)[i * ostride + j] - (int)gptr(pred)[i * pstride + j]);
+      sum = (int16_t)((int)gptr(org)[i * ostride + j] - (int)pred[i * pstride + j]);
     } else {
       for (int m = 0; m < scale; m++)
         for (int n = 0; n < scale; n++) {
           int y = i * scale + m, x = j * scale + n;
-          int r = (int16_t)((int)gptr(org)[y * ostride + x] - (int)gptr(pred)[y * pstride + x]);
+          int r = (int16_t)((int)gptr(org)[y * ostride + x] - (int)pred[y * pstride + x]);
           sum = clampi((int16_t)sum + r, -16384, 16383);
         }
     }
@@ -251,7 +251,7 @@ TK_DEV void inv_transform_recon(const Team t, XformWs* ws, const PIX* pred, int 
     for (int m = 0; m < scale; m++)
       for (int x = 0; x < scale; x++) {
         int yy = scale * i + m, xx = scale * j + x;
-        gptr(rec)[yy * rstride + xx] = (PIX)sat_pix(r + (int)gptr(pred)[yy * pstride + xx], bitdepth);
+        rec[yy * rstride + xx] = (PIX)sat_pix(r + (int)pred[yy * pstride + xx], bitdepth);
       }
   }
   t.sync();
@@ -267,7 +267,7 @@ TK_DEV void copy_block(const Team t, PIX* dst, int dstride, const PIX* src, int 
     for (int k = t.rank; k < w * h; k += t.size) {
       int i, j;
       split2(pw, k, i, j);
-      gptr(dst)[i * dstride + j] = gptr(src)[i * sstride + j];
+      dst[i * dstride + j] = src[i * sstride + j];
     }
   } else {  // frame-edge rectangles (skip blocks)
     for (int k = t.rank; k < w * h; k += t.size) {
