@@ -58,6 +58,9 @@ struct WgShared {
   unsigned long long wkey[kWaves];
   BlkParam wbest[kWaves];
   MdItem items[kMdMaxItems];
+  // original samples (Y, U, V; stride = block size) of the coding block being decided when it is at most kLdsBlk wide:
+  // loaded once by the master, read by every trial of every wave instead of the frame in global memory
+  alignas(16) unsigned char org_raw[kLdsBlk * kLdsBlk * 3];
 };
 template <typename PIX> struct SmallWs {
   XformWs xf;
@@ -98,6 +101,8 @@ template <typename PIX> struct TeamWs {  // view (lives in registers)
   PIX *pred_y, *pred_u, *pred_v, *p0_y, *p0_u, *p0_v, *p1_y, *p1_u, *p1_v, *rec_y, *rec_u, *rec_v, *org8;  // current (ws_select)
   BigWs<PIX>* big;
   PIX* lbuf;
+  const PIX *org_y, *org_u, *org_v;  // original samples of the current coding block (origin), strides org_sy / org_sc
+  int org_sy, org_sc;
 };
 // Point the sample-block views at the LDS buffers (coding blocks up to kLdsBlk) or at the global scratch slot.
 template <typename PIX> TK_DEV void ws_select(TeamWs<PIX>* w, int size) {
@@ -117,6 +122,38 @@ template <typename PIX> TK_DEV void ws_select(TeamWs<PIX>* w, int size) {
     w->rec_y = g->rec_y; w->rec_u = g->rec_u; w->rec_v = g->rec_v; w->org8 = g->org8;
   }
 }
+// Point ws->org_* at the original samples of coding block `nd`: the frame planes, or (blocks up to kLdsBlk) the
+// workgroup's LDS copy, which the master fills with load = 1 before any wave uses it.
+template <typename PIX>
+TK_DEV void org_select(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* w, int size, int ypos, int xpos, int bw, int bh, int load) {
+  if (size <= kLdsBlk) {
+    PIX* b = (PIX*)w->sh->org_raw;
+    const int n = size * size, sc = size >> 1;
+    if (load) {
+      t.sync();
+      const Div2 dw = mk_div(bw), dc = mk_div(bw >> 1);
+      const TK_GLOBAL PIX* gy = gptr(J.orig.y + ypos * J.orig.sy + xpos);
+      const TK_GLOBAL PIX* gu = gptr(J.orig.u + (ypos >> 1) * J.orig.sc + (xpos >> 1));
+      const TK_GLOBAL PIX* gv = gptr(J.orig.v + (ypos >> 1) * J.orig.sc + (xpos >> 1));
+      for (int k = t.rank; k < bw * bh; k += t.size) { int i, j; split2(dw, k, i, j); b[i * size + j] = gy[i * J.orig.sy + j]; }
+      for (int k = t.rank; k < (bw >> 1) * (bh >> 1); k += t.size) {
+        int i, j;
+        split2(dc, k, i, j);
+        b[n + i * sc + j] = gu[i * J.orig.sc + j];
+        b[n + (n >> 2) + i * sc + j] = gv[i * J.orig.sc + j];
+      }
+      t.sync();
+    }
+    w->org_y = b; w->org_u = b + n; w->org_v = b + n + (n >> 2);
+    w->org_sy = size; w->org_sc = sc;
+  } else {
+    w->org_y = J.orig.y + ypos * J.orig.sy + xpos;
+    w->org_u = J.orig.u + (ypos >> 1) * J.orig.sc + (xpos >> 1);
+    w->org_v = J.orig.v + (ypos >> 1) * J.orig.sc + (xpos >> 1);
+    w->org_sy = J.orig.sy; w->org_sc = J.orig.sc;
+  }
+}
+
 template <typename PIX> TK_DEV TeamWs<PIX> make_ws(SmallWs<PIX>* s, WgShared* sh, BigWs<PIX>* g) {
   TeamWs<PIX> w;
   w.xfp = &s->xf; w.mep = &s->me; w.edgep = &s->edge;
@@ -126,6 +163,7 @@ template <typename PIX> TK_DEV TeamWs<PIX> make_ws(SmallWs<PIX>* s, WgShared* sh
   w.acc = s->acc; w.stack = sh->stack; w.prof = s->prof;
   s->xf.prof = s->prof; s->me.prof = s->prof;
   w.big = g; w.lbuf = s->lbuf;
+  w.org_y = w.org_u = w.org_v = nullptr; w.org_sy = w.org_sc = 0;
   ws_select(&w, kMaxSb);
   return w;
 }
@@ -255,7 +293,7 @@ TK_DEV void ssd_acc(const Team t, unsigned long long* acc, const PIX* a, int as,
     for (int k = t.rank; k < w * h; k += t.size) {
       int i, j;
       split2(pw, k, i, j);
-      int d = (int)gptr(a)[i * as + j] - (int)b[i * bs + j];  // a: original frame plane, b: per-wave block
+      int d = (int)a[i * as + j] - (int)b[i * bs + j];
       local += (unsigned long long)(d * d);
     }
   } else {
@@ -278,9 +316,9 @@ TK_DEVNI unsigned rd_cost(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
   if (t.rank == 0) ws->acc[0] = ssd_y >= 0 ? (unsigned long long)ssd_y : 0ull;
   t.sync();
   const int yc = nd.ypos >> 1, xc = nd.xpos >> 1, sc = nd.size >> 1;
-  if (ssd_y < 0) ssd_acc(t, &ws->acc[0], J.orig.y + nd.ypos * J.orig.sy + nd.xpos, J.orig.sy, ws->rec_y, nd.size, nd.bw, nd.bh);
-  ssd_acc(t, &ws->acc[0], J.orig.u + yc * J.orig.sc + xc, J.orig.sc, ws->rec_u, sc, nd.bw >> 1, nd.bh >> 1);
-  ssd_acc(t, &ws->acc[0], J.orig.v + yc * J.orig.sc + xc, J.orig.sc, ws->rec_v, sc, nd.bw >> 1, nd.bh >> 1);
+  if (ssd_y < 0) ssd_acc(t, &ws->acc[0], ws->org_y, ws->org_sy, ws->rec_y, nd.size, nd.bw, nd.bh);
+  ssd_acc(t, &ws->acc[0], ws->org_u, ws->org_sc, ws->rec_u, sc, nd.bw >> 1, nd.bh >> 1);
+  ssd_acc(t, &ws->acc[0], ws->org_v, ws->org_sc, ws->rec_v, sc, nd.bw >> 1, nd.bh >> 1);
   t.sync();
   unsigned long long ssd = ws->acc[0];
   t.sync();
@@ -431,7 +469,7 @@ TK_DEV int prune_after_quadrant(const Team t, const FrameJob<PIX>& J, TeamWs<PIX
   t.sync();
   if (t.rank == 0) ws->acc[1] = 0;
   t.sync();
-  ssd_acc(t, &ws->acc[1], J.orig.y + (nd.ypos + i) * J.orig.sy + nd.xpos + j, J.orig.sy, ws->rec_y + i * nd.size + j, nd.size, s2, s2);
+  ssd_acc(t, &ws->acc[1], ws->org_y + i * ws->org_sy + j, ws->org_sy, ws->rec_y + i * nd.size + j, nd.size, s2, s2);
   t.sync();
   pc->ssd_part += (long long)ws->acc[1];
   t.sync();
@@ -457,7 +495,7 @@ TK_DEV int prune_after_luma(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* w
   t.sync();
   if (t.rank == 0) ws->acc[1] = 0;
   t.sync();
-  ssd_acc(t, &ws->acc[1], J.orig.y + nd.ypos * J.orig.sy + nd.xpos, J.orig.sy, ws->rec_y, size, nd.bw, nd.bh);
+  ssd_acc(t, &ws->acc[1], ws->org_y, ws->org_sy, ws->rec_y, size, nd.bw, nd.bh);
   t.sync();
   const unsigned long long ssd = ws->acc[1];
   t.sync();
@@ -527,9 +565,10 @@ TK_DEVNI int encode_block(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
     ws->coef_u = bigc ? ws->coef_u_big : ws->coef_u_small;
     ws->coef_v = bigc ? ws->coef_v_big : ws->coef_v_small;
   }
-  const PIX* oy = J.orig.y + nd.ypos * J.orig.sy + nd.xpos;
-  const PIX* ou = J.orig.u + yc * J.orig.sc + xc;
-  const PIX* ov = J.orig.v + yc * J.orig.sc + xc;
+  const PIX* oy = ws->org_y;
+  const PIX* ou = ws->org_u;
+  const PIX* ov = ws->org_v;
+  const int osy = TKU(ws->org_sy), osc = TKU(ws->org_sc);
   int cbp_y = 0, cbp_u = 0, cbp_v = 0;
 
   if (TKU(p.mode) == M_INTRA) {
@@ -547,7 +586,7 @@ TK_DEVNI int encode_block(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
           make_edges(t, ws->edgep, fy, J.rec.sy, ws->rec_y + i * size + j, size, i, j, nd.ypos, nd.xpos, s2, ur, dl, 1, bd);
           pred_intra(t, ws->edgep, nd.ypos + i, nd.xpos + j, s2, ws->pred_y + i * size + j, size, p.intra_mode, bd);
           t.sync();
-          int bit = code_tu(t, ws->xfp, oy + i * J.orig.sy + j, J.orig.sy, ws->pred_y + i * size + j, size,
+          int bit = code_tu(t, ws->xfp, oy + i * osy + j, osy, ws->pred_y + i * size + j, size,
                             ws->rec_y + i * size + j, size, s2, qpY, ftI | 0, c.encoder_speed > 1, ws->coef_y + index, bd);
           cbp_y = (cbp_y << 1) + bit;
           if (prune_after_quadrant(t, J, ws, nd, 1, (i ? 2 : 0) + (j ? 1 : 0), i, j, s2, bit, ws->coef_y + index, pc)) return 0;
@@ -557,7 +596,7 @@ TK_DEVNI int encode_block(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
       make_edges(t, ws->edgep, fy, J.rec.sy, (const PIX*)nullptr, 0, 0, 0, nd.ypos, nd.xpos, size, ur, dl, 0, bd);
       pred_intra(t, ws->edgep, nd.ypos, nd.xpos, size, ws->pred_y, size, p.intra_mode, bd);
       t.sync();
-      cbp_y = code_tu(t, ws->xfp, oy, J.orig.sy, ws->pred_y, size, ws->rec_y, size, size, qpY, ftI | 0,
+      cbp_y = code_tu(t, ws->xfp, oy, osy, ws->pred_y, size, ws->rec_y, size, size, qpY, ftI | 0,
                       c.encoder_speed > 1, ws->coef_y, bd);
     }
     if (prune_after_luma(t, J, ws, nd, p, cbp_y, tb_split, pc)) return 0;
@@ -577,10 +616,10 @@ TK_DEVNI int encode_block(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
           if (c.cfl_intra)  // sic: luma pointers offset in CHROMA units (encode_block.c:1199)
             improve_uv(t, ws, ws->pred_y + i * sizeC + j, ws->pred_u + i * sizeC + j, ws->pred_v + i * sizeC + j,
                        ws->rec_y + (i << 1) * size + (j << 1), s2 << 1, sizeC << 1, size, bd);
-          int bu = code_tu(t, ws->xfp, ou + i * J.orig.sc + j, J.orig.sc, ws->pred_u + i * sizeC + j, sizeC,
+          int bu = code_tu(t, ws->xfp, ou + i * osc + j, osc, ws->pred_u + i * sizeC + j, sizeC,
                            ws->rec_u + i * sizeC + j, sizeC, s2, qpC, ftI | 1, c.encoder_speed > 1, ws->coef_u + index, bd);
           cbp_u = (cbp_u << 1) + bu;
-          int bv = code_tu(t, ws->xfp, ov + i * J.orig.sc + j, J.orig.sc, ws->pred_v + i * sizeC + j, sizeC,
+          int bv = code_tu(t, ws->xfp, ov + i * osc + j, osc, ws->pred_v + i * sizeC + j, sizeC,
                            ws->rec_v + i * sizeC + j, sizeC, s2, qpC, ftI | 1, c.encoder_speed > 1, ws->coef_v + index, bd);
           cbp_v = (cbp_v << 1) + bv;
           index += tmin(s2, 16) * tmin(s2, 16);
@@ -593,9 +632,9 @@ TK_DEVNI int encode_block(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
       pred_intra(t, ws->edgep, yc, xc, sizeC, ws->pred_v, sizeC, p.intra_mode, bd);
       t.sync();
       if (c.cfl_intra) improve_uv(t, ws, ws->pred_y, ws->pred_u, ws->pred_v, ws->rec_y, size, size, size, bd);
-      cbp_u = code_tu(t, ws->xfp, ou, J.orig.sc, ws->pred_u, sizeC, ws->rec_u, sizeC, sizeC, qpC, ftI | 1,
+      cbp_u = code_tu(t, ws->xfp, ou, osc, ws->pred_u, sizeC, ws->rec_u, sizeC, sizeC, qpC, ftI | 1,
                       c.encoder_speed > 1, ws->coef_u, bd);
-      cbp_v = code_tu(t, ws->xfp, ov, J.orig.sc, ws->pred_v, sizeC, ws->rec_v, sizeC, sizeC, qpC, ftI | 1,
+      cbp_v = code_tu(t, ws->xfp, ov, osc, ws->pred_v, sizeC, ws->rec_v, sizeC, sizeC, qpC, ftI | 1,
                       c.encoder_speed > 1, ws->coef_v, bd);
     }
   } else {
@@ -607,12 +646,12 @@ TK_DEVNI int encode_block(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
       copy_block(t, ws->rec_v, sizeC, ws->pred_v, sizeC, nd.bw >> 1, nd.bh >> 1);
       t.sync();
     } else {
-      cbp_y = code_inter_plane(t, J, ws, oy, J.orig.sy, ws->pred_y, ws->rec_y, size, qpY, ftI | 0, tb_split, ws->coef_y, &nd, pc);
+      cbp_y = code_inter_plane(t, J, ws, oy, osy, ws->pred_y, ws->rec_y, size, qpY, ftI | 0, tb_split, ws->coef_y, &nd, pc);
       if (prune_after_luma(t, J, ws, nd, p, cbp_y, tb_split, pc)) return 0;
       if (c.cfl_inter) improve_uv(t, ws, ws->pred_y, ws->pred_u, ws->pred_v, ws->rec_y, size, size, size, bd);
       const int csplit = tb_split && sizeC > 4;
-      cbp_u = code_inter_plane(t, J, ws, ou, J.orig.sc, ws->pred_u, ws->rec_u, sizeC, qpC, ftI | 1, csplit, ws->coef_u);
-      cbp_v = code_inter_plane(t, J, ws, ov, J.orig.sc, ws->pred_v, ws->rec_v, sizeC, qpC, ftI | 1, csplit, ws->coef_v);
+      cbp_u = code_inter_plane(t, J, ws, ou, osc, ws->pred_u, ws->rec_u, sizeC, qpC, ftI | 1, csplit, ws->coef_u);
+      cbp_v = code_inter_plane(t, J, ws, ov, osc, ws->pred_v, ws->rec_v, sizeC, qpC, ftI | 1, csplit, ws->coef_v);
     }
   }
   p.cbp_y = (uint8_t)cbp_y;
@@ -722,7 +761,8 @@ TK_DEVNI void search_bipred(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* w
   mv_t min0[4], min1[4];
   for (int i = 0; i < 4; i++) { min0[i] = mvp; min1[i] = mvp; }
   unsigned min_sad = 1u << 30;
-  const PIX* oy = J.orig.y + nd.ypos * J.orig.sy + nd.xpos;
+  const PIX* oy = ws->org_y;
+  const int osy = ws->org_sy;
   for (int n = 0; n < num_iter; n++) {
     const int stop = part == 0 ? 0 : 1;
     for (int list = 1; list >= stop; list--) {
@@ -734,7 +774,7 @@ TK_DEVNI void search_bipred(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* w
       for (int k = t.rank; k < size * size; k += t.size) {
         int i, j;
         split2(mk_pow2(size), k, i, j);
-        ws->org8[k] = (PIX)sat_pix(2 * (int)gptr(oy)[i * J.orig.sy + j] - (int)ws->pred_y[k], c.bitdepth);
+        ws->org8[k] = (PIX)sat_pix(2 * (int)oy[i * osy + j] - (int)ws->pred_y[k], c.bitdepth);
       }
       t.sync();
       int ref_start, ref_end;
@@ -771,7 +811,8 @@ TK_DEVNI unsigned intra_sad_search(const Team t, const FrameJob<PIX>& J, TeamWs<
   const int ur = upright_avail(nd.ypos, nd.xpos, size, size, c.width, kMaxSb);
   const int dl = downleft_avail(nd.ypos, nd.xpos, size, size, c.height, kMaxSb);
   const PIX* fy = J.rec.y + nd.ypos * J.rec.sy + nd.xpos;
-  const PIX* oy = J.orig.y + nd.ypos * J.orig.sy + nd.xpos;
+  const PIX* oy = ws->org_y;
+  const int osy = ws->org_sy;
   make_edges(t, ws->edgep, fy, J.rec.sy, (const PIX*)nullptr, 0, 0, 0, nd.ypos, nd.xpos, size, ur, dl, 0, bd);
   t.sync();
   unsigned min_sad = 1u << 30;
@@ -785,7 +826,7 @@ TK_DEVNI unsigned intra_sad_search(const Team t, const FrameJob<PIX>& J, TeamWs<
     for (int k = t.rank; k < size * size; k += t.size) {
       int i, j;
       split2(mk_pow2(size), k, i, j);
-      local += iabs((int)gptr(oy)[i * J.orig.sy + j] - (int)ws->pred_y[k]);
+      local += iabs((int)oy[i * osy + j] - (int)ws->pred_y[k]);
     }
     const unsigned sad = (unsigned)team_sum(t, local) >> (bd - 8);
     t.sync();
@@ -850,7 +891,7 @@ TK_DEVNI unsigned mode_decision(const Team t, const FrameJob<PIX>& J, TeamWs<PIX
       mv_t mv_center[kMaxRefs];
       mv_t mv_all[4][4];
       mv_t mvp = mk_mv(0, 0);
-      const PIX* oy = J.orig.y + nd.ypos * J.orig.sy + nd.xpos;
+      const PIX* oy = ws->org_y;
       int min_idx = 0, max_idx = J.num_ref - 1;
       {
         const int br = ws->mep->lists->best_ref;
@@ -866,7 +907,7 @@ TK_DEVNI unsigned mode_decision(const Team t, const FrameJob<PIX>& J, TeamWs<PIX
         mv_center[r] = mvp;
         unsigned sad_inter = 0xffffffffu;
         for (int part = 0; part < max_pb; part++) {
-          unsigned sad = search_inter(t, J, ws, nd.ypos, nd.xpos, size, oy, J.orig.sy, r, mv_center[r], mvp, mv_all[part], part, J.sign[r]);
+          unsigned sad = search_inter(t, J, ws, nd.ypos, nd.xpos, size, oy, ws->org_sy, r, mv_center[r], mvp, mv_all[part], part, J.sign[r]);
           add_cands4(t, ws, r, mv_all[part]);
           mv_center[r] = mv_all[0][0];
           sad_inter = sad < sad_inter ? sad : sad_inter;
@@ -922,7 +963,7 @@ TK_DEVNI unsigned mode_decision(const Team t, const FrameJob<PIX>& J, TeamWs<PIX
           const Plane3<PIX>& f0 = J.ref[ri0];
           const Plane3<PIX>& f1 = J.ref[ri1];
           MeArgs a;
-          a.cb_size = size; a.ostride = J.orig.sy; a.width = size; a.height = size; a.rstride = f0.sy; a.sign = 0;
+          a.cb_size = size; a.ostride = ws->org_sy; a.width = size; a.height = size; a.rstride = f0.sy; a.sign = 0;
           a.fwidth = c.width; a.fheight = c.height; a.xpos = nd.xpos; a.ypos = nd.ypos; a.enable_bipred = 1;
           a.bitdepth = c.bitdepth; a.lam = J.sqrt_lambda; a.speed = c.encoder_speed;
           mv_t mvb;
@@ -1056,9 +1097,9 @@ TK_DEVNI void md_item_bipred(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* 
     const int ri0 = J.interp_ref ? 1 : 0, ri1 = J.interp_ref ? 2 : 1;
     const Plane3<PIX>& f0 = J.ref[ri0];
     const Plane3<PIX>& f1 = J.ref[ri1];
-    const PIX* oy = J.orig.y + nd.ypos * J.orig.sy + nd.xpos;
+    const PIX* oy = ws->org_y;
     MeArgs a;
-    a.cb_size = size; a.ostride = J.orig.sy; a.width = size; a.height = size; a.rstride = f0.sy; a.sign = 0;
+    a.cb_size = size; a.ostride = ws->org_sy; a.width = size; a.height = size; a.rstride = f0.sy; a.sign = 0;
     a.fwidth = c.width; a.fheight = c.height; a.xpos = nd.xpos; a.ypos = nd.ypos; a.enable_bipred = 1;
     a.bitdepth = c.bitdepth; a.lam = J.sqrt_lambda; a.speed = c.encoder_speed;
     mv_t mvb;
@@ -1079,13 +1120,13 @@ TK_DEVNI void md_item_ref(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
   const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
   const int max_pb = c.enable_pb_split ? 4 : 1;
   const mv_t mvp = M.sh->mvp;
-  const PIX* oy = J.orig.y + nd.ypos * J.orig.sy + nd.xpos;
+  const PIX* oy = ws->org_y;
   if (t.rank == 0) add_mvcand(ws->mep, r, mvp);
   t.sync();
   mv_t mv_center = mvp;
   mv_t mv_all[4][4];
   for (int part = 0; part < max_pb; part++) {
-    search_inter(t, J, ws, nd.ypos, nd.xpos, size, oy, J.orig.sy, r, mv_center, mvp, mv_all[part], part, J.sign[r]);
+    search_inter(t, J, ws, nd.ypos, nd.xpos, size, oy, ws->org_sy, r, mv_center, mvp, mv_all[part], part, J.sign[r]);
     add_cands4(t, ws, r, mv_all[part]);
     mv_center = mv_all[0][0];
   }
@@ -1110,6 +1151,7 @@ TK_DEVNI void md_worker(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamW
   MdCtx<PIX> M;
   M.wg = wg; M.sh = sh; M.nd = &sh->stack[sh->node]; M.mykey = ~0ull;
   ws_select(ws, tk_uniform(M.nd->size));
+  org_select(t, J, ws, tk_uniform(M.nd->size), M.nd->ypos, M.nd->xpos, M.nd->bw, M.nd->bh, 0);
   const EncCfg& c = J.cfg;
   const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
   const int n_items = sh->n_items;
@@ -1313,12 +1355,12 @@ TK_DEVNI int check_early_skip(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>*
                        p.mv0, J.sign[p.ref0], c.width, c.height, c.enable_bipred, 0, c.bitdepth);
       }
       t.sync();
-      significant = early_skip_sub(t, J, ws, J.orig.y + sub.ypos * J.orig.sy + sub.xpos, J.orig.sy, ws->pred_y, size0,
+      significant = early_skip_sub(t, J, ws, ws->org_y + i * ws->org_sy + j, ws->org_sy, ws->pred_y, size0,
                                    size0, qpY, thr);
       if (!significant)
-        significant = early_skip_subC(t, J, ws, J.orig.u + yc * J.orig.sc + xc, J.orig.sc, ws->pred_u, size0c, size0c, qpC, thr);
+        significant = early_skip_subC(t, J, ws, ws->org_u + (i >> 1) * ws->org_sc + (j >> 1), ws->org_sc, ws->pred_u, size0c, size0c, qpC, thr);
       if (!significant)
-        significant = early_skip_subC(t, J, ws, J.orig.v + yc * J.orig.sc + xc, J.orig.sc, ws->pred_v, size0c, size0c, qpC, thr);
+        significant = early_skip_subC(t, J, ws, ws->org_v + (i >> 1) * ws->org_sc + (j >> 1), ws->org_sc, ws->pred_v, size0c, size0c, qpC, thr);
     }
   return !significant;
 }
@@ -1424,6 +1466,7 @@ TK_DEV void process_sb(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamWs
         }
       }
       t.sync();
+      org_select(t, J, ws, tk_uniform(size), ypos, xpos, tk_uniform(nd.bw), tk_uniform(nd.bh), 1);
       // ---- early skip
       if (nd.encode_this_size && J.frame_type != F_I && c.early_skip_thr > 0.0f) {
         unsigned min_cost = kCostInit;
@@ -1506,6 +1549,7 @@ TK_DEV void process_sb(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamWs
     // ---- stage 2: decide this size
     {
       ws_select(ws, tk_uniform(nd.size));
+      org_select(t, J, ws, tk_uniform(nd.size), nd.ypos, nd.xpos, tk_uniform(nd.bw), tk_uniform(nd.bh), 1);  // the children replaced the LDS copy
       unsigned cost = 1u << 28;
       if (nd.encode_this_size || nd.encode_rect) {
         if (!nd.md_done) {

@@ -72,12 +72,12 @@ TK_DEV void fwd_transform(const Team t, XformWs* ws, const PIX* org, int ostride
     split2(mk_pow2(size1), k, i, j);
     int sum = 0;
     if (scale == 1) {
-      sum = (int16_t)((int)gptr(org)[i * ostride + j] - (int)pred[i * pstride + j]);
+      sum = (int16_t)((int)org[i * ostride + j] - (int)pred[i * pstride + j]);
     } else {
       for (int m = 0; m < scale; m++)
         for (int n = 0; n < scale; n++) {
           int y = i * scale + m, x = j * scale + n;
-          int r = (int16_t)((int)gptr(org)[y * ostride + x] - (int)pred[y * pstride + x]);
+          int r = (int16_t)((int)org[y * ostride + x] - (int)pred[y * pstride + x]);
           sum = clampi((int16_t)sum + r, -16384, 16383);
         }
     }
