@@ -14,6 +14,14 @@
 #include "tk_xform.h"
 #include "tk_me.h"
 
+#if defined(THOR_PROF_NOMD)
+#define TK_MDPROF_MARK(v) do {} while (0)
+#define TK_MDPROF_ACC(ws, id, v) do {} while (0)
+#else
+#define TK_MDPROF_MARK(v) TK_PROF_MARK(v)
+#define TK_MDPROF_ACC(ws, id, v) TK_PROF_ACC(ws, id, v)
+#endif
+
 namespace tk {
 
 struct Node {
@@ -50,7 +58,14 @@ struct WgShared {
   int cmd;                       // what the parked waves do after the next workgroup barrier
   int next_item, n_items;        // work queue cursor (atomic) / length
   int refs_done, n_ref_items;    // reference searches finished (atomic) / expected; the last one triggers the bipred item
-  int do_bipred;
+  int do_bipred;                 // 0 none, 1 one item (B frames), 2 lock-step phase after the queue (P frames)
+  // bi-prediction search of P frames, run by all waves in lock step (bipred_par)
+  const void* bp_org8;           // 2*org - pred of the current step (leader's buffer)
+  unsigned bp_sad[kMaxRefs];
+  mv_t bp_mv[kMaxRefs][4];
+  unsigned bp_min_sad;
+  int bp_ref0, bp_ref1;
+  mv_t bp_min0[4], bp_min1[4];
   int node;                      // index of the node being decided in `stack`
   mv_t mvp;
   mv_t mv_center[kMaxRefs];
@@ -1144,6 +1159,73 @@ TK_DEVNI void md_item_ref(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
   }
 }
 
+// search_bipred_prediction_params (me_mode 0, PART_NONE) of a P frame with all waves in lock step.  The reference walks
+// 2 iterations x {list 1, list 0}; inside one such step it searches EVERY reference against 2*org - pred of the other
+// list and keeps the first strictly smaller SAD (encode_block.c:1770-1816).  The searches of one step are independent
+// (each touches only its own candidate list), so wave w takes reference w; the leader (wave 0) builds 2*org - pred before
+// and reduces in reference order after each step - the very scan of the reference.  Then the two trials (tb 0 / 1).
+template <typename PIX>
+TK_DEVNI void bipred_par(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, MdCtx<PIX>& M) {
+  const EncCfg& c = J.cfg;
+  WgShared* sh = M.sh;
+  Node& nd = *M.nd;
+  const int size = nd.size;
+  const int num_iter = c.encoder_speed == 0 ? 2 : 1;
+  const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
+  const mv_t mvp = sh->mvp;
+  for (int n = 0; n < num_iter; n++)
+    for (int list = 1; list >= 0; list--) {
+      if (wg.wave == 0) {
+        mv_t mo[4];
+        for (int i = 0; i < 4; i++) mo[i] = list ? sh->bp_min0[i] : sh->bp_min1[i];
+        const int ref_o = list ? sh->bp_ref0 : sh->bp_ref1;
+        pred_inter_yuv(t, J.ref[ref_o], ws->pred_y, ws->pred_u, ws->pred_v, nd.ypos, nd.xpos, size, nd.bw, nd.bh, mo, J.sign[ref_o], c.width,
+                       c.height, c.enable_bipred, 0, c.bitdepth);
+        t.sync();
+        const PIX* oy = ws->org_y;
+        const int osy = ws->org_sy;
+        for (int k = t.rank; k < size * size; k += t.size) {
+          int i, j;
+          split2(mk_pow2(size), k, i, j);
+          ws->org8[k] = (PIX)sat_pix(2 * (int)oy[i * osy + j] - (int)ws->pred_y[k], c.bitdepth);
+        }
+        if (t.rank == 0) sh->bp_org8 = ws->org8;
+        t.sync();
+      }
+      wg.barrier();
+      const PIX* org8 = (const PIX*)sh->bp_org8;
+      for (int r = wg.wave; r < J.num_ref; r += wg.nwaves) {
+        mv_t mv_all[4];
+        const unsigned sad = search_inter(t, J, ws, nd.ypos, nd.xpos, size, org8, size, r, sh->mv_center[r], mvp, mv_all, 0, J.sign[r]);
+        add_cands4(t, ws, r, mv_all);
+        if (t.rank == 0) { sh->bp_sad[r] = sad; for (int i = 0; i < 4; i++) sh->bp_mv[r][i] = mv_all[i]; }
+      }
+      t.sync();
+      wg.barrier();
+      if (wg.wave == 0) {
+        if (t.rank == 0)
+          for (int r = 0; r < J.num_ref; r++)
+            if (sh->bp_sad[r] < sh->bp_min_sad) {
+              sh->bp_min_sad = sh->bp_sad[r];
+              if (list) { sh->bp_ref1 = r; for (int i = 0; i < 4; i++) sh->bp_min1[i] = sh->bp_mv[r][i]; }
+              else { sh->bp_ref0 = r; for (int i = 0; i < 4; i++) sh->bp_min0[i] = sh->bp_mv[r][i]; }
+            }
+        t.sync();
+      }
+    }
+  wg.barrier();
+  // trials: tb 0 on wave 0, tb 1 on the next wave (each builds its own prediction)
+  for (int tb = 0; tb <= max_tb - 1; tb++)
+    if (wg.wave == tb % wg.nwaves) {
+      BlkParam p = blank_param();
+      p.mode = M_BIPRED; p.pb_part = P_NONE;
+      p.ref0 = (int8_t)sh->bp_ref0; p.ref1 = (int8_t)sh->bp_ref1;
+      for (int i = 0; i < 4; i++) { p.mv0[i] = sh->bp_min0[i]; p.mv1[i] = sh->bp_min1[i]; }
+      p.tb_param = (int8_t)tb;
+      par_trial(t, J, ws, M, p, 54u + (unsigned)tb, 0);
+    }
+}
+
 // Executed by every wave of the workgroup between the fork and the join barrier.
 template <typename PIX>
 TK_DEVNI void md_worker(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws) {
@@ -1162,7 +1244,7 @@ TK_DEVNI void md_worker(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamW
     if (i >= n_items) break;
     const MdItem it = sh->items[i];
     const int kind = team_bcast0(t, it.kind), ia = team_bcast0(t, it.a), ib = team_bcast0(t, it.b);
-    TK_PROF_MARK(pit_);
+    TK_MDPROF_MARK(pit_);
     if (kind == MD_SKIP) {
       BlkParam p = blank_param();
       set_cand(p, M.nd->skip[ia], ia, M_SKIP);
@@ -1184,15 +1266,20 @@ TK_DEVNI void md_worker(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamW
       int done = 0;
       if (t.rank == 0) done = wg_fetch_add(&sh->refs_done, 1) + 1;
       done = team_bcast0(t, done);
-      TK_PROF_ACC(ws, 27, pit_);
-      if (done == sh->n_ref_items && sh->do_bipred) {
-        TK_PROF_MARK(pbi_);
+      TK_MDPROF_ACC(ws, 27, pit_);
+      if (done == sh->n_ref_items && sh->do_bipred == 1) {
+        TK_MDPROF_MARK(pbi_);
         md_item_bipred(t, J, ws, M);
-        TK_PROF_ACC(ws, 28, pbi_);
+        TK_MDPROF_ACC(ws, 28, pbi_);
       }
     }
-    if (kind == MD_SKIP || kind == MD_MERGE) { TK_PROF_ACC(ws, 29, pit_); }
-    else if (kind == MD_INTRA) { TK_PROF_ACC(ws, 26, pit_); }
+    if (kind == MD_SKIP || kind == MD_MERGE) { TK_MDPROF_ACC(ws, 29, pit_); }
+    else if (kind == MD_INTRA) { TK_MDPROF_ACC(ws, 26, pit_); }
+  }
+  if (sh->do_bipred == 2) {  // uniform over the workgroup: every wave takes part (same number of barriers)
+    t.sync();
+    wg.barrier();            // every reference search has finished: mv_center[] and the candidate lists are final
+    bipred_par(wg, t, J, ws, M);
   }
 }
 
@@ -1203,7 +1290,11 @@ TK_DEV void wg_helper_loop(const Wg wg, const Team t, const FrameJob<PIX>& J, Te
     wg.barrier();
     const int cmd = team_bcast0(t, ws->sh->cmd);
     if (cmd == WG_CMD_EXIT) { wg.barrier(); break; }  // second barrier: every wave has read the command before the master reuses it
+#ifdef THOR_PROF_OUTER
+    { TK_PROF_MARK(pw_); md_worker(wg, t, J, ws); TK_PROF_ACC(ws, 5, pw_); }
+#else
     md_worker(wg, t, J, ws);
+#endif
     t.sync();
     wg.barrier();
   }
@@ -1233,19 +1324,25 @@ TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, const FrameJob<PI
       for (int tb = 0; tb <= max_tb - 1; tb++) push(MD_INTRA, m, tb);
     sh->n_items = n; sh->next_item = 0;
     sh->refs_done = 0; sh->n_ref_items = inter ? J.num_ref : 0;
-    sh->do_bipred = inter && J.num_ref > 1 && c.enable_bipred;
+    sh->do_bipred = (inter && J.num_ref > 1 && c.enable_bipred) ? (J.frame_type == F_P ? 2 : 1) : 0;
+    sh->bp_min_sad = 1u << 30; sh->bp_ref0 = 0; sh->bp_ref1 = 0;
+    for (int i = 0; i < 4; i++) { sh->bp_min0[i] = mvp; sh->bp_min1[i] = mvp; }
     sh->node = node; sh->mvp = mvp;
     sh->bestkey = ~0ull;
     for (int w = 0; w < kWaves; w++) sh->wkey[w] = ~0ull;
     sh->cmd = WG_CMD_MD;
   }
   t.sync();
-  TK_PROF_MARK(ppar_);
+  TK_MDPROF_MARK(ppar_);
   wg.barrier();   // fork
+#ifdef THOR_PROF_OUTER
+  { TK_PROF_MARK(pw_); md_worker(wg, t, J, ws); TK_PROF_ACC(ws, 5, pw_); t.sync(); wg.barrier(); TK_PROF_ACC(ws, 29, pw_); }
+#else
   md_worker(wg, t, J, ws);
   t.sync();
   wg.barrier();   // join
-  TK_PROF_ACC(ws, 5, ppar_);  // wall cycles of the parallel region (x kWaves = wave-cycles available to the items)
+#endif
+  TK_MDPROF_ACC(ws, 5, ppar_);  // wall cycles of the parallel region (x kWaves = wave-cycles available to the items)
   unsigned long long best = ~0ull;
   int bw = 0;
   for (int w = 0; w < wg.nwaves; w++) {

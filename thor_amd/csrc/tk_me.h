@@ -366,7 +366,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
     x.p = ref + (s * (x.mv.y >> 2)) * a.rstride + s * (x.mv.x >> 2);
     return x;
   };
-#if defined(THOR_PROF) && !TK_HOST
+#if defined(THOR_PROF) && !TK_HOST && !defined(THOR_PROF_NOMACROS)
   long long pq_ = (long long)__builtin_readcyclecounter();
   if (t.rank == 0) w->prof[11] += 1;
 #endif
@@ -429,7 +429,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
     mv_ref = mv_opt;
   }
 
-#if defined(THOR_PROF) && !TK_HOST
+#if defined(THOR_PROF) && !TK_HOST && !defined(THOR_PROF_NOMACROS)
   if (t.rank == 0) w->prof[13] += (long long)__builtin_readcyclecounter() - pq_;
   pq_ = (long long)__builtin_readcyclecounter();
 #endif
@@ -457,7 +457,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
     mv_ref = mv_opt;
   }
 
-#if defined(THOR_PROF) && !TK_HOST
+#if defined(THOR_PROF) && !TK_HOST && !defined(THOR_PROF_NOMACROS)
   if (t.rank == 0) w->prof[14] += (long long)__builtin_readcyclecounter() - pq_;
   pq_ = (long long)__builtin_readcyclecounter();
 #endif
@@ -486,12 +486,12 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
     }
   }
 
-#if defined(THOR_PROF) && !TK_HOST
+#if defined(THOR_PROF) && !TK_HOST && !defined(THOR_PROF_NOMACROS)
   if (t.rank == 0) w->prof[15] += (long long)__builtin_readcyclecounter() - pq_;
 #endif
   TK_PROF_ADD(w, 2);
   // --- half-pel then quarter-pel (encode_block.c:628-663)
-#if defined(THOR_PROF) && !TK_HOST
+#if defined(THOR_PROF) && !TK_HOST && !defined(THOR_PROF_NOMACROS)
   pt0_ = (long long)__builtin_readcyclecounter();
 #endif
   unsigned cmin = min_sad;

@@ -8,11 +8,16 @@
 #include "tk_common.h"
 
 #ifndef TK_PROF_T0
-#if defined(THOR_PROF) && !TK_HOST
-#define TK_PROF_T0() long long pt0_ = (long long)__builtin_readcyclecounter()
-#define TK_PROF_ADD(ws, id) do { if (t.rank == 0) (ws)->prof[id] += (long long)__builtin_readcyclecounter() - pt0_; } while (0)
-#define TK_PROF_MARK(v) long long v = (long long)__builtin_readcyclecounter()
-#define TK_PROF_ACC(ws, id, v) do { if (t.rank == 0) (ws)->prof[id] += (long long)__builtin_readcyclecounter() - (v); } while (0)
+#if defined(THOR_PROF) && !TK_HOST && !defined(THOR_PROF_NOMACROS)
+#ifdef THOR_PROF_WALL
+#define TK_CYC() ((long long)wall_clock64())
+#else
+#define TK_CYC() ((long long)__builtin_readcyclecounter())
+#endif
+#define TK_PROF_T0() long long pt0_ = TK_CYC()
+#define TK_PROF_ADD(ws, id) do { if (t.rank == 0) (ws)->prof[id] += TK_CYC() - pt0_; } while (0)
+#define TK_PROF_MARK(v) long long v = TK_CYC()
+#define TK_PROF_ACC(ws, id, v) do { if (t.rank == 0) (ws)->prof[id] += TK_CYC() - (v); } while (0)
 #define TK_PROF_CNT(ws, id) do { if (t.rank == 0) (ws)->prof[id] += 1; } while (0)
 #else
 #define TK_PROF_T0() do {} while (0)
