@@ -173,6 +173,9 @@ template <typename PIX> TK_DEV TeamWs<PIX> make_ws(SmallWs<PIX>* s, WgShared* sh
   TeamWs<PIX> w;
   w.xfp = &s->xf; w.mep = &s->me; w.edgep = &s->edge;
   w.sh = sh; s->xf.tabs = &sh->tabs; s->me.lists = &sh->lists;
+  // the search window lives in the transform workspace (in | tmp | coef: 3584 contiguous bytes), idle during a motion search
+  static_assert(offsetof(XformWs, flag) - offsetof(XformWs, in) >= (size_t)kMeWinBytes + 4, "search window does not fit the transform workspace");
+  s->me.win = sizeof(PIX) == 1 ? (uint32_t*)s->xf.in : nullptr;
   w.coef_y = s->coef_y; w.coef_u = s->coef_u; w.coef_v = s->coef_v;
   w.coef_u_small = s->coef_u; w.coef_v_small = s->coef_v; w.coef_u_big = g->coef_u_big; w.coef_v_big = g->coef_v_big;
   w.acc = s->acc; w.stack = sh->stack; w.prof = s->prof;
@@ -728,13 +731,14 @@ TK_DEV unsigned search_inter(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* 
   unsigned sad = 0;
   mv_t mv, mvp2 = mvp;
   if (part == P_NONE) {
-    a.width = size; a.height = size;
+    a.width = size; a.height = size; a.pu_x = xpos; a.pu_y = ypos;
     sad += motion_estimate(t, ws->mep, org, ref_y, a, mvc, mvp2, ref_idx, &mv);
     mv_arr[0] = mv_arr[1] = mv_arr[2] = mv_arr[3] = mv;
   } else if (part == P_HOR) {
     a.width = size; a.height = size / 2;
     for (int index = 0; index < 4; index += 2) {
       int py = index >> 1;
+      a.pu_x = xpos; a.pu_y = ypos + py * (size / 2);
       sad += motion_estimate(t, ws->mep, org + py * (size / 2) * ostride, ref_y + py * (size / 2) * ref.sy, a, mvc, mvp2, ref_idx, &mv);
       mv_arr[index] = mv; mv_arr[index + 1] = mv;
       mvp2 = mv_arr[0];
@@ -742,6 +746,7 @@ TK_DEV unsigned search_inter(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* 
   } else if (part == P_VER) {
     a.width = size / 2; a.height = size;
     for (int index = 0; index < 2; index++) {
+      a.pu_x = xpos + index * (size / 2); a.pu_y = ypos;
       sad += motion_estimate(t, ws->mep, org + index * (size / 2), ref_y + index * (size / 2), a, mvc, mvp2, ref_idx, &mv);
       mv_arr[index] = mv; mv_arr[index + 2] = mv;
       mvp2 = mv_arr[0];
@@ -750,6 +755,7 @@ TK_DEV unsigned search_inter(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* 
     a.width = size / 2; a.height = size / 2;
     for (int index = 0; index < 4; index++) {
       int px = index & 1, py = index >> 1;
+      a.pu_x = xpos + px * (size / 2); a.pu_y = ypos + py * (size / 2);
       sad += motion_estimate(t, ws->mep, org + py * (size / 2) * ostride + px * (size / 2),
                              ref_y + py * (size / 2) * ref.sy + px * (size / 2), a, mvc, mvp2, ref_idx, &mv);
       mv_arr[index] = mv;
@@ -980,7 +986,7 @@ TK_DEVNI unsigned mode_decision(const Team t, const FrameJob<PIX>& J, TeamWs<PIX
           MeArgs a;
           a.cb_size = size; a.ostride = ws->org_sy; a.width = size; a.height = size; a.rstride = f0.sy; a.sign = 0;
           a.fwidth = c.width; a.fheight = c.height; a.xpos = nd.xpos; a.ypos = nd.ypos; a.enable_bipred = 1;
-          a.bitdepth = c.bitdepth; a.lam = J.sqrt_lambda; a.speed = c.encoder_speed;
+          a.bitdepth = c.bitdepth; a.lam = J.sqrt_lambda; a.speed = c.encoder_speed; a.pu_x = nd.xpos; a.pu_y = nd.ypos;
           mv_t mvb;
           motion_estimate_bi(t, ws->mep, oy, f0.y + nd.ypos * f0.sy + nd.xpos, f1.y + nd.ypos * f1.sy + nd.xpos, a, mv_center[ri0],
                              mvp, ri0, &mvb);
@@ -1116,7 +1122,7 @@ TK_DEVNI void md_item_bipred(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* 
     MeArgs a;
     a.cb_size = size; a.ostride = ws->org_sy; a.width = size; a.height = size; a.rstride = f0.sy; a.sign = 0;
     a.fwidth = c.width; a.fheight = c.height; a.xpos = nd.xpos; a.ypos = nd.ypos; a.enable_bipred = 1;
-    a.bitdepth = c.bitdepth; a.lam = J.sqrt_lambda; a.speed = c.encoder_speed;
+    a.bitdepth = c.bitdepth; a.lam = J.sqrt_lambda; a.speed = c.encoder_speed; a.pu_x = nd.xpos; a.pu_y = nd.ypos;
     mv_t mvb;
     motion_estimate_bi(t, ws->mep, oy, f0.y + nd.ypos * f0.sy + nd.xpos, f1.y + nd.ypos * f1.sy + nd.xpos, a, mv_center[ri0], mvp, ri0, &mvb);
     p.mode = M_BIPRED; p.pb_part = P_NONE;

@@ -27,7 +27,32 @@ struct MeWs {  // per wavefront
   mv_t cmv[64];
   MeLists* lists;
   long long* prof;
+  // LDS search window of the full-pel search (8-bit samples, coding blocks up to 16x16): kMeWinBytes of per-wave LDS
+  // that nothing else uses during a motion search (it aliases the transform workspace, see make_ws); nullptr: off
+  uint32_t* win;
 };
+enum { kMeWinR = 20, kMeWinMaxCb = 16, kMeWinBytes = (kMeWinMaxCb + 2 * kMeWinR) * (kMeWinMaxCb + 2 * kMeWinR) };
+#ifndef TK_ME_WINDOW
+#define TK_ME_WINDOW 1
+#endif
+// The window: Ww x Wh samples of the reference plane around the search centre, row pitch Ww bytes (a multiple of 4),
+// origin (ox, oy) relative to the PU's co-located reference position.
+struct MeWin {
+  const uint32_t* w32;
+  int ox, oy, Ww, Wh;
+  int on;
+};
+// 4 samples at byte offset `off` of the window (any alignment): two aligned dwords + v_alignbyte
+TK_DEV uint32_t win_ld4(const uint32_t* w32, int off) {
+#if TK_HOST
+  const uint32_t lo = w32[off >> 2], hi = w32[(off >> 2) + 1];
+  return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * (off & 3)));
+#else
+  const TK_LDS uint32_t* l = (const TK_LDS uint32_t*)w32;
+  const uint32_t lo = l[off >> 2], hi = l[(off >> 2) + 1];
+  return __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(off & 3));
+#endif
+}
 
 TK_DEV int mv_len1(int a) {
   a = iabs(a);
@@ -161,7 +186,7 @@ template <> __device__ __forceinline__ int sad4v<uint8_t>(const Px4<uint8_t>& a,
 // cand(c) -> {clipped mv, pointer to the displaced reference block}; returns min (cost<<32 | index).
 template <typename PIX, class CandF, class CostF>
 TK_DEV unsigned long long eval_fullpel(const Team t, int n, const PIX* org, int ostride, int rstride, int width, int height,
-                                       CandF cand, CostF cost) {
+                                       CandF cand, CostF cost, const MeWin& win) {
   const int gpr = width >> 2, lg = ilog2((unsigned)gpr), nit = height * gpr;
   int G = nit >> 4;
   if (G < 1) G = 1;
@@ -191,6 +216,45 @@ TK_DEV unsigned long long eval_fullpel(const Team t, int n, const PIX* org, int 
     auto xa = cand(va ? ca : 0);
     auto xb = cand(vb ? cb : 0);
     int sa = 0, sb = 0;
+    // LDS path when EVERY candidate block of this pass lies inside the staged window (wave-uniform decision)
+    int use_win = 0;
+    if (sizeof(PIX) == 1 && win.on) {
+      const int ina = xa.dx >= win.ox && xa.dx + width <= win.ox + win.Ww && xa.dy >= win.oy && xa.dy + height <= win.oy + win.Wh;
+      const int inb = xb.dx >= win.ox && xb.dx + width <= win.ox + win.Ww && xb.dy >= win.oy && xb.dy + height <= win.oy + win.Wh;
+      use_win = team_ballot(t, (va && !ina) || (vb && !inb)) == 0ull;
+#if TK_HOST && defined(THOR_WIN_STAT)
+      { extern long long g_win_stat[2]; g_win_stat[use_win ? 1 : 0]++; }
+#endif
+    }
+    if (use_win) {
+      if constexpr (sizeof(PIX) == 1) {
+        if (va) {
+          const int ba = (xa.dy - win.oy) * win.Ww + (xa.dx - win.ox), bb = (xb.dy - win.oy) * win.Ww + (xb.dx - win.ox);
+          for (int k0 = 0; k0 < ipl; k0 += 16) {
+            const int cnt = ipl - k0 < 16 ? ipl - k0 : 16;
+#if !TK_HOST
+#pragma unroll
+#endif
+            for (int k = 0; k < 16; k++)
+              if (k < cnt) {
+                const int r = sub + (k0 + k) * G, i = r >> lg, g = r & (gpr - 1);
+                if (!hoist) o[k] = ld4(org + i * ostride + 4 * g);
+                uint32_t ov;
+                __builtin_memcpy(&ov, &o[k], 4);
+                const int off = i * win.Ww + 4 * g;
+#if TK_HOST
+                auto sad32 = [](uint32_t x, uint32_t y) { int s2 = 0; for (int q = 0; q < 4; q++) s2 += iabs((int)((x >> (8 * q)) & 255u) - (int)((y >> (8 * q)) & 255u)); return s2; };
+                sa += sad32(ov, win_ld4(win.w32, ba + off));
+                if (vb) sb += sad32(ov, win_ld4(win.w32, bb + off));
+#else
+                sa = (int)__builtin_amdgcn_sad_u8(ov, win_ld4(win.w32, ba + off), (unsigned)sa);
+                if (vb) sb = (int)__builtin_amdgcn_sad_u8(ov, win_ld4(win.w32, bb + off), (unsigned)sb);
+#endif
+              }
+          }
+        }
+      }
+    } else
     if (va) {
       for (int k0 = 0; k0 < ipl; k0 += 16) {
         const int cnt = ipl - k0 < 16 ? ipl - k0 : 16;
@@ -230,6 +294,7 @@ struct MeArgs {
   int width, height;     // PU dims
   int rstride;
   int sign, fwidth, fheight, xpos, ypos;  // CB position (Appendix B.16)
+  int pu_x, pu_y;        // PU position (absolute, luma samples): only the LDS search window needs it
   int enable_bipred, bitdepth;
   int speed;             // encoder_speed (0 slow .. 2 fast)
   double lam;            // sqrt(lambda)
@@ -339,6 +404,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
   a_u.fwidth = tk_uniform(a_in.fwidth); a_u.fheight = tk_uniform(a_in.fheight); a_u.xpos = tk_uniform(a_in.xpos);
   a_u.ypos = tk_uniform(a_in.ypos); a_u.enable_bipred = tk_uniform(a_in.enable_bipred); a_u.bitdepth = tk_uniform(a_in.bitdepth);
   a_u.speed = tk_uniform(a_in.speed); a_u.lam = tk_uniform_f64(a_in.lam);
+  a_u.pu_x = tk_uniform(a_in.pu_x); a_u.pu_y = tk_uniform(a_in.pu_y);
   const MeArgs& a = a_u;
   mvc = mk_mv(tk_uniform(mvc.x), tk_uniform(mvc.y));
   mvp = mk_mv(tk_uniform(mvp.x), tk_uniform(mvp.y));
@@ -356,14 +422,16 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
     return ref + (s * (m.y >> 2)) * a.rstride + s * (m.x >> 2);
   };
 
-  struct FP { mv_t mv; const PIX* p; };
+  struct FP { mv_t mv; const PIX* p; int dx, dy; };
   auto fp_cost = [&](const FP& x, int sad) -> unsigned {
     return ((unsigned)sad >> sh) + mv_cost(a.lam, x.mv.y - mvp.y, x.mv.x - mvp.x);
   };
   auto mk_fp = [&](mv_t mv) -> FP {
     FP x;
     x.mv = clip_mv(mv, a.ypos, a.xpos, a.fwidth, a.fheight, a.cb_size, a.cb_size, a.sign);
-    x.p = ref + (s * (x.mv.y >> 2)) * a.rstride + s * (x.mv.x >> 2);
+    x.dx = s * (x.mv.x >> 2);
+    x.dy = s * (x.mv.y >> 2);
+    x.p = ref + x.dy * a.rstride + x.dx;
     return x;
   };
 #if defined(THOR_PROF) && !TK_HOST && !defined(THOR_PROF_NOMACROS)
@@ -405,6 +473,35 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
     }
     return bestk;
   };
+  // --- stage the search window in LDS: rows of Ww bytes read with coalesced dword loads (clamped into the padded plane;
+  // clamped cells are never part of a candidate block, which clip_mv keeps inside frame +-144)
+  MeWin win;
+  win.on = 0; win.w32 = nullptr; win.ox = win.oy = win.Ww = win.Wh = 0;
+#if TK_ME_WINDOW
+  if constexpr (sizeof(PIX) == 1) {
+    if (w->win && a.cb_size <= kMeWinMaxCb && a.speed == 0) {
+      win.Ww = a.width + 2 * kMeWinR; win.Wh = a.height + 2 * kMeWinR;
+      win.ox = s * (mv_ref.x >> 2) - kMeWinR; win.oy = s * (mv_ref.y >> 2) - kMeWinR;
+      win.w32 = w->win;
+      win.on = 1;
+      const int wpr = win.Ww >> 2, total = wpr * win.Wh;
+      t.sync();
+      for (int k = t.rank; k < total; k += t.size) {
+        const int row = k / wpr, c4 = k - row * wpr;
+        const int ay = clampi(a.pu_y + win.oy + row, -kPadY, a.fheight + kPadY - 1) - a.pu_y;
+        const int ax = clampi(a.pu_x + win.ox + 4 * c4, -kPadY, a.fwidth + kPadY - 4) - a.pu_x;
+#if TK_HOST
+        uint32_t v;
+        __builtin_memcpy(&v, ref + ay * a.rstride + ax, 4);
+        w->win[k] = v;
+#else
+        ((TK_LDS uint32_t*)w->win)[k] = gload32(ref + ay * a.rstride + ax);
+#endif
+      }
+      t.sync();
+    }
+  }
+#endif
   // --- telescope (encode_block.c:529-561); encoder_speed > 0 keeps it only for 16x16 CBs with bipred on
   if ((a.cb_size == 16 && a.enable_bipred) || a.speed == 0)
   for (int step = 32; step >= 4; step >>= 1) {
@@ -423,7 +520,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
       if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = w->cmv[(int)(unsigned)k]; }
       t.sync();
     } else {
-      unsigned long long k = eval_fullpel(t, n, org, a.ostride, a.rstride, a.width, a.height, tele, fp_cost);
+      unsigned long long k = eval_fullpel(t, n, org, a.ostride, a.rstride, a.width, a.height, tele, fp_cost, win);
       if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = tele((int)(unsigned)k).mv; }
     }
     mv_ref = mv_opt;
@@ -449,7 +546,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
         t.sync();
       } else {
         auto cl = [&](int c) -> FP { return mk_fp(w->cmv[c]); };  // cmv already clipped: clip_mv is idempotent
-        unsigned long long k = eval_fullpel(t, n, org, a.ostride, a.rstride, a.width, a.height, cl, fp_cost);
+        unsigned long long k = eval_fullpel(t, n, org, a.ostride, a.rstride, a.width, a.height, cl, fp_cost, win);
         if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = w->cmv[(int)(unsigned)k]; }
         t.sync();
       }
@@ -475,7 +572,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
         return mk_fp(mk_mv(centre.x + ox * 4, centre.y + oy * 4));
       };
       int which = -1;
-      unsigned long long k = eval_fullpel(t, n, org, a.ostride, a.rstride, a.width, a.height, hex, fp_cost);
+      unsigned long long k = eval_fullpel(t, n, org, a.ostride, a.rstride, a.width, a.height, hex, fp_cost, win);
       if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); which = (int)(unsigned)k; mv_opt = hex(which).mv; }
       int best_dir = which < 0 ? -1 : (start + which) % 6;
       mv_ref = mv_opt;
