@@ -32,8 +32,10 @@ struct MeWs {  // per wavefront
   uint32_t* win;
 };
 enum { kMeWinR = 20, kMeWinMaxCb = 16, kMeWinBytes = (kMeWinMaxCb + 2 * kMeWinR) * (kMeWinMaxCb + 2 * kMeWinR) };
+// Off by default: measured 9 % SLOWER than the gather path on the MI355X (profiles/r02_ab_variants.md) although it is
+// bit-exact there (the full -m gpu suite passed with it); -DTK_ME_WINDOW=1 builds it.
 #ifndef TK_ME_WINDOW
-#define TK_ME_WINDOW 1
+#define TK_ME_WINDOW 0
 #endif
 // The window: Ww x Wh samples of the reference plane around the search centre, row pitch Ww bytes (a multiple of 4),
 // origin (ox, oy) relative to the PU's co-located reference position.
