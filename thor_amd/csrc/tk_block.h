@@ -64,6 +64,7 @@ struct WgShared {
   unsigned bp_sad[kMaxRefs];
   mv_t bp_mv[kMaxRefs][4];
   unsigned bp_min_sad;
+  int bp_skip[4];                // per step: its inputs equal those of the previous step of the same list (see bipred_par)
   int bp_ref0, bp_ref1;
   mv_t bp_min0[4], bp_min1[4];
   int node;                      // index of the node being decided in `stack`
@@ -784,11 +785,27 @@ TK_DEVNI void search_bipred(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* w
   unsigned min_sad = 1u << 30;
   const PIX* oy = ws->org_y;
   const int osy = ws->org_sy;
+  // a step whose inputs equal those of the previous step of the same list changes nothing (see bipred_par): skipped
+  int prev_ref[2] = {-1, -1}, prev_cnt[2][kMaxRefs];
+  mv_t prev_mv[2][4];
   for (int n = 0; n < num_iter; n++) {
     const int stop = part == 0 ? 0 : 1;
     for (int list = 1; list >= stop; list--) {
       mv_t mvo = list ? min0[0] : min1[0];
       int ref_o = list ? min_ref0 : min_ref1;
+      {
+        const mv_t* mo = list ? min0 : min1;
+        int same = n > 0 && prev_ref[list] == ref_o;
+        for (int i = 0; i < 4; i++) same = same && prev_mv[list][i].x == mo[i].x && prev_mv[list][i].y == mo[i].y;
+        for (int r = 0; r < J.num_ref; r++) {
+          const int cnt = ws->mep->lists->mvcand_num[r];
+          same = same && prev_cnt[list][r] == cnt;
+          prev_cnt[list][r] = cnt;
+        }
+        prev_ref[list] = ref_o;
+        for (int i = 0; i < 4; i++) prev_mv[list][i] = mo[i];
+        if (tk_uniform(same)) continue;
+      }
       pred_inter_yuv(t, J.ref[ref_o], ws->pred_y, ws->pred_u, ws->pred_v, nd.ypos, nd.xpos, size, nd.bw, nd.bh,
                      list ? min0 : min1, J.sign[ref_o], c.width, c.height, c.enable_bipred, part > 0, c.bitdepth);
       t.sync();
@@ -1179,26 +1196,47 @@ TK_DEVNI void bipred_par(const Wg wg, const Team t, const FrameJob<PIX>& J, Team
   const int num_iter = c.encoder_speed == 0 ? 2 : 1;
   const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
   const mv_t mvp = sh->mvp;
+  // A step whose inputs - reference and vector of the other list, hence 2*org - pred; and the candidate list of every
+  // reference - equal those of the previous step of the same list finds the same SADs again, none of which is below
+  // min_sad any more (the earlier step left min_sad <= all of them): it changes nothing and is skipped (about a third of
+  // all steps on typical content).  Exact, not a heuristic.
+  int prev_ref[2] = {-1, -1}, prev_cnt[2][kMaxRefs];
+  mv_t prev_mv[2][4];
   for (int n = 0; n < num_iter; n++)
     for (int list = 1; list >= 0; list--) {
+      const int step = 2 * n + (1 - list);
       if (wg.wave == 0) {
         mv_t mo[4];
         for (int i = 0; i < 4; i++) mo[i] = list ? sh->bp_min0[i] : sh->bp_min1[i];
         const int ref_o = list ? sh->bp_ref0 : sh->bp_ref1;
-        pred_inter_yuv(t, J.ref[ref_o], ws->pred_y, ws->pred_u, ws->pred_v, nd.ypos, nd.xpos, size, nd.bw, nd.bh, mo, J.sign[ref_o], c.width,
-                       c.height, c.enable_bipred, 0, c.bitdepth);
-        t.sync();
-        const PIX* oy = ws->org_y;
-        const int osy = ws->org_sy;
-        for (int k = t.rank; k < size * size; k += t.size) {
-          int i, j;
-          split2(mk_pow2(size), k, i, j);
-          ws->org8[k] = (PIX)sat_pix(2 * (int)oy[i * osy + j] - (int)ws->pred_y[k], c.bitdepth);
+        int same = n > 0 && prev_ref[list] == ref_o;
+        for (int i = 0; i < 4; i++) same = same && prev_mv[list][i].x == mo[i].x && prev_mv[list][i].y == mo[i].y;
+        for (int r = 0; r < J.num_ref; r++) {
+          const int cnt = ws->mep->lists->mvcand_num[r];
+          same = same && prev_cnt[list][r] == cnt;
+          prev_cnt[list][r] = cnt;
         }
-        if (t.rank == 0) sh->bp_org8 = ws->org8;
+        prev_ref[list] = ref_o;
+        for (int i = 0; i < 4; i++) prev_mv[list][i] = mo[i];
+        same = tk_uniform(same);
+        if (t.rank == 0) sh->bp_skip[step] = same;
+        if (!same) {
+          pred_inter_yuv(t, J.ref[ref_o], ws->pred_y, ws->pred_u, ws->pred_v, nd.ypos, nd.xpos, size, nd.bw, nd.bh, mo, J.sign[ref_o], c.width,
+                         c.height, c.enable_bipred, 0, c.bitdepth);
+          t.sync();
+          const PIX* oy = ws->org_y;
+          const int osy = ws->org_sy;
+          for (int k = t.rank; k < size * size; k += t.size) {
+            int i, j;
+            split2(mk_pow2(size), k, i, j);
+            ws->org8[k] = (PIX)sat_pix(2 * (int)oy[i * osy + j] - (int)ws->pred_y[k], c.bitdepth);
+          }
+          if (t.rank == 0) sh->bp_org8 = ws->org8;
+        }
         t.sync();
       }
       wg.barrier();
+      if (team_bcast0(t, sh->bp_skip[step])) continue;  // uniform over the workgroup
       const PIX* org8 = (const PIX*)sh->bp_org8;
       for (int r = wg.wave; r < J.num_ref; r += wg.nwaves) {
         mv_t mv_all[4];
