@@ -1173,6 +1173,17 @@ TK_DEVNI void md_item_ref(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
   p.mode = M_INTER;
   p.ref0 = p.ref1 = (int8_t)r;
   for (int part = 0; part < max_pb; part++) {
+    // With enable_pb_split every inter trial predicts the four quadrants with mv0[0..3] whatever the partition, so a
+    // partition whose quadrant vectors equal those of an EARLIER partition has the same prediction, residual, SSD and
+    // coefficient bits as that one and strictly more header bits (longer partition code, more vector differences): its
+    // cost is not smaller and its evaluation order is later - it can never be selected.  Skipped (exact).
+    int dup = 0;
+    for (int q = 0; q < part && c.enable_pb_split; q++) {
+      int eq = 1;
+      for (int i = 0; i < 4; i++) eq = eq && mv_all[q][i].x == mv_all[part][i].x && mv_all[q][i].y == mv_all[part][i].y;
+      dup = dup || eq;
+    }
+    if (tk_uniform(dup)) continue;
     p.pb_part = (int8_t)part;
     for (int i = 0; i < 4; i++) { p.mv0[i] = mv_all[part][i]; p.mv1[i] = mv_all[part][i]; }
     for (int tb = -1; tb <= max_tb - 1; tb++) {
