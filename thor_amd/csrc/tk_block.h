@@ -14,13 +14,6 @@
 #include "tk_xform.h"
 #include "tk_me.h"
 
-#if defined(THOR_PROF_NOMD)
-#define TK_MDPROF_MARK(v) do {} while (0)
-#define TK_MDPROF_ACC(ws, id, v) do {} while (0)
-#else
-#define TK_MDPROF_MARK(v) TK_PROF_MARK(v)
-#define TK_MDPROF_ACC(ws, id, v) TK_PROF_ACC(ws, id, v)
-#endif
 
 namespace tk {
 
@@ -1299,7 +1292,6 @@ TK_DEVNI void md_worker(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamW
     if (i >= n_items) break;
     const MdItem it = sh->items[i];
     const int kind = team_bcast0(t, it.kind), ia = team_bcast0(t, it.a), ib = team_bcast0(t, it.b);
-    TK_MDPROF_MARK(pit_);
     if (kind == MD_SKIP) {
       BlkParam p = blank_param();
       set_cand(p, M.nd->skip[ia], ia, M_SKIP);
@@ -1321,15 +1313,10 @@ TK_DEVNI void md_worker(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamW
       int done = 0;
       if (t.rank == 0) done = wg_fetch_add(&sh->refs_done, 1) + 1;
       done = team_bcast0(t, done);
-      TK_MDPROF_ACC(ws, 27, pit_);
       if (done == sh->n_ref_items && sh->do_bipred == 1) {
-        TK_MDPROF_MARK(pbi_);
         md_item_bipred(t, J, ws, M);
-        TK_MDPROF_ACC(ws, 28, pbi_);
       }
     }
-    if (kind == MD_SKIP || kind == MD_MERGE) { TK_MDPROF_ACC(ws, 29, pit_); }
-    else if (kind == MD_INTRA) { TK_MDPROF_ACC(ws, 26, pit_); }
   }
   if (sh->do_bipred == 2) {  // uniform over the workgroup: every wave takes part (same number of barriers)
     t.sync();
@@ -1345,7 +1332,7 @@ TK_DEV void wg_helper_loop(const Wg wg, const Team t, const FrameJob<PIX>& J, Te
     wg.barrier();
     const int cmd = team_bcast0(t, ws->sh->cmd);
     if (cmd == WG_CMD_EXIT) { wg.barrier(); break; }  // second barrier: every wave has read the command before the master reuses it
-#ifdef THOR_PROF_OUTER
+#ifdef THOR_PROF
     { TK_PROF_MARK(pw_); md_worker(wg, t, J, ws); TK_PROF_ACC(ws, 5, pw_); }
 #else
     md_worker(wg, t, J, ws);
@@ -1388,16 +1375,14 @@ TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, const FrameJob<PI
     sh->cmd = WG_CMD_MD;
   }
   t.sync();
-  TK_MDPROF_MARK(ppar_);
   wg.barrier();   // fork
-#ifdef THOR_PROF_OUTER
+#ifdef THOR_PROF
   { TK_PROF_MARK(pw_); md_worker(wg, t, J, ws); TK_PROF_ACC(ws, 5, pw_); t.sync(); wg.barrier(); TK_PROF_ACC(ws, 29, pw_); }
 #else
   md_worker(wg, t, J, ws);
   t.sync();
   wg.barrier();   // join
 #endif
-  TK_MDPROF_ACC(ws, 5, ppar_);  // wall cycles of the parallel region (x kWaves = wave-cycles available to the items)
   unsigned long long best = ~0ull;
   int bw = 0;
   for (int w = 0; w < wg.nwaves; w++) {

@@ -93,9 +93,9 @@ int main(int argc, char** argv) {
   fprintf(stdout, "thorenc_hip: %d stream(s) x %d frame(s) %dx%d: encode %.3f s (%.3f Mpx/s), total %.3f s; superblock kernels %.1f ms in %ld launches, filters %.1f ms\n",
           S, n, p.width, p.height, tenc, mpx / tenc, now_s() - t0, sb_ms, launches, filt_ms);
   if (getenv("THOR_PROF")) {
-    static const char* nm[32] = {"sb_total", "early_skip", "me_fullpel", "me_subpel", "pred_inter", "md_par_wall", "code_tu", "bits", "cost", "final", "subpel_loop",
+    static const char* nm[32] = {"sb_total", "early_skip", "me_fullpel", "me_subpel", "pred_inter", "md_worker_all_waves", "code_tu", "bits", "cost", "final", "subpel_loop",
                                  "me_calls(n)", "quant", "me_telescope", "me_cands", "me_hex", "tu4", "tu8", "tu16", "tu32", "tu64+",
-                                 "tu4(n)", "tu8(n)", "tu16(n)", "tu32(n)", "tu64+(n)", "md_intra", "md_uni_inter", "md_bipred", "md_skip_merge", "tu_fwd", "tu_inv"};
+                                 "tu4(n)", "tu8(n)", "tu16(n)", "tu32(n)", "tu64+(n)", "md_intra(serial)", "md_uni_inter(serial)", "md_bipred(serial)", "md_fork_to_join(master)", "tu_fwd", "tu_inv"};
     long long pr[32];
     thor_hip_read_prof(e, pr);
     for (int k = 0; k < 32; k++) fprintf(stdout, "prof %-14s %16lld %6.2f%%\n", nm[k], pr[k], pr[0] ? 100.0 * pr[k] / pr[0] : 0.0);
