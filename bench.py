@@ -381,6 +381,7 @@ def main():
         print(json.dumps(out), flush=True)
     enc.close()
     if dist is not None:
+        dist.barrier()   # the other ranks wait here while rank 0 runs the CPU legs (reference runs) above
         dist.destroy_process_group()
     if rc:
         sys.exit(rc)
