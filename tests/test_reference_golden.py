@@ -60,6 +60,17 @@ def test_engine_multi_wave_host_simulation_matches_golden(name):
 
 
 @needs_ref
+def test_multi_wave_host_simulation_416x240_four_references_vs_live_reference():
+    """416x240 LDB_high_efficiency, I + 5 P (the last two P frames search 4 references): the regime bench.py times - lock-step
+    bi-prediction search over 4 references with skipped repeat steps, duplicate-partition skipping, key-based pruning - in the
+    4-wave host simulation against a live run of the reference."""
+    clip = golden_clip('gen:416,240,6,2,2.0')
+    rb, rr = run_encoder(REF_ENC, clip, 416, 240, 6, 32)
+    bits, rec = run_encoder(build_hostsim(waves=4), clip, 416, 240, 6, 32)
+    assert bits == rb and rec == rr
+
+
+@needs_ref
 def test_host_simulation_two_random_access_streams_equal_reference_chunks():
     """Two closed RA streams (hierarchical B + interpolated references, host-threaded interpolation) in lock step ==
     the reference run on each chunk with -skip/-n."""
