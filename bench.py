@@ -4,23 +4,29 @@
 
 Workload ("step"): one lock-step frame of S independent closed streams (sequence chunks - the only partition of this
 path that is bit-exact, SURVEY.md 8e: stream s is exactly what the reference produces with -skip/-n for its chunk).
-Warm-up steps include each stream's I frame; the timed K steps are the following P frames.  Defaults: warm-up 1 (the I
-frame) + 4 timed P frames, the last of which searches all 4 reference frames of the operating point; the driver's
-`--steps 20 --warmup 5` times P frames 5..24, all with 4 references + bi-prediction.  Inputs are resident in HBM before
-the timed region: rank 0 generates the seeded clip, broadcasts it over RCCL (world > 1) and every rank cuts its chunks'
-frames out of it ON THE GPU (torch ops) and hands them to the encoder device-to-device.
+Warm-up steps include each stream's I frame; the timed K steps are the following frames in coding order.  Defaults:
+warm-up 1 (the I frame) + 4 timed P frames, the last of which searches all 4 reference frames of the operating point; the
+driver's `--steps 20 --warmup 5` times P frames 5..24, all with 4 references + bi-prediction.  Inputs are resident in HBM
+before the timed region: every rank generates the seeded clip, cuts its chunks' frames out of it ON THE GPU (torch ops)
+and hands them to the encoder device-to-device.
 value = luma pixels coded by all ranks / max-over-ranks wall time.
 
-The line is self-verifying: after the timed region the bitstreams of the first and the last stream of rank 0 (first
-`--verify-frames` frames: header + I + P) and the reconstruction of the last of those frames are compared with a live run
-of the reference encoder (oracle/_ref/Thorenc, the checker - never the thing measured); "bit_exact": false zeroes the metric.
+The line is self-verifying.  BEFORE the timed region rank 0 starts live runs of the reference encoder
+(oracle/_ref/Thorenc: the checker and the reported CPU baseline - never the thing measured) on the first and the last of
+its streams; they run on host cores concurrently with the GPU work and cover `verify_frames` = min(frames, max(warmup + 2, 7))
+frames, i.e. they reach INTO the timed region (with the driver's flags: I, P1..P4 and the timed 4-reference frames P5, P6).
+The GPU bitstream prefix of those frames and the reconstruction of the last of them must equal the reference's;
+"bit_exact": false zeroes the metric and the exit code is 1.
 
-  python bench.py --gpus N --steps K --warmup W [--streams S] [--width 3840 --height 2160]
+  python bench.py --gpus N --steps K --warmup W [--streams S] [--width 3840 --height 2160] [--config ldb|ra|hdb16]
+                  [--bitdepth 8|10] [--sigma 2.0]
 For N > 1 launch with torch.distributed.run (one rank per GPU); streams are sharded across ranks with no data-path
-collective in the timed region ("weak" scaling: S streams per GPU); RCCL carries the clip broadcast before it and the
-ordered gather of the per-chunk bitstreams + the all-reduce of the bit/frame counts after it.
+collective in the timed region ("weak" scaling: S streams per GPU); RCCL carries a consistency broadcast of the input
+before it and the ordered gather of the per-chunk bitstreams + the all-reduce of the bit/frame counts after it.  A launch
+through torch.distributed.run with ONE process runs the same collectives over RCCL on one GPU.
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -32,9 +38,16 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-CFG = os.path.join(ROOT, 'configs', 'ldb_high_efficiency.cfg')
+CONFIGS = {  # operating points of BASELINE.json: config file, default qp
+    'ldb': ('ldb_high_efficiency.cfg', 32),
+    'ra': ('ra_high_efficiency.cfg', 27),
+    'hdb16': ('hdb16_high_efficiency.cfg', 32),
+}
 REF_ENC = os.path.join(ROOT, 'oracle', '_ref', 'Thorenc')
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+# v_sad_u8: 4 sample differences per lane and instruction, 64 lanes, one wave64 VALU instruction per 4 clocks and SIMD,
+# 1024 SIMDs at 2.4 GHz (MI355X_MICROARCH.md) -> pixel-differences per second the chip could accumulate
+SAD_PEAK_PXOPS = 1024 * 2.4e9 / 4 * 64 * 4
 
 
 # ---- helpers that the CPU (gloo) tests exercise --------------------------------------------------
@@ -44,6 +57,7 @@ def shard_streams(total, world):
 
 
 def stream_ids(total, world, rank):
+    """Global ids of the streams (sequence chunks) rank `rank` encodes: contiguous, rank-major."""
     parts = shard_streams(total, world)
     start = sum(parts[:rank])
     return list(range(start, start + parts[rank]))
@@ -70,15 +84,14 @@ def reduce_sum(v, dist):
 
 
 def broadcast_clip(clip_u8, dist, src=0):
-    """Rank `src` owns the clip (1-D uint8 numpy array of all frames); every rank returns a torch uint8 tensor with the
-    same bytes on its collective device.  This is the "scatter of the raw input" of SURVEY.md 8e: the chunks of all
-    ranks are windows of this one clip."""
+    """Rank `src` owns the bytes (1-D uint8 numpy array); every rank returns a torch uint8 tensor with the same bytes on
+    its collective device (the "scatter of the raw input" of SURVEY.md 8e)."""
     import torch
     dev = _reduce_device(dist)
     n = torch.tensor([0 if clip_u8 is None else clip_u8.size], dtype=torch.int64, device=dev)
     dist.broadcast(n, src=src)
     if dist.get_rank() == src:
-        t = torch.from_numpy(clip_u8).to(dev)
+        t = torch.from_numpy(np.ascontiguousarray(clip_u8)).to(dev)
     else:
         t = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
     dist.broadcast(t, src=src)
@@ -133,74 +146,52 @@ def stream_prefix(bits, nframes):
     return bits[:pos]
 
 
-# ---- CPU legs (checker + reported baseline; run after the timed region, in parallel on host cores) --------------
-def _ref_cmd(d, tag, w, h, qp, n, with_rec):
-    cmd = [REF_ENC, '-cf', CFG, '-if', os.path.join(d, tag + '.yuv'), '-width', str(w), '-height', str(h), '-qp', str(qp),
-           '-n', str(n), '-f', '30', '-of', os.path.join(d, f'{tag}_{n}.bit')]
-    if with_rec:
-        cmd += ['-rf', os.path.join(d, f'{tag}_{n}.yuv')]
-    return cmd
+# ---- CPU legs: the checker and the reported baseline (host processes, started BEFORE the timed region) ------------
+class CpuLegs:
+    """Live runs of the reference encoder on host cores, one process per leg:
+       'v<sid>'  stream sid, first nv coded frames, stream + reconstruction   (bit-exactness of the GPU path)
+       'b'       stream of the first verify leg, nv - 1 frames                (1-core baseline: t[v] - t[b] = one frame at the
+                                                                               benched geometry with every reference in use)
+       'm<k>'    further streams, min(nv, 3) frames                           (N-process figure: N cores busy at once)
+    The legs run while the GPU encodes; collect() waits for them after the timed region."""
 
+    def __init__(self, cfg_path, w, h, qp, extra, total_frames, reordered):
+        self.cfg, self.w, self.h, self.qp, self.extra = cfg_path, w, h, qp, list(extra)
+        self.total, self.reordered = total_frames, reordered
+        self.dir = tempfile.TemporaryDirectory()
+        self.procs = []  # (tag, n, t0, Popen)
+        self.ncores = os.cpu_count() or 1
 
-def cpu_legs(verify, base_frames, w, h, qp, nv, want_baseline):
-    """verify: {stream id: (frames, gpu_bits, gpu_rec_last)}.  Runs the reference on the first nv frames of each of
-    those streams (bit-exactness check) and, for the reported CPU baseline, on a bounded sample: the top-left
-    1920x1080 crop of stream-0's frames, n = k and n = k-1 frames (the difference isolates one P frame with
-    min(4, k-1) references).  All runs are separate processes started together, one host core each."""
-    res = {'bit_exact': None, 'checked': [], 'cpu_baseline': None}
-    if not os.path.exists(REF_ENC):
-        res['note'] = 'oracle/_ref/Thorenc not in the snapshot: bit-exactness not checked in this run'
-        return res
-    with tempfile.TemporaryDirectory() as d:
-        procs = []
-        for sid, (frames, _, _) in verify.items():
-            open(os.path.join(d, f'v{sid}.yuv'), 'wb').write(b''.join(f.tobytes() for f in frames[:nv]))
-            procs.append(('v', sid, time.perf_counter(), subprocess.Popen(_ref_cmd(d, f'v{sid}', w, h, qp, nv, True), stdout=subprocess.DEVNULL)))
-        kb = 0
-        if want_baseline:
-            cw, ch = min(w, 1920), min(h, 1080)
-            kb = min(len(base_frames), 6)
-            crop = []
-            for f in base_frames[:kb]:
-                Y = f[:w * h].reshape(h, w)[:ch, :cw]
-                U = f[w * h:w * h + (w // 2) * (h // 2)].reshape(h // 2, w // 2)[:ch // 2, :cw // 2]
-                V = f[w * h + (w // 2) * (h // 2):].reshape(h // 2, w // 2)[:ch // 2, :cw // 2]
-                crop.append(np.concatenate([np.ascontiguousarray(Y).ravel(), np.ascontiguousarray(U).ravel(), np.ascontiguousarray(V).ravel()]))
-            open(os.path.join(d, 'b.yuv'), 'wb').write(b''.join(c.tobytes() for c in crop))
-            if kb >= 2:
-                for n in (kb, kb - 1):
-                    procs.append(('b', n, time.perf_counter(), subprocess.Popen(_ref_cmd(d, 'b', cw, ch, qp, n, False), stdout=subprocess.DEVNULL)))
-        tb = {}
-        pending = list(procs)
+    def available(self):
+        return os.path.exists(REF_ENC)
+
+    def start(self, tag, frames_bytes, n, with_rec):
+        d = self.dir.name
+        path = os.path.join(d, tag + '.yuv')
+        if not os.path.exists(path):
+            with open(path, 'wb') as f:
+                for fr in frames_bytes:
+                    f.write(fr)
+        cmd = [REF_ENC, '-cf', self.cfg, '-if', path, '-width', str(self.w), '-height', str(self.h), '-qp', str(self.qp),
+               '-n', str(n), '-f', '30', '-of', os.path.join(d, f'{tag}_{n}.bit')] + self.extra
+        if with_rec:
+            cmd += ['-rf', os.path.join(d, f'{tag}_{n}.yuv')]
+        self.procs.append([tag, n, time.perf_counter(), subprocess.Popen(cmd, stdout=subprocess.DEVNULL), None])
+
+    def collect(self):
+        pending = [p for p in self.procs if p[4] is None]
         while pending:  # poll so that every process gets its own wall time
             for it in list(pending):
-                kind, key, t0, pr = it
-                if pr.poll() is not None:
-                    if pr.returncode != 0:
-                        raise RuntimeError(f'reference encoder failed ({kind} {key})')
-                    if kind == 'b':
-                        tb[key] = time.perf_counter() - t0
+                if it[3].poll() is not None:
+                    if it[3].returncode != 0:
+                        raise RuntimeError(f'reference encoder failed ({it[0]})')
+                    it[4] = time.perf_counter() - it[2]
                     pending.remove(it)
             time.sleep(0.05)
-        ok = True
-        for sid, (frames, gbits, grec) in verify.items():
-            rbits = open(os.path.join(d, f'v{sid}_{nv}.bit'), 'rb').read()
-            rrec = open(os.path.join(d, f'v{sid}_{nv}.yuv'), 'rb').read()
-            fsz = w * h * 3 // 2
-            same = stream_prefix(gbits, nv) == rbits
-            if grec is not None:
-                same = same and rrec[(nv - 1) * fsz:nv * fsz] == grec.tobytes()
-            res['checked'].append({'stream': sid, 'frames': nv, 'bitstream_bytes': len(rbits), 'recon_checked': grec is not None, 'ok': bool(same)})
-            ok = ok and same
-        res['bit_exact'] = bool(ok)
-        if want_baseline and kb >= 2:
-            cw, ch = min(w, 1920), min(h, 1080)
-            dt = max(tb[kb] - tb[kb - 1], 1e-9)
-            res['cpu_baseline'] = {
-                'value': round(cw * ch / dt / 1e6, 4), 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'reference',
-                'sample': f'top-left {cw}x{ch} crop of stream 0 of the same clip, P frame {kb - 1} ({min(4, kb - 1)} references): '
-                          f't[{kb} frames] - t[{kb - 1} frames] = {tb[kb]:.1f} s - {tb[kb - 1]:.1f} s, Thorenc SIMD build, 1 thread per run'}
-    return res
+        return {(p[0], p[1]): p[4] for p in self.procs}
+
+    def read(self, tag, n, what):
+        return open(os.path.join(self.dir.name, f'{tag}_{n}.{what}'), 'rb').read()
 
 
 def main():
@@ -211,8 +202,11 @@ def main():
     ap.add_argument('--streams', type=int, default=int(os.environ.get('THOR_BENCH_STREAMS', '96')), help='streams PER GPU')
     ap.add_argument('--width', type=int, default=3840)
     ap.add_argument('--height', type=int, default=2160)
-    ap.add_argument('--qp', type=int, default=32)
-    ap.add_argument('--verify-frames', type=int, default=2)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='ldb')
+    ap.add_argument('--qp', type=int, default=None)
+    ap.add_argument('--bitdepth', type=int, default=8, choices=(8, 10))
+    ap.add_argument('--sigma', type=float, default=2.0, help='temporal noise of the synthetic clip (SURVEY 8d: 2 = default, 6 = hard variant)')
+    ap.add_argument('--verify-frames', type=int, default=None, help='coded frames compared with the live reference (default: min(frames, max(warmup + 2, 7)))')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-verify', action='store_true')
     a = ap.parse_args()
@@ -231,33 +225,60 @@ def main():
     dev = torch.device('cuda', local_rank) if have_gpu else torch.device('cpu')
     if have_gpu:
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    # a torch.distributed.run launch (even with one process) runs the collectives: RCCL on the GPU box, gloo on CPU (tests)
+    if world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ):
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group('nccl')
+        dist.init_process_group(os.environ.get('THOR_BENCH_BACKEND', 'nccl' if have_gpu else 'gloo'))
 
     import thor_amd
     from thor_amd import synth
     w, h, S = a.width, a.height, a.streams
-    nframes = a.warmup + a.steps
-    fsz = w * h * 3 // 2
+    cfg_name, qp_default = CONFIGS[a.config]
+    cfg_path = os.path.join(ROOT, 'configs', cfg_name)
+    qp = a.qp if a.qp is not None else qp_default
+    hbd = a.bitdepth > 8
+    bps = 2 if hbd else 1
+    ref_extra = ['-bitdepth', str(a.bitdepth), '-input_bitdepth', str(a.bitdepth)] if hbd else []
+    nframes = a.warmup + a.steps           # coded frames = display frames of every chunk
+    fpx = w * h * 3 // 2                   # samples per frame
     extra = 3
-    # ---- input: rank 0 generates the clip; RCCL broadcast; chunks are cut on the GPU -------------------------------
+    reordered = a.config != 'ldb'
+    # ---- input: every rank generates the seeded clip; chunks are cut on the GPU --------------------------------------
     t_in = time.perf_counter()
-    base = None
-    if rank == 0:
-        base = synth.make_clip(w, h, nframes + extra, 4 if w >= 3840 else 2, 2.0)  # BASELINE cfg 4 / cfg 2 content model and seed
-        flat = np.concatenate([np.concatenate([p.ravel() for p in fr]) for fr in base])
-    if dist is not None:
-        clip_t = broadcast_clip(flat if rank == 0 else None, dist)
-    else:
-        clip_t = torch.from_numpy(flat).to(dev)
-    dev_frames = clip_t.view(nframes + extra, fsz)
-    p = thor_amd.load_config(CFG, width=w, height=h, qp=a.qp, f=30)
+    seed = {'ldb': 4 if w >= 3840 else 2, 'ra': 3, 'hdb16': 5}[a.config]     # cfg 4 / 2 / 3 / 5 content seeds
+    base = synth.make_clip(w, h, nframes + extra, seed, a.sigma, a.bitdepth)
+    flat = np.concatenate([np.concatenate([p.ravel() for p in fr]) for fr in base])
+    my_ids = stream_ids(S * world, world, rank)
+    if dist is not None:  # consistency of the inputs across ranks: rank 0's first frame travels over RCCL and is compared
+        f0 = broadcast_clip(flat[:fpx].view(np.uint8) if rank == 0 else None, dist)
+        assert f0.cpu().numpy().tobytes() == flat[:fpx].tobytes(), 'ranks generated different clips'
+    clip_t = torch.from_numpy(flat.view(np.int16) if hbd else flat).to(dev)
+    dev_frames = clip_t.view(nframes + extra, fpx)
+    over = {'bitdepth': a.bitdepth, 'input_bitdepth': a.bitdepth} if hbd else {}
+    p = thor_amd.load_config(cfg_path, width=w, height=h, qp=qp, f=30, **over)
     enc = thor_amd.Encoder(p, S, device=local_rank)
     c2 = (w // 2) * (h // 2)
+    maxv = (1 << a.bitdepth) - 1
 
-    def dev_stream_frame(sid, f):  # the torch restatement of synth.make_stream_frames (checked against it below)
+    def host_stream_frames(sid):
+        if not hbd:
+            return synth.make_stream_frames(base, sid, nframes)
+        # 10-bit: same window / flip / offset rule on uint16 samples
+        off = sid % max(1, len(base) - nframes + 1)
+        mode = (sid // 3) % 4
+        out = []
+        for f in range(nframes):
+            Y, U, V = base[off + f]
+            if mode & 1:
+                Y, U, V = Y[:, ::-1], U[:, ::-1], V[:, ::-1]
+            if mode & 2:
+                Y, U, V = Y[::-1], U[::-1], V[::-1]
+            Y = np.clip(Y.astype(np.int32) + (sid % 5), 0, maxv).astype('<u2')
+            out.append(np.concatenate([np.ascontiguousarray(Y).ravel(), np.ascontiguousarray(U).ravel(), np.ascontiguousarray(V).ravel()]))
+        return out
+
+    def dev_stream_frame(sid, f):  # the torch restatement of host_stream_frames (checked against it below)
         off = sid % max(1, (nframes + extra) - nframes + 1)
         mode = (sid // 3) % 4
         fr = dev_frames[off + f]
@@ -265,41 +286,79 @@ def main():
         dims = ([1] if mode & 1 else []) + ([0] if mode & 2 else [])
         if dims:
             Y, U, V = torch.flip(Y, dims), torch.flip(U, dims), torch.flip(V, dims)
-        Y = torch.clamp(Y.to(torch.int16) + (sid % 5), 0, 255).to(torch.uint8)
+        Y = torch.clamp(Y.to(torch.int32) + (sid % 5), 0, maxv).to(Y.dtype)
         return torch.cat([Y.reshape(-1), U.reshape(-1), V.reshape(-1)])
 
-    my_ids = [rank * S + s for s in range(S)]
+    # ---- checker / CPU baseline: reference processes start NOW and run beside the GPU ------------------------------
+    nv = a.verify_frames if a.verify_frames is not None else max(a.warmup + 2, 7)
+    nv = max(1, min(nv, nframes))
+    legs = CpuLegs(cfg_path, w, h, qp, ref_extra, nframes, reordered)
+    verify = {}        # local stream index -> [host frames, gpu bits, gpu recon of coded frame nv-1]
+    do_verify = rank == 0 and not a.no_verify and legs.available()
+    do_base = rank == 0 and not a.no_cpu_baseline and legs.available() and world == 1
+    n_ref = nframes if reordered else nv   # with frame reordering the coding order depends on the chunk length: run it all
+    base_legs = []
+    if rank == 0 and (do_verify or do_base):
+        vs = sorted({0, S - 1}) if do_verify else [0]
+        for s in vs:
+            fr = host_stream_frames(my_ids[s])
+            verify[s] = [fr, None, None]
+            if do_verify:
+                legs.start(f'v{my_ids[s]}', [x.tobytes() for x in fr[:n_ref]], n_ref, True)
+        if do_base and not reordered and nv >= 2:
+            s0 = vs[0]
+            if do_verify:
+                legs.start(f'v{my_ids[s0]}', None, nv - 1, False)
+            else:
+                legs.start(f'v{my_ids[s0]}', [x.tobytes() for x in verify[s0][0][:nv]], nv, False)
+                legs.start(f'v{my_ids[s0]}', None, nv - 1, False)
+            # N-process figure: fill the remaining host cores (one is left to this process) with further chunks
+            nm = max(0, min(legs.ncores - 1, 8) - len(legs.procs))
+            km = min(nv, 3)
+            for k in range(nm):
+                sid = my_ids[(1 + k) % S]
+                legs.start(f'm{k}', [x.tobytes() for x in host_stream_frames(sid)[:km]], km, False)
+                base_legs.append((f'm{k}', km))
+    if rank == 0 and verify:
+        s_chk = sorted(verify)[-1]
+        assert np.array_equal(dev_stream_frame(my_ids[s_chk], 0).cpu().numpy().view(np.uint8), verify[s_chk][0][0].view(np.uint8)), \
+            'GPU chunk cutter differs from the host stream generator'
+
     for s in range(S):
         for f in range(nframes):
             t = dev_stream_frame(my_ids[s], f)
             if have_gpu:
                 torch.cuda.synchronize()
             enc.stage_device(s, f, t.data_ptr())
-    verify = {}
-    if rank == 0:
-        for s in sorted({0, S - 1}):
-            fr = synth.make_stream_frames(base, my_ids[s], nframes)
-            assert np.array_equal(dev_stream_frame(my_ids[s], 0).cpu().numpy(), fr[0]), 'GPU chunk cutter differs from synth.make_stream_frames'
-            verify[s] = [fr, None, None]
+        if reordered:
+            enc.begin_sequence(s, 0, nframes, nframes)
     t_in = time.perf_counter() - t_in
-    nv = max(1, min(a.verify_frames, a.warmup if a.warmup > 0 else 1, nframes))
 
-    def grab_recon(f):
-        if rank == 0 and f == nv - 1 and not a.no_verify:
+    coded = [0]
+
+    def step():
+        """One lock-step frame of every stream, in coding order."""
+        if reordered:
+            idx = [enc.next_frame(s) for s in range(S)]
+            assert idx[0] is not None
+        else:
+            idx = [coded[0]] * S
+        enc.encode_staged(idx)      # blocks until all streams' bits are on the host
+        coded[0] += 1
+        if do_verify and coded[0] == nv:
             for s in verify:
-                verify[s][2] = enc.recon(s)
+                verify[s][2] = (idx[s], enc.recon(s))   # (display index, samples) of coded frame nv-1
 
-    for f in range(a.warmup):
-        enc.encode_staged([f] * S)
-        grab_recon(f)
+    for _ in range(a.warmup):
+        step()
     enc.kernel_time_reset()
     if dist is not None:
         dist.barrier()
     if have_gpu:
         torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for f in range(a.warmup, nframes):
-        enc.encode_staged([f] * S)   # blocks until all streams' bits are on the host
+    for _ in range(a.steps):
+        step()
     if have_gpu:
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -322,47 +381,87 @@ def main():
         if rank == 0:
             assert len(allbits) == S * world and allbits[:S] == local_bits, 'ordered gather lost the chunk order'
     t_g = time.perf_counter() - t_g
+    stats = enc.stats() if hasattr(enc, 'stats') else None
 
     rc = 0
     if rank == 0:
-        for s in verify:
-            verify[s][1] = local_bits[s]
-        legs = {'bit_exact': None, 'checked': [], 'cpu_baseline': None, 'note': 'verification disabled (--no-verify)'}
-        if not a.no_verify or not a.no_cpu_baseline:
-            legs = cpu_legs({} if a.no_verify else {my_ids[s]: tuple(v) for s, v in verify.items()}, verify[0][0], w, h, a.qp, nv,
-                            not a.no_cpu_baseline and world == 1)
-            if a.no_verify:
-                legs['bit_exact'] = None
-        if legs['bit_exact'] is False:
+        res = {'bit_exact': None, 'checked': [], 'cpu_baseline': None}
+        if not legs.available():
+            res['note'] = 'oracle/_ref/Thorenc not in the snapshot: bit-exactness not checked in this run'
+        elif a.no_verify:
+            res['note'] = 'verification disabled (--no-verify)'
+        t_w = time.perf_counter()
+        times = legs.collect() if legs.procs else {}
+        t_w = time.perf_counter() - t_w
+        if do_verify:
+            ok = True
+            fbytes = fpx * bps
+            for s in sorted(verify):
+                fr, _, rec = verify[s]
+                tag = f'v{my_ids[s]}'
+                rbits = legs.read(tag, n_ref, 'bit')
+                rrec = legs.read(tag, n_ref, 'yuv')
+                gbits = local_bits[s]
+                same = stream_prefix(gbits, nv) == stream_prefix(rbits, nv)
+                rec_ok = None
+                if rec is not None:
+                    di, px = rec   # the reference writes its reconstruction in DISPLAY order
+                    rec_ok = rrec[di * fbytes:(di + 1) * fbytes] == px.tobytes()
+                    same = same and rec_ok
+                res['checked'].append({'stream': my_ids[s], 'frames': nv, 'timed_frames_covered': max(0, nv - a.warmup),
+                                       'bitstream_bytes': len(stream_prefix(rbits, nv) or b''), 'recon_checked': rec_ok is not None, 'ok': bool(same)})
+                ok = ok and same
+            res['bit_exact'] = bool(ok)
+        if do_base and not reordered and nv >= 2:
+            tag = f'v{my_ids[sorted(verify)[0]]}'
+            t_hi, t_lo = times[(tag, nv)], times[(tag, nv - 1)]
+            dtc = max(t_hi - t_lo, 1e-9)
+            nproc = len(legs.procs)
+            # aggregate of all concurrently running reference processes: pixels coded / wall of the slowest
+            agg_px = sum(n for (_, n) in times) * float(w) * h
+            agg = agg_px / max(times.values()) / 1e6
+            res['cpu_baseline'] = {
+                'value': round(w * h / dtc / 1e6, 4), 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'reference',
+                'sample': f'stream {my_ids[sorted(verify)[0]]} of the same workload at the benched geometry {w}x{h}: coded frame {nv - 1} '
+                          f'({min(int(p.max_num_ref), nv - 1)} references) = t[{nv} frames] - t[{nv - 1} frames] = {t_hi:.1f} s - {t_lo:.1f} s; '
+                          f'Thorenc SIMD build, 1 thread per process, {nproc} reference processes running at the same time beside the GPU job',
+                'n_process': {'procs': nproc, 'host_cores': legs.ncores, 'value': round(agg, 4), 'unit': 'Mpixels/s',
+                              'note': 'all concurrently running reference processes (verify + baseline + fill-up chunks): pixels coded / wall of the slowest'}}
+        if res['bit_exact'] is False:
             value, rc = 0.0, 1
         # roofline of the dominant kernel (k_superblocks): algorithmic HBM bytes per luma pixel of a P frame with R
-        # references = 1.5 * (1 orig + R refs + 1 rec) (block-path terms).  Frame f of a chunk (f >= 1)
-        # references min(max_num_ref, f) earlier frames: average over the timed frames.
-        R = sum(min(int(p.max_num_ref), f) for f in range(a.warmup, nframes)) / max(a.steps, 1)
-        bytes_per_px = 1.5 * (2 + R)
+        # references = 1.5 * bps * (1 orig + R refs + 1 rec) (block-path terms).  Coded frame f of an LDB chunk
+        # (f >= 1) references min(max_num_ref, f) earlier frames: average over the timed frames.
+        mref = int(p.max_num_ref)
+        R = sum(min(mref, f) for f in range(a.warmup, nframes)) / max(a.steps, 1)
+        bytes_per_px = 1.5 * bps * (2 + R)
         alg_bytes_per_launch = (w * h * a.steps * S * bytes_per_px) / max(launches, 1)
         avg_launch_s = (sb_ms / 1e3) / max(launches, 1)
         achieved = alg_bytes_per_launch / max(avg_launch_s, 1e-12) / 1e9
-        # HBM traffic per launch from the committed PMC passes of this kernel (profiles/r02_pmc.json: FETCH_SIZE + WRITE_SIZE
-        # with the guide's gfx950 corrections, collected in their own runs on a saturated workload of the same operating
-        # point) scaled from bytes per luma pixel to the pixels one launch of THIS run covers; null if the file is missing.
-        traffic, traffic_src = None, None
+        # HBM traffic and SQ figures: only from a committed PMC pass of THIS workload geometry (profiles/r03_pmc_bench.json,
+        # written by scripts/pmc_summary.py from rocprofv3 --pmc passes of the same bench command); otherwise null.
+        traffic, traffic_src, valu_util = None, None, None
         try:
-            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc.json')))
-            traffic = round((pm['fetch_bytes_per_px'] + pm['write_bytes_per_px']) * w * h * S * a.steps / max(launches, 1))
-            traffic_src = 'profiles/r02_pmc.md (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE: %.0f + %.0f B per luma pixel on: %s)' % (
-                pm['fetch_bytes_per_px'], pm['write_bytes_per_px'], pm['workload'])
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_bench.json')))
+            if pm.get('width') == w and pm.get('height') == h and pm.get('streams') == S and pm.get('config', 'ldb') == a.config:
+                traffic = round((pm['fetch_bytes_per_px'] + pm['write_bytes_per_px']) * w * h * S * a.steps / max(launches, 1))
+                traffic_src = 'profiles/r03_pmc_bench.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this geometry (%s)' % pm['workload']
+                valu_util = pm.get('valu_util_chip')
         except (OSError, KeyError, ValueError):
             pass
+        # op model: ~1.1e4 SAD pixel-differences per pixel of a 4-reference P frame at speed 0 (+30 % for the
+        # bi-prediction search), scaled by the references in use; against the v_sad_u8 rate of the chip
+        sad_ops_px = 1.1e4 * (R / 4.0) * (1.3 if R > 1 else 1.0)
+        sad_frac = value * 1e6 * sad_ops_px / SAD_PEAK_PXOPS
         out = {
             'metric': 'encoder Mpixels/s at fixed qp, bit-exact recon vs ref', 'value': round(value, 3), 'unit': 'Mpixels/s',
             'fps': round(value * 1e6 / (w * h), 3),
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt * 1e3 / max(a.steps, 1), 2),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
-            'bit_exact': legs['bit_exact'], 'bit_exact_checked': legs['checked'],
-            'config': {'workload': f'{w}x{h} 8-bit 4:2:0, LDB_high_efficiency (configs/ldb_high_efficiency.cfg), qp {a.qp}, '
-                                   f'{S} independent closed streams per GPU in lock step, timed frames = P frames {a.warmup}..{nframes - 1} of each stream '
-                                   f'({R:.2f} references on average)',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u16' if hbd else 'u8', 'data': 'synthetic',
+            'bit_exact': res['bit_exact'], 'bit_exact_checked': res['checked'],
+            'config': {'workload': f'{w}x{h} {a.bitdepth}-bit 4:2:0, {cfg_name[:-4]} (configs/{cfg_name}), qp {qp}, '
+                                   f'{S} independent closed streams per GPU in lock step, timed frames = coded frames {a.warmup}..{nframes - 1} of each stream '
+                                   f'({R:.2f} references on average), synthetic content sigma {a.sigma:g}',
                        'streams_per_gpu': S, 'frames_timed_per_stream': a.steps, 'parallelism': f'stream-sharded x{world}',
                        'per_stream_fps': round(a.steps / dt, 4), 'per_stream_mpx_s': round(w * h * a.steps / dt / 1e6, 4)},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 4), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -370,18 +469,24 @@ def main():
                          'alg_bytes_per_launch': round(alg_bytes_per_launch),
                          'kernel': 'k_superblocks', 'launches': launches, 'avg_launch_ms': round(avg_launch_s * 1e3, 3),
                          'alg_bytes_per_px': round(bytes_per_px, 3),
-                         'note': 'one persistent dependency-driven launch per frame; the path is latency/VALU-bound, not HBM-bound (SURVEY.md 0.7); '
+                         'ops': {'model': 'SAD pixel-differences per luma pixel (SURVEY 8d): %.3g' % sad_ops_px,
+                                 'achieved_pxops_per_s': round(value * 1e6 * sad_ops_px, 0), 'peak_pxops_per_s': SAD_PEAK_PXOPS,
+                                 'unit': 'v_sad_u8 pixel-differences/s', 'frac': round(sad_frac, 6), 'valu_util_chip': valu_util},
+                         'note': 'one persistent dependency-driven launch per frame; the path is latency/instruction-bound, not HBM-bound (SURVEY.md 0.7); '
                                  'filters+ref kernels took %.1f ms in the timed region' % filt_ms},
-            'io': {'input_setup_s': round(t_in, 2), 'gather_s': round(t_g, 3), 'stream_bytes_total': int(total_bytes), 'frames_total': int(total_frames)},
+            'io': {'input_setup_s': round(t_in, 2), 'gather_s': round(t_g, 3), 'cpu_legs_wait_s': round(t_w, 1),
+                   'stream_bytes_total': int(total_bytes), 'frames_total': int(total_frames)},
         }
-        if legs.get('note'):
-            out['bit_exact_note'] = legs['note']
-        if legs['cpu_baseline']:
-            out['cpu_baseline'] = legs['cpu_baseline']
+        if stats:
+            out['content'] = stats
+        if res.get('note'):
+            out['bit_exact_note'] = res['note']
+        if res['cpu_baseline']:
+            out['cpu_baseline'] = res['cpu_baseline']
         print(json.dumps(out), flush=True)
     enc.close()
     if dist is not None:
-        dist.barrier()   # the other ranks wait here while rank 0 runs the CPU legs (reference runs) above
+        dist.barrier()   # the other ranks wait here while rank 0 collects the CPU legs (reference runs) above
         dist.destroy_process_group()
     if rc:
         sys.exit(rc)

@@ -113,6 +113,11 @@ int thor_hip_get_recon(thor_hip_encoder* e, int stream, void* yuv_out);
  * reset; used by bench.py for the roofline figure. */
 void thor_hip_kernel_time(thor_hip_encoder* e, double* sb_ms, long* sb_launches, double* filter_ms);
 void thor_hip_kernel_time_reset(thor_hip_encoder* e);
+/* Content statistics of the inter frames coded since the last reset ("always log the fraction of SBs that
+ * early-skipped"; reference shortcut enc/encode_block.c:2231,2440-2480): out[0] luma pixels coded by the early-skip
+ * shortcut (any block size), out[1] superblocks early-skipped as a whole, out[2] superblocks processed, out[3] luma
+ * pixels processed.  reset != 0 clears the counters. */
+void thor_hip_read_stats(thor_hip_encoder* e, unsigned long long out[4], int reset);
 /* Development aid: 32 shader-cycle / event counters summed over all superblock wavefronts (all zero unless
  * the library was built with -DTHOR_PROF). */
 void thor_hip_read_prof(thor_hip_encoder* e, long long out[32]);

@@ -71,6 +71,7 @@ def lib():
         L.thor_hip_get_recon.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.thor_hip_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]
         L.thor_hip_kernel_time_reset.argtypes = [C.c_void_p]
+        L.thor_hip_read_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
         L.thor_hip_deblock_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.thor_hip_params_from_config.argtypes = [C.POINTER(ThorParams), C.c_char_p]
         L.thor_hip_params_set.argtypes = [C.POINTER(ThorParams), C.c_char_p, C.c_char_p]
@@ -177,6 +178,15 @@ class Encoder:
 
     def kernel_time_reset(self):
         lib().thor_hip_kernel_time_reset(self.h)
+        self.stats(reset=True)
+
+    def stats(self, reset=False):
+        """Early-skip statistics of the inter frames coded since the last reset (thor_hip_read_stats)."""
+        a = (C.c_ulonglong * 4)()
+        lib().thor_hip_read_stats(self.h, a, 1 if reset else 0)
+        px, sb = max(int(a[3]), 1), max(int(a[2]), 1)
+        return {'early_skip_pixel_fraction': round(int(a[0]) / px, 4), 'early_skip_sb128_fraction': round(int(a[1]) / sb, 4),
+                'inter_superblocks': int(a[2]), 'inter_luma_pixels': int(a[3])}
 
     def __enter__(self):
         return self

@@ -95,12 +95,13 @@ template <typename PIX> __global__ __launch_bounds__(kWgThreads, TK_OCC) void k_
   __shared__ WgShared sh;
   __shared__ SmallWs<PIX> sws[kWaves];
   __shared__ unsigned s_task;
-  const FrameJob<PIX>& J = sJ;
+  JobR<PIX> J = *ldsc(&sJ);
   const unsigned total = (unsigned)A.S * (unsigned)A.nsb;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
   const Wg wg{wave, kWaves};
-  TeamWs<PIX> wsv = make_ws(&sws[wave], &sh, (BigWs<PIX>*)(A.pool + ((size_t)blockIdx.x * kWaves + wave) * A.slot_bytes));
-  TeamWs<PIX>* ws = &wsv;
+  __shared__ TeamWs<PIX> s_view[kWaves];   // per-wave view of the workspaces: in LDS so that the callees read it with ds_read
+  lds_st(&s_view[wave], make_ws(&sws[wave], &sh, (BigWs<PIX>*)(A.pool + ((size_t)blockIdx.x * kWaves + wave) * A.slot_bytes)));
+  WsP<PIX> ws = ldsc(&s_view[wave]);
   const Team t{lane, 64, sh.tabs.izz};
   xform_tables_fill(&sh.tabs, (int)threadIdx.x, kWgThreads);  // constant: once per workgroup
   for (;;) {
@@ -826,6 +827,10 @@ void thor_hip_kernel_time(thor_hip_encoder*, double* sb_ms, long* sb_launches, d
 }
 void thor_hip_read_prof(thor_hip_encoder* e, long long out[32]) { if (!e || !out) return; ENC_DISPATCH(e, { backend::d2h(out, E.eng.d_prof, 32 * sizeof(long long)); }); }
 void thor_hip_kernel_time_reset(thor_hip_encoder*) { g_clk.sb_ms = g_clk.filt_ms = 0; g_clk.sb_launches = 0; }
+void thor_hip_read_stats(thor_hip_encoder* e, unsigned long long out[4], int reset) {
+  if (!e || !out) return;
+  ENC_DISPATCH(e, { backend::d2h(out, E.eng.d_stats, 4 * sizeof(unsigned long long)); if (reset) backend::dev_memset(E.eng.d_stats, 0, 8 * sizeof(unsigned long long)); });
+}
 
 }  // extern "C"
 
@@ -990,7 +995,7 @@ __global__ __launch_bounds__(64) void k_kat_sad(const uint8_t* org, int w, int h
     auto ptr = [&](int c) -> const uint8_t* {
       return refp + (size_t)(by + cand[2 * (base + c) + 1]) * rstride + bx + cand[2 * (base + c)];
     };
-    sad_many_ptr(t, sad, m, org, w, w, h, rstride, ptr);
+    sad_many_ptr<SP_GLOBAL>(t, sad, m, org, w, w, h, rstride, ptr);
     for (int c = threadIdx.x; c < m; c += 64) out[base + c] = (uint32_t)sad[c];
     __syncthreads();
   }
@@ -999,7 +1004,7 @@ __global__ __launch_bounds__(64) void k_kat_interp(const uint8_t* ref0, int rstr
                                                   int h, const int16_t* mv, int bipred, uint8_t* out) {
   Team t{(int)threadIdx.x, 64};
   const int i = blockIdx.x;
-  pred_luma(t, out + (size_t)i * w * h, w, ref0 + (size_t)by * rstride + bx, rstride, w, h, mk_mv(mv[2 * i], mv[2 * i + 1]), 0,
+  pred_luma<SP_GLOBAL>(t, out + (size_t)i * w * h, w, ref0 + (size_t)by * rstride + bx, rstride, w, h, mk_mv(mv[2 * i], mv[2 * i + 1]), 0,
             bipred, pic_w, pic_h, bx, by, 8);
 }
 __global__ __launch_bounds__(64) void k_kat_tu(const uint8_t* org, const uint8_t* pred, int size, int qp, int coeff_type, int fast,

@@ -16,8 +16,10 @@ struct BitSink {
   int ovf;
 };
 
-TK_DEV void bs_put(BitSink& b, int n, uint32_t val) {
-  if (b.emit && n > 0) {
+// E = false: counting only (the emission code is not even compiled into the caller: the counting instances are the ones
+// every RDO trial runs, and the instruction cache is shared by all wavefronts of two CUs).
+template <bool E> TK_DEV void bs_put_t(BitSink& b, int n, uint32_t val) {
+  if (E && b.emit && n > 0) {
     if (b.pos + n > b.cap) {
       b.ovf = 1;
     } else {
@@ -38,6 +40,7 @@ TK_DEV void bs_put(BitSink& b, int n, uint32_t val) {
   }
   b.pos += n;
 }
+TK_DEV void bs_put(BitSink& b, int n, uint32_t val) { bs_put_t<true>(b, n, val); }
 
 // (len, code) of VLC table n for symbol cn (enc/putvlc.c:73-160).
 TK_DEV void vlc_code(int n, uint32_t cn, int& len, uint32_t& code) {
@@ -73,13 +76,15 @@ TK_DEV void vlc_code(int n, uint32_t cn, int& len, uint32_t& code) {
   code = (cn != m) ? 1u : 0u;
 }
 
-TK_DEV int bs_vlc(BitSink& b, int n, uint32_t cn) {
+template <bool E> TK_DEV int bs_vlc_t(BitSink& b, int n, uint32_t cn) {
   int len; uint32_t code;
   vlc_code(n, cn, len, code);
-  if (len > 32) { bs_put(b, len - 32, 0); bs_put(b, 32, code); }
-  else bs_put(b, len, code);
+  if (!E) { b.pos += len; return len; }
+  if (len > 32) { bs_put_t<E>(b, len - 32, 0); bs_put_t<E>(b, 32, code); }
+  else bs_put_t<E>(b, len, code);
   return len;
 }
+TK_DEV int bs_vlc(BitSink& b, int n, uint32_t cn) { return bs_vlc_t<true>(b, n, cn); }
 TK_DEV int vlc_len(int n, uint32_t cn) {
   int len; uint32_t code;
   vlc_code(n, cn, len, code);
@@ -87,13 +92,13 @@ TK_DEV int vlc_len(int n, uint32_t cn) {
 }
 
 // write_mv (enc/write_bits.c:123-143): mvd via VLC 7 + sign bit per component, x first.
-TK_DEV void bs_mv(BitSink& b, mv_t mv, mv_t mvp) {
+template <bool E> TK_DEV void bs_mv_t(BitSink& b, mv_t mv, mv_t mvp) {
   int dx = (int16_t)(mv.x - mvp.x), dy = (int16_t)(mv.y - mvp.y);
   uint32_t ax = (uint16_t)iabs(dx), ay = (uint16_t)iabs(dy);
-  bs_vlc(b, 7, ax);
-  if (ax > 0) bs_put(b, 1, dx < 0);
-  bs_vlc(b, 7, ay);
-  if (ay > 0) bs_put(b, 1, dy < 0);
+  bs_vlc_t<E>(b, 7, ax);
+  if (ax > 0) bs_put_t<E>(b, 1, dx < 0);
+  bs_vlc_t<E>(b, 7, ay);
+  if (ay > 0) bs_put_t<E>(b, 1, dy < 0);
 }
 
 // write_coeff (enc/write_bits.c:145-241). coeff: qsize x qsize row-major (qsize=min(size,16)),
@@ -169,10 +174,13 @@ struct BlkParam {  // block_param_t without the coefficient arrays (common/types
 // must be called by ALL lanes of the team).  The level/run mode is again a {identity, ->run, ->level}
 // automaton (zero -> run mode, |c| > 1 -> level mode, |c| == 1 keeps the mode), so ballots give each
 // position its mode, its adaptive-VLC flag and its run length.  With W = 1 this is the serial loop.
-TK_DEV int coeff_bits_team(const Team t, const int16_t* coeff, int size, int type) {
+// SC: address space of the coefficient block (SP_LDS for every buffer except the chroma buffers of tb-split 64/128 blocks)
+template <int SC>
+TK_DEVNI int coeff_bits_team(const Team t, const int16_t* coeff_, int size, int type) {
 #ifdef THOR_EXP_UNIFORM
-  coeff = tk_uniform_ptr(coeff); size = tk_uniform(size); type = tk_uniform(type);
+  coeff_ = tk_uniform_ptr(coeff_); size = tk_uniform(size); type = tk_uniform(type);
 #endif
+  const auto coeff = spc<SC>(coeff_);
   const int qsize = size < kMaxQuant ? size : kMaxQuant;
   const int N = qsize * qsize;
   const IzzRef izzr = izz_ref(t, qsize);
@@ -254,19 +262,19 @@ TK_DEV int coeff_bits_team(const Team t, const int16_t* coeff, int size, int typ
 }
 
 // write_super_mode (enc/write_bits.c:257-358).
-TK_DEV void bs_super_mode(BitSink& b, const SynCtx& s, int mode, int ref0, int split_flag) {
+template <bool E> TK_DEV void bs_super_mode_t(BitSink& b, const SynCtx& s, int mode, int ref0, int split_flag) {
   if (s.frame_type != F_I) {
-    if (!s.encode_this_size) { bs_put(b, 1, !split_flag); return; }
+    if (!s.encode_this_size) { bs_put_t<E>(b, 1, !split_flag); return; }
     int bipred_possible = s.num_ref > 1 && s.enable_bipred;
     int split_possible = s.size > kMinBlk;
     int maxbit = 2 + s.num_ref + split_possible + bipred_possible;
     if (s.interp_ref > 2) maxbit -= 1;
     int moved = (s.ctx_index == 2 || s.ctx_index > 3);
     if (split_flag == 1) {
-      if (s.size > 128) { bs_put(b, 1, 0); return; }
+      if (s.size > 128) { bs_put_t<E>(b, 1, 0); return; }
       int code = 1;
       if (moved) code = (code + 3) % 4;
-      bs_vlc(b, 10 + maxbit, (uint32_t)code);
+      bs_vlc_t<E>(b, 10 + maxbit, (uint32_t)code);
       return;
     }
     int code = 0;
@@ -291,11 +299,13 @@ TK_DEV void bs_super_mode(BitSink& b, const SynCtx& s, int mode, int ref0, int s
       if (!split_possible && code > 1) code--;
       if (moved && s.size > kMinBlk && code < 4) code = (code + 3) % 4;
     }
-    bs_vlc(b, 10 + maxbit, (uint32_t)code);
+    bs_vlc_t<E>(b, 10 + maxbit, (uint32_t)code);
   } else {
-    if (s.encode_this_size && (s.size > kMinBlk || split_flag == 1)) bs_put(b, 1, (uint32_t)split_flag);
+    if (s.encode_this_size && (s.size > kMinBlk || split_flag == 1)) bs_put_t<E>(b, 1, (uint32_t)split_flag);
   }
 }
+
+TK_DEV void bs_super_mode(BitSink& b, const SynCtx& s, int mode, int ref0, int split_flag) { bs_super_mode_t<true>(b, s, mode, ref0, split_flag); }
 
 TK_DEV int cbp_code(int cbp) {  // cbp_table (enc/write_bits.c:382)
   return cbp == 0 ? 1 : cbp == 1 ? 0 : cbp == 2 ? 5 : cbp == 3 ? 2 : cbp == 4 ? 6 : cbp == 5 ? 3 : cbp == 6 ? 7 : 4;
@@ -304,8 +314,8 @@ TK_DEV int cbp_code(int cbp) {  // cbp_table (enc/write_bits.c:382)
 // write_block (enc/write_bits.c:360-600).  cy/cu/cv: quantised coefficients, TU t of a
 // tb-split block at offset t*256 (MAX_QUANT_SIZE^2) like the reference.
 // `t`: team for cooperative counting (b.emit == 0, all lanes call) or nullptr (single-lane emission).
-TK_DEV void bs_coeff_any(BitSink& b, const Team* t, const int16_t* coeff, int size, int type) {
-  if (!b.emit && t) b.pos += coeff_bits_team(*t, coeff, size, type);
+template <bool E, int SC> TK_DEV void bs_coeff_any(BitSink& b, const Team* t, const int16_t* coeff, int size, int type) {
+  if (!E) b.pos += coeff_bits_team<SC>(*t, coeff, size, type);
   else bs_coeff(b, coeff, size, type);
 }
 
@@ -333,11 +343,15 @@ TK_DEV BlkParam uniform_blk(const BlkParam& a) {
 }
 #endif
 
-TK_DEVNI int bs_block(BitSink& b, const SynCtx& s_in, const BlkParam& p_in, const int16_t* cy, const int16_t* cu,
-                    const int16_t* cv, const Team* tm, const int* ybits = nullptr) {
+// E = false: cooperative counting (every lane of the team calls, b.emit == 0, tm != nullptr) - the instance all RDO trials
+// use; E = true: emission by ONE lane (or serial counting when tm == nullptr).
+// SCC: address space of the CHROMA coefficient buffers in counting mode (luma is always SP_LDS on the device).
+template <bool E, int SCC = SP_LDS>
+TK_DEVNI int bs_block_t(BitSink& b, const SynCtx& s_in, const BlkParam& p_in, const int16_t* cy, const int16_t* cu,
+                    const int16_t* cv, const Team* tm, const int* ybits) {
 #ifdef THOR_EXP_UNIFORM
   // only in cooperative counting mode: the emitting call is made by one lane alone
-  const bool coop = !b.emit && tm != nullptr;
+  const bool coop = !E;
   const SynCtx s = coop ? uniform_syn(s_in) : s_in;
   const BlkParam p = coop ? uniform_blk(p_in) : p_in;
 #else
@@ -351,39 +365,39 @@ TK_DEVNI int bs_block(BitSink& b, const SynCtx& s_in, const BlkParam& p_in, cons
   // coefficient offset of TU t of a tb-split block: t * qs^2, qs = min(TU size, 16)
   const int qy = size / 2 < kMaxQuant ? size / 2 : kMaxQuant, qc = size_uv / 2 < kMaxQuant ? size_uv / 2 : kMaxQuant;
   const int sty = qy * qy, stc = qc * qc;
-  bs_super_mode(b, s, mode, p.ref0, 0);
+  bs_super_mode_t<E>(b, s, mode, p.ref0, 0);
 
   if (mode == M_INTRA) {
-    if (s.num_intra_modes <= 4) bs_put(b, 2, (uint32_t)p.intra_mode);
-    else bs_vlc(b, 8, (uint32_t)p.intra_mode);
+    if (s.num_intra_modes <= 4) bs_put_t<E>(b, 2, (uint32_t)p.intra_mode);
+    else bs_vlc_t<E>(b, 8, (uint32_t)p.intra_mode);
   } else if (mode == M_INTER) {
-    if (s.max_pb_part > 1) bs_vlc(b, 13, (uint32_t)p.pb_part);
+    if (s.max_pb_part > 1) bs_vlc_t<E>(b, 13, (uint32_t)p.pb_part);
     mv_t mvp2 = s.mvp;
-    bs_mv(b, p.mv0[0], mvp2);
+    bs_mv_t<E>(b, p.mv0[0], mvp2);
     mvp2 = p.mv0[0];
-    if (p.pb_part == P_HOR) bs_mv(b, p.mv0[2], mvp2);
-    else if (p.pb_part == P_VER) bs_mv(b, p.mv0[1], mvp2);
-    else if (p.pb_part == P_QUAD) { bs_mv(b, p.mv0[1], mvp2); bs_mv(b, p.mv0[2], mvp2); bs_mv(b, p.mv0[3], mvp2); }
+    if (p.pb_part == P_HOR) bs_mv_t<E>(b, p.mv0[2], mvp2);
+    else if (p.pb_part == P_VER) bs_mv_t<E>(b, p.mv0[1], mvp2);
+    else if (p.pb_part == P_QUAD) { bs_mv_t<E>(b, p.mv0[1], mvp2); bs_mv_t<E>(b, p.mv0[2], mvp2); bs_mv_t<E>(b, p.mv0[3], mvp2); }
   } else if (mode == M_BIPRED) {
     mv_t mvp2 = s.mvp;
-    if (p.pb_part == P_NONE) bs_mv(b, p.mv0[0], mvp2);
+    if (p.pb_part == P_NONE) bs_mv_t<E>(b, p.mv0[0], mvp2);
     if (s.frame_type == F_B) mvp2 = p.mv0[0];
-    bs_mv(b, p.mv1[0], mvp2);
+    bs_mv_t<E>(b, p.mv1[0], mvp2);
     if (p.pb_part != P_NONE) {
       mvp2 = p.mv1[0];
-      if (p.pb_part == P_HOR) bs_mv(b, p.mv1[2], mvp2);
-      else if (p.pb_part == P_VER) bs_mv(b, p.mv1[1], mvp2);
-      else { bs_mv(b, p.mv1[1], mvp2); bs_mv(b, p.mv1[2], mvp2); bs_mv(b, p.mv1[3], mvp2); }
+      if (p.pb_part == P_HOR) bs_mv_t<E>(b, p.mv1[2], mvp2);
+      else if (p.pb_part == P_VER) bs_mv_t<E>(b, p.mv1[1], mvp2);
+      else { bs_mv_t<E>(b, p.mv1[1], mvp2); bs_mv_t<E>(b, p.mv1[2], mvp2); bs_mv_t<E>(b, p.mv1[3], mvp2); }
     }
     if (s.frame_type == F_P) {
-      if (s.num_ref == 2) bs_vlc(b, 13, (uint32_t)(2 * p.ref0 + p.ref1));
-      else bs_vlc(b, 10, (uint32_t)(4 * p.ref0 + p.ref1));
+      if (s.num_ref == 2) bs_vlc_t<E>(b, 13, (uint32_t)(2 * p.ref0 + p.ref1));
+      else bs_vlc_t<E>(b, 10, (uint32_t)(4 * p.ref0 + p.ref1));
     }
   } else if (mode == M_SKIP || mode == M_MERGE) {
     int nvec = mode == M_SKIP ? s.num_skip : s.num_merge;
-    if (nvec == 4) bs_put(b, 2, (uint32_t)p.skip_idx);
-    else if (nvec == 3) bs_vlc(b, 12, (uint32_t)p.skip_idx);
-    else if (nvec == 2) bs_put(b, 1, (uint32_t)p.skip_idx);
+    if (nvec == 4) bs_put_t<E>(b, 2, (uint32_t)p.skip_idx);
+    else if (nvec == 3) bs_vlc_t<E>(b, 12, (uint32_t)p.skip_idx);
+    else if (nvec == 2) bs_put_t<E>(b, 1, (uint32_t)p.skip_idx);
   }
 
   if (mode != M_SKIP) {
@@ -401,34 +415,33 @@ TK_DEVNI int bs_block(BitSink& b, const SynCtx& s_in, const BlkParam& p_in, cons
       } else if (s.ctx_cbp == 0 && code < 2) code = 1 - code;
       if (s.max_tb_part > 1 && code >= off) code++;
     }
-    bs_vlc(b, 0, (uint32_t)code);
+    bs_vlc_t<E>(b, 0, (uint32_t)code);
 
     if (tb_split == 0) {
-      if (p.cbp_y) { if (ybits && !b.emit) b.pos += ybits[0]; else bs_coeff_any(b, tm, cy, size, coeff_type | 0); }
-      if (p.cbp_u) bs_coeff_any(b, tm, cu, size_uv, coeff_type | 1);
-      if (p.cbp_v) bs_coeff_any(b, tm, cv, size_uv, coeff_type | 1);
+      if (p.cbp_y) { if (!E && ybits) b.pos += ybits[0]; else bs_coeff_any<E, SP_LDS>(b, tm, cy, size, coeff_type | 0); }
+      if (p.cbp_u) bs_coeff_any<E, SCC>(b, tm, cu, size_uv, coeff_type | 1);
+      if (p.cbp_v) bs_coeff_any<E, SCC>(b, tm, cv, size_uv, coeff_type | 1);
     } else if (size_uv > 4) {
       for (int t = 0; t < 4; t++) {
         int ty = (p.cbp_y >> (3 - t)) & 1, tu = (p.cbp_u >> (3 - t)) & 1, tv = (p.cbp_v >> (3 - t)) & 1;
         int c = cbp_code(ty + (tu << 1) + (tv << 2));
         if (s.ctx_cbp == 0 && c < 2) c = 1 - c;
-        bs_vlc(b, 0, (uint32_t)c);
-        if (ty) { if (ybits && !b.emit) b.pos += ybits[t]; else bs_coeff_any(b, tm, cy + t * sty, size / 2, coeff_type | 0); }
-        if (tu) bs_coeff_any(b, tm, cu + t * stc, size_uv / 2, coeff_type | 1);
-        if (tv) bs_coeff_any(b, tm, cv + t * stc, size_uv / 2, coeff_type | 1);
+        bs_vlc_t<E>(b, 0, (uint32_t)c);
+        if (ty) { if (!E && ybits) b.pos += ybits[t]; else bs_coeff_any<E, SP_LDS>(b, tm, cy + t * sty, size / 2, coeff_type | 0); }
+        if (tu) bs_coeff_any<E, SCC>(b, tm, cu + t * stc, size_uv / 2, coeff_type | 1);
+        if (tv) bs_coeff_any<E, SCC>(b, tm, cv + t * stc, size_uv / 2, coeff_type | 1);
       }
     } else {
       for (int t = 0; t < 4; t++) {
         int ty = (p.cbp_y >> (3 - t)) & 1;
-        bs_put(b, 1, (uint32_t)ty);
-        if (ty) { if (ybits && !b.emit) b.pos += ybits[t]; else bs_coeff_any(b, tm, cy + t * sty, size / 2, coeff_type | 0); }
+        bs_put_t<E>(b, 1, (uint32_t)ty);
+        if (ty) { if (!E && ybits) b.pos += ybits[t]; else bs_coeff_any<E, SP_LDS>(b, tm, cy + t * sty, size / 2, coeff_type | 0); }
       }
-      bs_vlc(b, 13, (uint32_t)(p.cbp_u + 2 * p.cbp_v));
-      if (p.cbp_u) bs_coeff_any(b, tm, cu, size_uv, coeff_type | 1);
-      if (p.cbp_v) bs_coeff_any(b, tm, cv, size_uv, coeff_type | 1);
+      bs_vlc_t<E>(b, 13, (uint32_t)(p.cbp_u + 2 * p.cbp_v));
+      if (p.cbp_u) bs_coeff_any<E, SCC>(b, tm, cu, size_uv, coeff_type | 1);
+      if (p.cbp_v) bs_coeff_any<E, SCC>(b, tm, cv, size_uv, coeff_type | 1);
     }
   }
   return b.pos - start;
 }
-
 }  // namespace tk

@@ -113,10 +113,19 @@ template <typename PIX> struct TeamWs {  // view (lives in registers)
   const PIX *org_y, *org_u, *org_v;  // original samples of the current coding block (origin), strides org_sy / org_sc
   int org_sy, org_sc;
 };
+// On the device the per-wave view and the frame job live in LDS and are passed around as LDS-typed pointer / reference
+// (ds_read of the members instead of generic loads); plain pointer / reference on the host.
+#if TK_HOST
+template <typename PIX> using WsP = TeamWs<PIX>*;
+template <typename PIX> using JobR = const FrameJob<PIX>&;
+#else
+template <typename PIX> using WsP = TK_LDS TeamWs<PIX>*;
+template <typename PIX> using JobR = const TK_LDS FrameJob<PIX>&;
+#endif
 // Point the sample-block views at the LDS buffers (coding blocks up to kLdsBlk) or at the global scratch slot.
-template <typename PIX> TK_DEV void ws_select(TeamWs<PIX>* w, int size) {
+template <class WP> TK_DEV void ws_select(WP w, int size) {  // WP: TeamWs<PIX>* in any address space
   if (size <= kLdsBlk) {
-    PIX* b = w->lbuf;
+    auto b = w->lbuf;
     const int n = size * size, c = n >> 2;
     w->pred_y = b; w->pred_u = b + n; w->pred_v = b + n + c; b += n + 2 * c;
     w->p0_y = b; w->p0_u = b + n; w->p0_v = b + n + c; b += n + 2 * c;
@@ -124,7 +133,7 @@ template <typename PIX> TK_DEV void ws_select(TeamWs<PIX>* w, int size) {
     w->rec_y = b; w->rec_u = b + n; w->rec_v = b + n + c; b += n + 2 * c;
     w->org8 = b;
   } else {
-    BigWs<PIX>* g = w->big;
+    auto g = w->big;
     w->pred_y = g->pred_y; w->pred_u = g->pred_u; w->pred_v = g->pred_v;
     w->p0_y = g->p0_y; w->p0_u = g->p0_u; w->p0_v = g->p0_v;
     w->p1_y = g->p1_y; w->p1_u = g->p1_u; w->p1_v = g->p1_v;
@@ -134,7 +143,7 @@ template <typename PIX> TK_DEV void ws_select(TeamWs<PIX>* w, int size) {
 // Point ws->org_* at the original samples of coding block `nd`: the frame planes, or (blocks up to kLdsBlk) the
 // workgroup's LDS copy, which the master fills with load = 1 before any wave uses it.
 template <typename PIX>
-TK_DEV void org_select(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* w, int size, int ypos, int xpos, int bw, int bh, int load) {
+TK_DEV void org_select(const Team t, JobR<PIX> J, WsP<PIX> w, int size, int ypos, int xpos, int bw, int bh, int load) {
   if (size <= kLdsBlk) {
     PIX* b = (PIX*)w->sh->org_raw;
     const int n = size * size, sc = size >> 1;
@@ -144,12 +153,13 @@ TK_DEV void org_select(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* w, int
       const TK_GLOBAL PIX* gy = gptr(J.orig.y + ypos * J.orig.sy + xpos);
       const TK_GLOBAL PIX* gu = gptr(J.orig.u + (ypos >> 1) * J.orig.sc + (xpos >> 1));
       const TK_GLOBAL PIX* gv = gptr(J.orig.v + (ypos >> 1) * J.orig.sc + (xpos >> 1));
-      for (int k = t.rank; k < bw * bh; k += t.size) { int i, j; split2(dw, k, i, j); b[i * size + j] = gy[i * J.orig.sy + j]; }
+      const auto bl = ldsc(b);
+      for (int k = t.rank; k < bw * bh; k += t.size) { int i, j; split2(dw, k, i, j); bl[i * size + j] = gy[i * J.orig.sy + j]; }
       for (int k = t.rank; k < (bw >> 1) * (bh >> 1); k += t.size) {
         int i, j;
         split2(dc, k, i, j);
-        b[n + i * sc + j] = gu[i * J.orig.sc + j];
-        b[n + (n >> 2) + i * sc + j] = gv[i * J.orig.sc + j];
+        bl[n + i * sc + j] = gu[i * J.orig.sc + j];
+        bl[n + (n >> 2) + i * sc + j] = gv[i * J.orig.sc + j];
       }
       t.sync();
     }
@@ -294,11 +304,14 @@ TK_DEV void find_contexts(const DbCell* cells, int cs, int ypos, int xpos, int f
 // ---------------------------------------------------------------------------------
 // SSD / cost
 // ---------------------------------------------------------------------------------
-template <typename PIX>
-TK_DEV void ssd_acc(const Team t, unsigned long long* acc, const PIX* a, int as, const PIX* b, int bs, int w, int h) {
+// SP: address space of both sample blocks; acc lives in LDS
+template <int SP, typename PIX>
+TK_DEV void ssd_acc(const Team t, unsigned long long* acc, const PIX* a_, int as, const PIX* b_, int bs, int w, int h) {
 #ifdef THOR_EXP_UNIFORM
-  acc = tk_uniform_ptr(acc); a = tk_uniform_ptr(a); b = tk_uniform_ptr(b); as = tk_uniform(as); bs = tk_uniform(bs); w = tk_uniform(w); h = tk_uniform(h);
+  acc = tk_uniform_ptr(acc); a_ = tk_uniform_ptr(a_); b_ = tk_uniform_ptr(b_); as = tk_uniform(as); bs = tk_uniform(bs); w = tk_uniform(w); h = tk_uniform(h);
 #endif
+  const auto a = spc<SP>(a_);
+  const auto b = spc<SP>(b_);
   unsigned long long local = 0;
   if ((w & (w - 1)) == 0) {  // every width except the frame-edge rectangles
     const Pow2 pw = mk_pow2(w);
@@ -317,22 +330,25 @@ TK_DEV void ssd_acc(const Team t, unsigned long long* acc, const PIX* a, int as,
   }
   // butterfly reduction + one writer instead of 64 same-address LDS atomics (the callers sync before reading)
   local = team_sum64(t, local);
-  if (t.rank == 0) *acc += local;
+  if (t.rank == 0) *ldsc(acc) += local;
 }
 
 // cost_calc (encode_block.c:916-926) on the trial recon in ws->rec_* vs. the original frame.
-template <typename PIX>
-TK_DEVNI unsigned rd_cost(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int nbits, double lambda,
+template <typename PIX, int SP>
+TK_DEVNI unsigned rd_cost(const Team t, JobR<PIX> J, WsP<PIX> ws, const Node& nd_, int nbits, double lambda,
                          long long ssd_y = -1) {
   TK_PROF_T0();
-  if (t.rank == 0) ws->acc[0] = ssd_y >= 0 ? (unsigned long long)ssd_y : 0ull;
+  const auto nd = ldsc(&nd_);
+  const auto acc = ldsc(ws->acc);
+  const int size = TKU(nd->size), bw = TKU(nd->bw), bh = TKU(nd->bh);
+  if (t.rank == 0) acc[0] = ssd_y >= 0 ? (unsigned long long)ssd_y : 0ull;
   t.sync();
-  const int yc = nd.ypos >> 1, xc = nd.xpos >> 1, sc = nd.size >> 1;
-  if (ssd_y < 0) ssd_acc(t, &ws->acc[0], ws->org_y, ws->org_sy, ws->rec_y, nd.size, nd.bw, nd.bh);
-  ssd_acc(t, &ws->acc[0], ws->org_u, ws->org_sc, ws->rec_u, sc, nd.bw >> 1, nd.bh >> 1);
-  ssd_acc(t, &ws->acc[0], ws->org_v, ws->org_sc, ws->rec_v, sc, nd.bw >> 1, nd.bh >> 1);
+  const int sc = size >> 1;
+  if (ssd_y < 0) ssd_acc<SP>(t, &ws->acc[0], ws->org_y, ws->org_sy, ws->rec_y, size, bw, bh);
+  ssd_acc<SP>(t, &ws->acc[0], ws->org_u, ws->org_sc, ws->rec_u, sc, bw >> 1, bh >> 1);
+  ssd_acc<SP>(t, &ws->acc[0], ws->org_v, ws->org_sc, ws->rec_v, sc, bw >> 1, bh >> 1);
   t.sync();
-  unsigned long long ssd = ws->acc[0];
+  unsigned long long ssd = acc[0];
   t.sync();
   unsigned long long cost = (ssd >> (J.cfg.bitdepth * 2 - 16)) + (unsigned long long)(long long)mul_add_nofma(lambda, (double)nbits, 0.5);
   if (cost > (1ull << 30)) cost = 1ull << 30;
@@ -344,11 +360,13 @@ TK_DEVNI unsigned rd_cost(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
 // Chroma-from-luma (common_block.c:347-428).  y: luma prediction (stride n), u/v: chroma
 // prediction (stride cstride>>1), ry: reconstructed luma (stride `stride`), n = luma size.
 // ---------------------------------------------------------------------------------
-template <typename PIX>
-TK_DEVNI void improve_uv(const Team t, TeamWs<PIX>* ws, const PIX* y, PIX* u, PIX* v, const PIX* ry, int n, int cstride,
+template <typename PIX, int SP>
+TK_DEVNI void improve_uv(const Team t, WsP<PIX> ws, const PIX* y_, PIX* u_, PIX* v_, const PIX* ry_, int n, int cstride,
                        int stride, int bitdepth) {
+  const auto y = spc<SP>(y_); const auto u = spc<SP>(u_); const auto v = spc<SP>(v_); const auto ry = spc<SP>(ry_);
+  const auto acc = ldsc(ws->acc);
   const int nc = n >> 1, lognc = ilog2(nc), cs = cstride >> 1;
-  for (int k = t.rank; k < 9; k += t.size) ws->acc[k] = 0;
+  for (int k = t.rank; k < 9; k += t.size) acc[k] = 0;
   t.sync();
   {
     unsigned long long local = 0;
@@ -359,10 +377,10 @@ TK_DEVNI void improve_uv(const Team t, TeamWs<PIX>* ws, const PIX* y, PIX* u, PI
       local += (unsigned long long)(d * d);
     }
     local = team_sum64(t, local);
-    if (t.rank == 0) ws->acc[0] += local;
+    if (t.rank == 0) acc[0] += local;
   }
   t.sync();
-  long long sq = (long long)ws->acc[0];
+  long long sq = (long long)acc[0];
   if ((sq >> (2 * ilog2(n))) <= (64ll << (2 * (bitdepth - 8)))) { t.sync(); return; }
   {
     unsigned long long ls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -377,12 +395,12 @@ TK_DEVNI void improve_uv(const Team t, TeamWs<PIX>* ws, const PIX* y, PIX* u, PI
     }
     for (int q = 0; q < 8; q++) {
       const unsigned long long tot = team_sum64(t, ls[q]);
-      if (t.rank == 0) ws->acc[1 + q] += tot;
+      if (t.rank == 0) acc[1 + q] += tot;
     }
   }
   t.sync();
-  const long long ysum = ws->acc[1], usum = ws->acc[2], vsum = ws->acc[3], yysum = ws->acc[4], yusum = ws->acc[5],
-                  yvsum = ws->acc[6], uusum = ws->acc[7], vvsum = ws->acc[8];
+  const long long ysum = acc[1], usum = acc[2], vsum = acc[3], yysum = acc[4], yusum = acc[5],
+                  yvsum = acc[6], uusum = acc[7], vvsum = acc[8];
   t.sync();
   const long long ssyy = yysum - ((ysum * ysum) >> (lognc * 2));
   const long long ssuu = uusum - ((usum * usum) >> (lognc * 2));
@@ -392,7 +410,7 @@ TK_DEVNI void improve_uv(const Team t, TeamWs<PIX>* ws, const PIX* y, PIX* u, PI
   if (!ssyy) return;
   for (int pl = 0; pl < 2; pl++) {
     const long long ssyc = pl ? ssyv : ssyu, sscc = pl ? ssvv : ssuu, csum = pl ? vsum : usum;
-    PIX* c = pl ? v : u;
+    const auto c = pl ? v : u;
     if (ssyc * ssyc * 2 > ssyy * sscc) {
       long long a64 = (ssyc << 16) / ssyy;
       long long b64 = ((csum << 16) - a64 * ysum) >> (lognc * 2);
@@ -420,22 +438,24 @@ TK_DEVNI void improve_uv(const Team t, TeamWs<PIX>* ws, const PIX* y, PIX* u, PI
 // encode_block (encode_block.c:1340-1514): prediction + residual coding of one CB into the trial
 // buffers ws->rec_* / ws->coef_*; returns the number of bits of write_block.  `bs` counts or emits.
 // ---------------------------------------------------------------------------------
-template <typename PIX>
-TK_DEV void predict_inter(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, const BlkParam& p,
+template <typename PIX, int SP>
+TK_DEV void predict_inter(const Team t, JobR<PIX> J, WsP<PIX> ws, const Node& nd_, const BlkParam& p,
                           int split) {
+  const auto ndl = ldsc(&nd_);
+  struct { int ypos, xpos, size, bw, bh; } nd = {TKU(ndl->ypos), TKU(ndl->xpos), TKU(ndl->size), TKU(ndl->bw), TKU(ndl->bh)};
   TK_PROF_T0();
-  const EncCfg& c = J.cfg;
+  const auto& c = J.cfg;
   const int bi = (p.mode == M_BIPRED) || ((p.mode == M_SKIP || p.mode == M_MERGE) && p.dir == 2);
   if (bi) {
-    pred_inter_yuv(t, J.ref[p.ref0], ws->p0_y, ws->p0_u, ws->p0_v, nd.ypos, nd.xpos, nd.size, nd.bw, nd.bh, p.mv0,
+    pred_inter_yuv<SP>(t, lds_ld(&J.ref[p.ref0]), ws->p0_y, ws->p0_u, ws->p0_v, nd.ypos, nd.xpos, nd.size, nd.bw, nd.bh, p.mv0,
                    J.sign[p.ref0], c.width, c.height, c.enable_bipred, split, c.bitdepth);
-    pred_inter_yuv(t, J.ref[p.ref1], ws->p1_y, ws->p1_u, ws->p1_v, nd.ypos, nd.xpos, nd.size, nd.bw, nd.bh, p.mv1,
+    pred_inter_yuv<SP>(t, lds_ld(&J.ref[p.ref1]), ws->p1_y, ws->p1_u, ws->p1_v, nd.ypos, nd.xpos, nd.size, nd.bw, nd.bh, p.mv1,
                    J.sign[p.ref1], c.width, c.height, c.enable_bipred, split, c.bitdepth);
     t.sync();
-    average_yuv(t, ws->pred_y, ws->pred_u, ws->pred_v, ws->p0_y, ws->p0_u, ws->p0_v, ws->p1_y, ws->p1_u, ws->p1_v,
+    average_yuv<SP>(t, ws->pred_y, ws->pred_u, ws->pred_v, ws->p0_y, ws->p0_u, ws->p0_v, ws->p1_y, ws->p1_u, ws->p1_v,
                 nd.size, nd.bw, nd.bh);
   } else {
-    pred_inter_yuv(t, J.ref[p.ref0], ws->pred_y, ws->pred_u, ws->pred_v, nd.ypos, nd.xpos, nd.size, nd.bw, nd.bh,
+    pred_inter_yuv<SP>(t, lds_ld(&J.ref[p.ref0]), ws->pred_y, ws->pred_u, ws->pred_v, nd.ypos, nd.xpos, nd.size, nd.bw, nd.bh,
                    p.mv0, J.sign[p.ref0], c.width, c.height, c.enable_bipred, split, c.bitdepth);
   }
   t.sync();
@@ -474,18 +494,19 @@ TK_DEV int prune_hit(const PruneCtx* pc, unsigned long long lb) {
   return lb >= (unsigned long long)pc->thr;
 }
 
-template <typename PIX>
-TK_DEV int prune_after_quadrant(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int intra, int tu, int i, int j,
+template <typename PIX, int SP>
+TK_DEV int prune_after_quadrant(const Team t, JobR<PIX> J, WsP<PIX> ws, int nd_size, int intra, int tu, int i, int j,
                                 int s2, int bit, const int16_t* coef, PruneCtx* pc) {
   if (!prune_active(pc)) return 0;
+  const auto acc = ldsc(ws->acc);
   t.sync();
-  if (t.rank == 0) ws->acc[1] = 0;
+  if (t.rank == 0) acc[1] = 0;
   t.sync();
-  ssd_acc(t, &ws->acc[1], ws->org_y + i * ws->org_sy + j, ws->org_sy, ws->rec_y + i * nd.size + j, nd.size, s2, s2);
+  ssd_acc<SP>(t, &ws->acc[1], ws->org_y + i * ws->org_sy + j, ws->org_sy, ws->rec_y + i * nd_size + j, nd_size, s2, s2);
   t.sync();
-  pc->ssd_part += (long long)ws->acc[1];
+  pc->ssd_part += (long long)acc[1];
   t.sync();
-  pc->ybits[tu] = bit ? coeff_bits_team(t, coef, s2, intra << 1) : 0;
+  pc->ybits[tu] = bit ? coeff_bits_team<SP_LDS>(t, coef, s2, intra << 1) : 0;  // luma coefficients: always SmallWs (LDS)
   pc->bits_part += pc->ybits[tu];
   if (tu == 3) { pc->ssd_y = pc->ssd_part; pc->have_ybits = 1; }
   unsigned long long lb = ((unsigned long long)pc->ssd_part >> (J.cfg.bitdepth * 2 - 16)) + (unsigned long long)(long long)mul_add_nofma(pc->lambda, (double)pc->bits_part, 0.5);
@@ -497,30 +518,30 @@ TK_DEV int prune_after_quadrant(const Team t, const FrameJob<PIX>& J, TeamWs<PIX
   return 0;
 }
 
-template <typename PIX>
-TK_DEV int prune_after_luma(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, const BlkParam& p, int cbp_y,
+template <typename PIX, int SP>
+TK_DEV int prune_after_luma(const Team t, JobR<PIX> J, WsP<PIX> ws, int size, int bw, int bh, const BlkParam& p, int cbp_y,
                             int tb_split, PruneCtx* pc) {
   if (!prune_active(pc)) return 0;
   if (pc->pruned) return 1;
   if (pc->have_ybits) return 0;  // tb-split luma: bound already evaluated quadrant by quadrant
-  const int size = nd.size;
+  const auto acc = ldsc(ws->acc);
   t.sync();
-  if (t.rank == 0) ws->acc[1] = 0;
+  if (t.rank == 0) acc[1] = 0;
   t.sync();
-  ssd_acc(t, &ws->acc[1], ws->org_y, ws->org_sy, ws->rec_y, size, nd.bw, nd.bh);
+  ssd_acc<SP>(t, &ws->acc[1], ws->org_y, ws->org_sy, ws->rec_y, size, bw, bh);
   t.sync();
-  const unsigned long long ssd = ws->acc[1];
+  const unsigned long long ssd = acc[1];
   t.sync();
   pc->ssd_y = (long long)ssd;
   const int coeff_type = (p.mode == M_INTRA) << 1;
   int bits = 0;
   if (!tb_split) {
-    pc->ybits[0] = cbp_y ? coeff_bits_team(t, ws->coef_y, size, coeff_type) : 0;
+    pc->ybits[0] = cbp_y ? coeff_bits_team<SP_LDS>(t, ws->coef_y, size, coeff_type) : 0;
     bits = pc->ybits[0];
   } else {
     const int qy = size / 2 < kMaxQuant ? size / 2 : kMaxQuant;
     for (int tu = 0; tu < 4; tu++) {
-      pc->ybits[tu] = ((cbp_y >> (3 - tu)) & 1) ? coeff_bits_team(t, ws->coef_y + tu * qy * qy, size / 2, coeff_type) : 0;
+      pc->ybits[tu] = ((cbp_y >> (3 - tu)) & 1) ? coeff_bits_team<SP_LDS>(t, ws->coef_y + tu * qy * qy, size / 2, coeff_type) : 0;
       bits += pc->ybits[tu];
     }
   }
@@ -535,24 +556,25 @@ TK_DEV int prune_after_luma(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* w
 }
 
 // residual coding of one plane of an inter block (encode_and_reconstruct_block_inter :1275-1338)
-template <typename PIX>
-TK_DEV int code_inter_plane(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const PIX* org, int ostride,
+// SP: address space of org / pred / rec, SC: of coef.  nd_size > 0: luma plane of a block of that size with pruning context pc.
+template <typename PIX, int SP, int SC>
+TK_DEV int code_inter_plane(const Team t, JobR<PIX> J, WsP<PIX> ws, const PIX* org, int ostride,
                             const PIX* pred, PIX* rec, int size, int qp, int coeff_type, int tb_split, int16_t* coef,
-                            const Node* nd = nullptr, PruneCtx* pc = nullptr) {
+                            int nd_size = 0, PruneCtx* pc = nullptr) {
   const int bd = J.cfg.bitdepth;
   if (!tb_split) {
     int fast = (size == 64 && J.cfg.encoder_speed > 0) || J.cfg.encoder_speed > 1;
-    return code_tu(t, ws->xfp, org, ostride, pred, size, rec, size, size, qp, coeff_type, fast, coef, bd);
+    return code_tu_sp<PIX, SP, SC>(t, ws->xfp, org, ostride, pred, size, rec, size, size, qp, coeff_type, fast, coef, bd);
   }
   const int s2 = size / 2;
   int cbp = 0, index = 0;
   for (int i = 0; i < size; i += s2)
     for (int j = 0; j < size; j += s2) {
       int fast = size == 64 || J.cfg.encoder_speed > 1;
-      int bit = code_tu(t, ws->xfp, org + i * ostride + j, ostride, pred + i * size + j, size, rec + i * size + j, size,
+      int bit = code_tu_sp<PIX, SP, SC>(t, ws->xfp, org + i * ostride + j, ostride, pred + i * size + j, size, rec + i * size + j, size,
                         s2, qp, coeff_type, fast, coef + index, bd);
       cbp = (cbp << 1) + bit;
-      if (nd && prune_after_quadrant(t, J, ws, *nd, 0, (i ? 2 : 0) + (j ? 1 : 0), i, j, s2, bit, coef + index, pc)) return cbp;
+      if (nd_size && prune_after_quadrant<PIX, SP>(t, J, ws, nd_size, 0, (i ? 2 : 0) + (j ? 1 : 0), i, j, s2, bit, coef + index, pc)) return cbp;
       index += tmin(s2, 16) * tmin(s2, 16);
     }
   return cbp;
@@ -560,23 +582,25 @@ TK_DEV int code_inter_plane(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* w
 
 // reuse_pred: the inter prediction of this (mode, refs, MVs) is already in ws->pred_* (previous trial
 // of the same candidate with another tb_param) - exact, the prediction does not depend on tb_param.
-template <typename PIX>
-TK_DEVNI int encode_block(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BlkParam& p, BitSink& bs,
+// SP: address space of the coding block's sample buffers and original samples (SP_LDS for blocks up to kLdsBlk).
+template <typename PIX, int SP>
+TK_DEVNI int encode_block(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd_, BlkParam& p, BitSink& bs,
                           int reuse_pred = 0, PruneCtx* pc = nullptr) {
-  const EncCfg& c = J.cfg;
-  const int size = TKU(nd.size), sizeC = size >> 1;
-  const int yc = TKU(nd.ypos) >> 1, xc = TKU(nd.xpos) >> 1;
+  const auto& c = J.cfg;
+  const auto ndl = ldsc(&nd_);
+  struct { int size, ypos, xpos, bw, bh; } nd = {TKU(ndl->size), TKU(ndl->ypos), TKU(ndl->xpos), TKU(ndl->bw), TKU(ndl->bh)};
+  const int size = nd.size, sizeC = size >> 1;
+  const int yc = nd.ypos >> 1, xc = nd.xpos >> 1;
   const int qpY = TKU(J.qp), qpC = TK_TAB.chroma_qp[qpY];
   const int tb_split = TKU(p.tb_param) > 0 ? TKU(p.tb_param) : 0;
   const int zero_block = TKU(p.tb_param) == -1;
   const int ftI = (TKU(J.frame_type) == F_I) << 1;
   const int bd = TKU(c.bitdepth);
   p.tb_split = (int8_t)tb_split;
-  {
-    const int bigc = tb_split && sizeC >= 32;  // 4 chroma TUs of 16x16 coefficients
-    ws->coef_u = bigc ? ws->coef_u_big : ws->coef_u_small;
-    ws->coef_v = bigc ? ws->coef_v_big : ws->coef_v_small;
-  }
+  // chroma coefficients: SmallWs (LDS) except the 4 x 16x16 units of tb-split 64 / 128 blocks (global scratch)
+  const int bigc = SP == SP_GLOBAL && tb_split && sizeC >= 32;
+  ws->coef_u = bigc ? ws->coef_u_big : ws->coef_u_small;
+  ws->coef_v = bigc ? ws->coef_v_big : ws->coef_v_small;
   const PIX* oy = ws->org_y;
   const PIX* ou = ws->org_u;
   const PIX* ov = ws->org_v;
@@ -595,23 +619,23 @@ TK_DEVNI int encode_block(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
       int index = 0;
       for (int i = 0; i < size; i += s2)
         for (int j = 0; j < size; j += s2) {
-          make_edges(t, ws->edgep, fy, J.rec.sy, ws->rec_y + i * size + j, size, i, j, nd.ypos, nd.xpos, s2, ur, dl, 1, bd);
-          pred_intra(t, ws->edgep, nd.ypos + i, nd.xpos + j, s2, ws->pred_y + i * size + j, size, p.intra_mode, bd);
+          make_edges<SP>(t, ws->edgep, fy, J.rec.sy, ws->rec_y + i * size + j, size, i, j, nd.ypos, nd.xpos, s2, ur, dl, 1, bd);
+          pred_intra<SP>(t, ws->edgep, nd.ypos + i, nd.xpos + j, s2, ws->pred_y + i * size + j, size, p.intra_mode, bd);
           t.sync();
-          int bit = code_tu(t, ws->xfp, oy + i * osy + j, osy, ws->pred_y + i * size + j, size,
+          int bit = code_tu_sp<PIX, SP, SP_LDS>(t, ws->xfp, oy + i * osy + j, osy, ws->pred_y + i * size + j, size,
                             ws->rec_y + i * size + j, size, s2, qpY, ftI | 0, c.encoder_speed > 1, ws->coef_y + index, bd);
           cbp_y = (cbp_y << 1) + bit;
-          if (prune_after_quadrant(t, J, ws, nd, 1, (i ? 2 : 0) + (j ? 1 : 0), i, j, s2, bit, ws->coef_y + index, pc)) return 0;
+          if (prune_after_quadrant<PIX, SP>(t, J, ws, size, 1, (i ? 2 : 0) + (j ? 1 : 0), i, j, s2, bit, ws->coef_y + index, pc)) return 0;
           index += tmin(s2, 16) * tmin(s2, 16);
         }
     } else {
-      make_edges(t, ws->edgep, fy, J.rec.sy, (const PIX*)nullptr, 0, 0, 0, nd.ypos, nd.xpos, size, ur, dl, 0, bd);
-      pred_intra(t, ws->edgep, nd.ypos, nd.xpos, size, ws->pred_y, size, p.intra_mode, bd);
+      make_edges<SP>(t, ws->edgep, fy, J.rec.sy, (const PIX*)nullptr, 0, 0, 0, nd.ypos, nd.xpos, size, ur, dl, 0, bd);
+      pred_intra<SP>(t, ws->edgep, nd.ypos, nd.xpos, size, ws->pred_y, size, p.intra_mode, bd);
       t.sync();
-      cbp_y = code_tu(t, ws->xfp, oy, osy, ws->pred_y, size, ws->rec_y, size, size, qpY, ftI | 0,
+      cbp_y = code_tu_sp<PIX, SP, SP_LDS>(t, ws->xfp, oy, osy, ws->pred_y, size, ws->rec_y, size, size, qpY, ftI | 0,
                       c.encoder_speed > 1, ws->coef_y, bd);
     }
-    if (prune_after_luma(t, J, ws, nd, p, cbp_y, tb_split, pc)) return 0;
+    if (prune_after_luma<PIX, SP>(t, J, ws, size, nd.bw, nd.bh, p, cbp_y, tb_split, pc)) return 0;
     // chroma (encode_and_reconstruct_block_intra_uv :1170-1273)
     const int csplit = tb_split && sizeC > 4;
     if (csplit) {
@@ -619,80 +643,96 @@ TK_DEVNI int encode_block(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
       int index = 0;
       for (int i = 0; i < sizeC; i += s2)
         for (int j = 0; j < sizeC; j += s2) {
-          make_edges(t, ws->edgep, fu, J.rec.sc, ws->rec_u + i * sizeC + j, sizeC, i, j, yc, xc, s2, ur, dl, 1, bd);
-          pred_intra(t, ws->edgep, yc + i, xc + j, s2, ws->pred_u + i * sizeC + j, sizeC, p.intra_mode, bd);
+          make_edges<SP>(t, ws->edgep, fu, J.rec.sc, ws->rec_u + i * sizeC + j, sizeC, i, j, yc, xc, s2, ur, dl, 1, bd);
+          pred_intra<SP>(t, ws->edgep, yc + i, xc + j, s2, ws->pred_u + i * sizeC + j, sizeC, p.intra_mode, bd);
           t.sync();
-          make_edges(t, ws->edgep, fv, J.rec.sc, ws->rec_v + i * sizeC + j, sizeC, i, j, yc, xc, s2, ur, dl, 1, bd);
-          pred_intra(t, ws->edgep, yc + i, xc + j, s2, ws->pred_v + i * sizeC + j, sizeC, p.intra_mode, bd);
+          make_edges<SP>(t, ws->edgep, fv, J.rec.sc, ws->rec_v + i * sizeC + j, sizeC, i, j, yc, xc, s2, ur, dl, 1, bd);
+          pred_intra<SP>(t, ws->edgep, yc + i, xc + j, s2, ws->pred_v + i * sizeC + j, sizeC, p.intra_mode, bd);
           t.sync();
           if (c.cfl_intra)  // sic: luma pointers offset in CHROMA units (encode_block.c:1199)
-            improve_uv(t, ws, ws->pred_y + i * sizeC + j, ws->pred_u + i * sizeC + j, ws->pred_v + i * sizeC + j,
+            improve_uv<PIX, SP>(t, ws, ws->pred_y + i * sizeC + j, ws->pred_u + i * sizeC + j, ws->pred_v + i * sizeC + j,
                        ws->rec_y + (i << 1) * size + (j << 1), s2 << 1, sizeC << 1, size, bd);
-          int bu = code_tu(t, ws->xfp, ou + i * osc + j, osc, ws->pred_u + i * sizeC + j, sizeC,
-                           ws->rec_u + i * sizeC + j, sizeC, s2, qpC, ftI | 1, c.encoder_speed > 1, ws->coef_u + index, bd);
+          int bu, bv;
+          if (bigc) {
+            bu = code_tu_sp<PIX, SP, SP_GLOBAL>(t, ws->xfp, ou + i * osc + j, osc, ws->pred_u + i * sizeC + j, sizeC,
+                             ws->rec_u + i * sizeC + j, sizeC, s2, qpC, ftI | 1, c.encoder_speed > 1, ws->coef_u + index, bd);
+            bv = code_tu_sp<PIX, SP, SP_GLOBAL>(t, ws->xfp, ov + i * osc + j, osc, ws->pred_v + i * sizeC + j, sizeC,
+                             ws->rec_v + i * sizeC + j, sizeC, s2, qpC, ftI | 1, c.encoder_speed > 1, ws->coef_v + index, bd);
+          } else {
+            bu = code_tu_sp<PIX, SP, SP_LDS>(t, ws->xfp, ou + i * osc + j, osc, ws->pred_u + i * sizeC + j, sizeC,
+                             ws->rec_u + i * sizeC + j, sizeC, s2, qpC, ftI | 1, c.encoder_speed > 1, ws->coef_u + index, bd);
+            bv = code_tu_sp<PIX, SP, SP_LDS>(t, ws->xfp, ov + i * osc + j, osc, ws->pred_v + i * sizeC + j, sizeC,
+                             ws->rec_v + i * sizeC + j, sizeC, s2, qpC, ftI | 1, c.encoder_speed > 1, ws->coef_v + index, bd);
+          }
           cbp_u = (cbp_u << 1) + bu;
-          int bv = code_tu(t, ws->xfp, ov + i * osc + j, osc, ws->pred_v + i * sizeC + j, sizeC,
-                           ws->rec_v + i * sizeC + j, sizeC, s2, qpC, ftI | 1, c.encoder_speed > 1, ws->coef_v + index, bd);
           cbp_v = (cbp_v << 1) + bv;
           index += tmin(s2, 16) * tmin(s2, 16);
         }
     } else {
-      make_edges(t, ws->edgep, fu, J.rec.sc, (const PIX*)nullptr, 0, 0, 0, yc, xc, sizeC, ur, dl, 0, bd);
-      pred_intra(t, ws->edgep, yc, xc, sizeC, ws->pred_u, sizeC, p.intra_mode, bd);
+      make_edges<SP>(t, ws->edgep, fu, J.rec.sc, (const PIX*)nullptr, 0, 0, 0, yc, xc, sizeC, ur, dl, 0, bd);
+      pred_intra<SP>(t, ws->edgep, yc, xc, sizeC, ws->pred_u, sizeC, p.intra_mode, bd);
       t.sync();
-      make_edges(t, ws->edgep, fv, J.rec.sc, (const PIX*)nullptr, 0, 0, 0, yc, xc, sizeC, ur, dl, 0, bd);
-      pred_intra(t, ws->edgep, yc, xc, sizeC, ws->pred_v, sizeC, p.intra_mode, bd);
+      make_edges<SP>(t, ws->edgep, fv, J.rec.sc, (const PIX*)nullptr, 0, 0, 0, yc, xc, sizeC, ur, dl, 0, bd);
+      pred_intra<SP>(t, ws->edgep, yc, xc, sizeC, ws->pred_v, sizeC, p.intra_mode, bd);
       t.sync();
-      if (c.cfl_intra) improve_uv(t, ws, ws->pred_y, ws->pred_u, ws->pred_v, ws->rec_y, size, size, size, bd);
-      cbp_u = code_tu(t, ws->xfp, ou, osc, ws->pred_u, sizeC, ws->rec_u, sizeC, sizeC, qpC, ftI | 1,
+      if (c.cfl_intra) improve_uv<PIX, SP>(t, ws, ws->pred_y, ws->pred_u, ws->pred_v, ws->rec_y, size, size, size, bd);
+      cbp_u = code_tu_sp<PIX, SP, SP_LDS>(t, ws->xfp, ou, osc, ws->pred_u, sizeC, ws->rec_u, sizeC, sizeC, qpC, ftI | 1,
                       c.encoder_speed > 1, ws->coef_u, bd);
-      cbp_v = code_tu(t, ws->xfp, ov, osc, ws->pred_v, sizeC, ws->rec_v, sizeC, sizeC, qpC, ftI | 1,
+      cbp_v = code_tu_sp<PIX, SP, SP_LDS>(t, ws->xfp, ov, osc, ws->pred_v, sizeC, ws->rec_v, sizeC, sizeC, qpC, ftI | 1,
                       c.encoder_speed > 1, ws->coef_v, bd);
     }
   } else {
     const int split = (TKU(p.mode) == M_INTER || TKU(p.mode) == M_BIPRED) ? c.enable_pb_split : 0;
-    if (!(reuse_pred && !c.cfl_inter)) predict_inter(t, J, ws, nd, p, split);
+    if (!(reuse_pred && !c.cfl_inter)) predict_inter<PIX, SP>(t, J, ws, nd_, p, split);
     if (TKU(p.mode) == M_SKIP || zero_block) {
-      copy_block(t, ws->rec_y, size, ws->pred_y, size, nd.bw, nd.bh);
-      copy_block(t, ws->rec_u, sizeC, ws->pred_u, sizeC, nd.bw >> 1, nd.bh >> 1);
-      copy_block(t, ws->rec_v, sizeC, ws->pred_v, sizeC, nd.bw >> 1, nd.bh >> 1);
+      copy_block<SP, SP>(t, ws->rec_y, size, ws->pred_y, size, nd.bw, nd.bh);
+      copy_block<SP, SP>(t, ws->rec_u, sizeC, ws->pred_u, sizeC, nd.bw >> 1, nd.bh >> 1);
+      copy_block<SP, SP>(t, ws->rec_v, sizeC, ws->pred_v, sizeC, nd.bw >> 1, nd.bh >> 1);
       t.sync();
     } else {
-      cbp_y = code_inter_plane(t, J, ws, oy, osy, ws->pred_y, ws->rec_y, size, qpY, ftI | 0, tb_split, ws->coef_y, &nd, pc);
-      if (prune_after_luma(t, J, ws, nd, p, cbp_y, tb_split, pc)) return 0;
-      if (c.cfl_inter) improve_uv(t, ws, ws->pred_y, ws->pred_u, ws->pred_v, ws->rec_y, size, size, size, bd);
+      cbp_y = code_inter_plane<PIX, SP, SP_LDS>(t, J, ws, oy, osy, ws->pred_y, ws->rec_y, size, qpY, ftI | 0, tb_split, ws->coef_y, size, pc);
+      if (prune_after_luma<PIX, SP>(t, J, ws, size, nd.bw, nd.bh, p, cbp_y, tb_split, pc)) return 0;
+      if (c.cfl_inter) improve_uv<PIX, SP>(t, ws, ws->pred_y, ws->pred_u, ws->pred_v, ws->rec_y, size, size, size, bd);
       const int csplit = tb_split && sizeC > 4;
-      cbp_u = code_inter_plane(t, J, ws, ou, osc, ws->pred_u, ws->rec_u, sizeC, qpC, ftI | 1, csplit, ws->coef_u);
-      cbp_v = code_inter_plane(t, J, ws, ov, osc, ws->pred_v, ws->rec_v, sizeC, qpC, ftI | 1, csplit, ws->coef_v);
+      if (bigc) {
+        cbp_u = code_inter_plane<PIX, SP, SP_GLOBAL>(t, J, ws, ou, osc, ws->pred_u, ws->rec_u, sizeC, qpC, ftI | 1, csplit, ws->coef_u);
+        cbp_v = code_inter_plane<PIX, SP, SP_GLOBAL>(t, J, ws, ov, osc, ws->pred_v, ws->rec_v, sizeC, qpC, ftI | 1, csplit, ws->coef_v);
+      } else {
+        cbp_u = code_inter_plane<PIX, SP, SP_LDS>(t, J, ws, ou, osc, ws->pred_u, ws->rec_u, sizeC, qpC, ftI | 1, csplit, ws->coef_u);
+        cbp_v = code_inter_plane<PIX, SP, SP_LDS>(t, J, ws, ov, osc, ws->pred_v, ws->rec_v, sizeC, qpC, ftI | 1, csplit, ws->coef_v);
+      }
     }
   }
   p.cbp_y = (uint8_t)cbp_y;
   p.cbp_u = (uint8_t)cbp_u;
   p.cbp_v = (uint8_t)cbp_v;
   TK_PROF_T0();
-  int nb_ = bs_block(bs, nd.syn, p, ws->coef_y, ws->coef_u, ws->coef_v, &t, (pc && pc->have_ybits) ? pc->ybits : nullptr);
+  const SynCtx syn = lds_ld(&nd_.syn);
+  const int* yb = (pc && pc->have_ybits) ? pc->ybits : nullptr;
+  int nb_ = bigc ? bs_block_t<false, SP_GLOBAL>(bs, syn, p, ws->coef_y, ws->coef_u, ws->coef_v, &t, yb)   // bs.emit == 0 always here
+                 : bs_block_t<false, SP_LDS>(bs, syn, p, ws->coef_y, ws->coef_u, ws->coef_v, &t, yb);
   TK_PROF_ADD(ws, PF_BITS);
   return nb_;
 }
 
 // One RDO trial: count bits, evaluate cost, keep `best` (copy_best_parameters, :1615-1677).
-template <typename PIX>
-TK_DEV unsigned rdo_trial(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BlkParam& p, double lambda,
+template <typename PIX, int SP>
+TK_DEV unsigned rdo_trial(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd, BlkParam& p, double lambda,
                           int reuse_pred = 0, unsigned prune_thr = 0xffffffffu, const unsigned long long* bestkey = nullptr,
                           unsigned order = 0) {
   BitSink cnt;
   cnt.buf = nullptr; cnt.pos = 0; cnt.cap = 0; cnt.emit = 0; cnt.ovf = 0;
   PruneCtx pc;
   pc.thr = prune_thr; pc.bestkey = bestkey; pc.order = order; pc.lambda = lambda; pc.ssd_y = -1; pc.have_ybits = 0; pc.pruned = 0; pc.ssd_part = 0; pc.bits_part = 0;
-  int nbits = encode_block(t, J, ws, nd, p, cnt, reuse_pred, &pc);
+  int nbits = encode_block<PIX, SP>(t, J, ws, nd, p, cnt, reuse_pred, &pc);
   if (pc.pruned) return kCostInit;  // lower bound >= threshold: cannot be selected
-  return rd_cost(t, J, ws, nd, nbits, lambda, pc.ssd_y);
+  return rd_cost<PIX, SP>(t, J, ws, nd, nbits, lambda, pc.ssd_y);
 }
 
 TK_DEV BlkParam normalize_best(const Node& nd, const BlkParam& p) {
   BlkParam b = p;
   if (p.mode == M_SKIP || p.mode == M_MERGE) {
-    const InterPred& c = (p.mode == M_SKIP) ? nd.skip[p.skip_idx] : nd.merge[p.skip_idx];
+    const InterPred c = lds_ld((p.mode == M_SKIP) ? &nd.skip[p.skip_idx] : &nd.merge[p.skip_idx]);
     b.ref0 = c.ref0; b.ref1 = c.ref1; b.dir = c.dir;
     for (int i = 0; i < 4; i++) { b.mv0[i] = c.mv0; b.mv1[i] = c.mv1; }
   } else if (p.mode == M_INTRA) {
@@ -702,7 +742,7 @@ TK_DEV BlkParam normalize_best(const Node& nd, const BlkParam& p) {
   else b.dir = 2;
   return b;
 }
-TK_DEV void keep_best(Node& nd, const BlkParam& p) { nd.best = normalize_best(nd, p); }
+TK_DEV void keep_best(Node& nd, const BlkParam& p) { lds_st(&nd.best, normalize_best(nd, p)); }
 
 TK_DEV void set_cand(BlkParam& p, const InterPred& c, int idx, int mode) {
   p.mode = (int8_t)mode;
@@ -712,11 +752,12 @@ TK_DEV void set_cand(BlkParam& p, const InterPred& c, int idx, int mode) {
 }
 
 // search_inter_prediction_params (encode_block.c:1033-1098)
-template <typename PIX>
-TK_DEV unsigned search_inter(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, int ypos, int xpos, int size,
+// SP: address space of `org`
+template <typename PIX, int SP>
+TK_DEV unsigned search_inter(const Team t, JobR<PIX> J, WsP<PIX> ws, int ypos, int xpos, int size,
                              const PIX* org, int ostride, int ref_idx, mv_t mvc, mv_t mvp, mv_t* mv_arr, int part,
                              int sign) {
-  const Plane3<PIX>& ref = J.ref[ref_idx];
+  const Plane3<PIX> ref = lds_ld(&J.ref[ref_idx]);
   const PIX* ref_y = ref.y + ypos * ref.sy + xpos;
   MeArgs a;
   a.cb_size = size; a.rstride = ref.sy; a.sign = sign; a.fwidth = J.cfg.width; a.fheight = J.cfg.height;
@@ -726,14 +767,14 @@ TK_DEV unsigned search_inter(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* 
   mv_t mv, mvp2 = mvp;
   if (part == P_NONE) {
     a.width = size; a.height = size; a.pu_x = xpos; a.pu_y = ypos;
-    sad += motion_estimate(t, ws->mep, org, ref_y, a, mvc, mvp2, ref_idx, &mv);
+    sad += motion_estimate<PIX, SP>(t, ws->mep, org, ref_y, a, mvc, mvp2, ref_idx, &mv);
     mv_arr[0] = mv_arr[1] = mv_arr[2] = mv_arr[3] = mv;
   } else if (part == P_HOR) {
     a.width = size; a.height = size / 2;
     for (int index = 0; index < 4; index += 2) {
       int py = index >> 1;
       a.pu_x = xpos; a.pu_y = ypos + py * (size / 2);
-      sad += motion_estimate(t, ws->mep, org + py * (size / 2) * ostride, ref_y + py * (size / 2) * ref.sy, a, mvc, mvp2, ref_idx, &mv);
+      sad += motion_estimate<PIX, SP>(t, ws->mep, org + py * (size / 2) * ostride, ref_y + py * (size / 2) * ref.sy, a, mvc, mvp2, ref_idx, &mv);
       mv_arr[index] = mv; mv_arr[index + 1] = mv;
       mvp2 = mv_arr[0];
     }
@@ -741,7 +782,7 @@ TK_DEV unsigned search_inter(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* 
     a.width = size / 2; a.height = size;
     for (int index = 0; index < 2; index++) {
       a.pu_x = xpos + index * (size / 2); a.pu_y = ypos;
-      sad += motion_estimate(t, ws->mep, org + index * (size / 2), ref_y + index * (size / 2), a, mvc, mvp2, ref_idx, &mv);
+      sad += motion_estimate<PIX, SP>(t, ws->mep, org + index * (size / 2), ref_y + index * (size / 2), a, mvc, mvp2, ref_idx, &mv);
       mv_arr[index] = mv; mv_arr[index + 2] = mv;
       mvp2 = mv_arr[0];
     }
@@ -750,7 +791,7 @@ TK_DEV unsigned search_inter(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* 
     for (int index = 0; index < 4; index++) {
       int px = index & 1, py = index >> 1;
       a.pu_x = xpos + px * (size / 2); a.pu_y = ypos + py * (size / 2);
-      sad += motion_estimate(t, ws->mep, org + py * (size / 2) * ostride + px * (size / 2),
+      sad += motion_estimate<PIX, SP>(t, ws->mep, org + py * (size / 2) * ostride + px * (size / 2),
                              ref_y + py * (size / 2) * ref.sy + px * (size / 2), a, mvc, mvp2, ref_idx, &mv);
       mv_arr[index] = mv;
       mvp2 = mv_arr[0];
@@ -759,17 +800,20 @@ TK_DEV unsigned search_inter(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* 
   return sad;
 }
 
-template <typename PIX> TK_DEV void add_cands4(const Team t, TeamWs<PIX>* ws, int ref_idx, const mv_t* mv4) {
+template <typename PIX> TK_DEV void add_cands4(const Team t, WsP<PIX> ws, int ref_idx, const mv_t* mv4) {
   if (t.rank == 0)
     for (int i = 0; i < 4; i++) add_mvcand(ws->mep, ref_idx, mv4[i]);
   t.sync();
 }
 
 // search_bipred_prediction_params, me_mode 0 (encode_block.c:1739-1832) - P and B frames.
-template <typename PIX>
-TK_DEVNI void search_bipred(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int part,
+template <typename PIX, int SP>
+TK_DEVNI void search_bipred(const Team t, JobR<PIX> J, WsP<PIX> ws, const Node& nd_, int part,
                           const mv_t* mv_center, mv_t mvp, int* ref_idx0, int* ref_idx1, mv_t* mv_arr0, mv_t* mv_arr1) {
-  const EncCfg& c = J.cfg;
+  const auto& c = J.cfg;
+  const auto ndl = ldsc(&nd_);
+  struct { int size, ypos, xpos, bw, bh; } nd = {TKU(ndl->size), TKU(ndl->ypos), TKU(ndl->xpos), TKU(ndl->bw), TKU(ndl->bh)};
+  const auto lists = ldsc(lds_ld(&ws->mep->lists));
   const int size = nd.size;
   const int num_iter = c.encoder_speed == 0 ? 2 : 1;
   int min_ref0 = (J.frame_type == F_B && J.interp_ref > 0) ? 1 : 0, min_ref1 = 0;
@@ -791,7 +835,7 @@ TK_DEVNI void search_bipred(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* w
         int same = n > 0 && prev_ref[list] == ref_o;
         for (int i = 0; i < 4; i++) same = same && prev_mv[list][i].x == mo[i].x && prev_mv[list][i].y == mo[i].y;
         for (int r = 0; r < J.num_ref; r++) {
-          const int cnt = ws->mep->lists->mvcand_num[r];
+          const int cnt = lists->mvcand_num[r];
           same = same && prev_cnt[list][r] == cnt;
           prev_cnt[list][r] = cnt;
         }
@@ -799,13 +843,18 @@ TK_DEVNI void search_bipred(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* w
         for (int i = 0; i < 4; i++) prev_mv[list][i] = mo[i];
         if (tk_uniform(same)) continue;
       }
-      pred_inter_yuv(t, J.ref[ref_o], ws->pred_y, ws->pred_u, ws->pred_v, nd.ypos, nd.xpos, size, nd.bw, nd.bh,
+      pred_inter_yuv<SP>(t, lds_ld(&J.ref[ref_o]), ws->pred_y, ws->pred_u, ws->pred_v, nd.ypos, nd.xpos, size, nd.bw, nd.bh,
                      list ? min0 : min1, J.sign[ref_o], c.width, c.height, c.enable_bipred, part > 0, c.bitdepth);
       t.sync();
-      for (int k = t.rank; k < size * size; k += t.size) {
-        int i, j;
-        split2(mk_pow2(size), k, i, j);
-        ws->org8[k] = (PIX)sat_pix(2 * (int)oy[i * osy + j] - (int)ws->pred_y[k], c.bitdepth);
+      {
+        const auto o8 = spc<SP>(ws->org8);
+        const auto oys = spc<SP>(oy);
+        const auto pys = spc<SP>(ws->pred_y);
+        for (int k = t.rank; k < size * size; k += t.size) {
+          int i, j;
+          split2(mk_pow2(size), k, i, j);
+          o8[k] = (PIX)sat_pix(2 * (int)oys[i * osy + j] - (int)pys[k], c.bitdepth);
+        }
       }
       t.sync();
       int ref_start, ref_end;
@@ -817,7 +866,7 @@ TK_DEVNI void search_bipred(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* w
       for (int r = ref_start; r <= ref_end; r++) {
         mv_t mvp2 = (J.frame_type == F_B && list == 1) ? mvo : mvp;
         mv_t mv_all[4];
-        unsigned sad = search_inter(t, J, ws, nd.ypos, nd.xpos, size, ws->org8, size, r, mv_center[r], mvp2, mv_all, part, J.sign[r]);
+        unsigned sad = search_inter<PIX, SP>(t, J, ws, nd.ypos, nd.xpos, size, ws->org8, size, r, mv_center[r], mvp2, mv_all, part, J.sign[r]);
         add_cands4(t, ws, r, mv_all);
         if (sad < min_sad) {
           min_sad = sad;
@@ -835,29 +884,29 @@ TK_DEVNI void search_bipred(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* w
 // search_intra_prediction_params (encode_block.c:928-1031): intra mode by luma SAD against the frame-edge
 // prediction; evaluation order DC, HOR, VER, PLANAR (stop here when num_intra_modes == 4), then the six
 // angular modes; first minimum wins.  DC is always built from (left, top) here (sic: `xposY >= 0` :953).
-template <typename PIX>
-TK_DEVNI unsigned intra_sad_search(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, int num_modes, int* mode_out) {
-  const EncCfg& c = J.cfg;
+template <typename PIX, int SP>
+TK_DEVNI unsigned intra_sad_search(const Team t, JobR<PIX> J, WsP<PIX> ws, const Node& nd, int num_modes, int* mode_out) {
+  const auto& c = J.cfg;
   const int size = nd.size, bd = c.bitdepth;
   const int ur = upright_avail(nd.ypos, nd.xpos, size, size, c.width, kMaxSb);
   const int dl = downleft_avail(nd.ypos, nd.xpos, size, size, c.height, kMaxSb);
   const PIX* fy = J.rec.y + nd.ypos * J.rec.sy + nd.xpos;
   const PIX* oy = ws->org_y;
   const int osy = ws->org_sy;
-  make_edges(t, ws->edgep, fy, J.rec.sy, (const PIX*)nullptr, 0, 0, 0, nd.ypos, nd.xpos, size, ur, dl, 0, bd);
+  make_edges<SP>(t, ws->edgep, fy, J.rec.sy, (const PIX*)nullptr, 0, 0, 0, nd.ypos, nd.xpos, size, ur, dl, 0, bd);
   t.sync();
   unsigned min_sad = 1u << 30;
   int best = 0;
   const int n = num_modes == 4 ? 4 : 10;
   for (int e = 0; e < n; e++) {
     const int m = e == 0 ? 0 : e == 1 ? 2 : e == 2 ? 3 : e == 3 ? 1 : e;  // evaluation order -> intra_mode_t
-    pred_intra(t, ws->edgep, 1, 1, size, ws->pred_y, size, m, bd);
+    pred_intra<SP>(t, ws->edgep, 1, 1, size, ws->pred_y, size, m, bd);
     t.sync();
     int local = 0;
     for (int k = t.rank; k < size * size; k += t.size) {
       int i, j;
       split2(mk_pow2(size), k, i, j);
-      local += iabs((int)oy[i * osy + j] - (int)ws->pred_y[k]);
+      local += iabs((int)spc<SP>(oy)[i * osy + j] - (int)spc<SP>(ws->pred_y)[k]);
     }
     const unsigned sad = (unsigned)team_sum(t, local) >> (bd - 8);
     t.sync();
@@ -870,9 +919,9 @@ TK_DEVNI unsigned intra_sad_search(const Team t, const FrameJob<PIX>& J, TeamWs<
 // ---------------------------------------------------------------------------------
 // mode_decision_rdo (encode_block.c:1835-2121).  Result in nd.best; returns min cost.
 // ---------------------------------------------------------------------------------
-template <typename PIX>
-TK_DEVNI unsigned mode_decision(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd) {
-  const EncCfg& c = J.cfg;
+template <typename PIX, int SP>
+TK_DEVNI unsigned mode_decision(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd) {
+  const auto& c = J.cfg;
   const int size = nd.size;
   const double lambda = J.lambda;
   const int rect = nd.bw != size || nd.bh != size;
@@ -892,7 +941,7 @@ TK_DEVNI unsigned mode_decision(const Team t, const FrameJob<PIX>& J, TeamWs<PIX
     p.pb_part = P_NONE;
     for (int k = 0; k < nd.syn.num_skip; k++) {
       set_cand(p, nd.skip[k], k, M_SKIP);
-      unsigned cost = rdo_trial(t, J, ws, nd, p, lambda);
+      unsigned cost = rdo_trial<PIX, SP>(t, J, ws, nd, p, lambda);
       if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
     }
   }
@@ -904,7 +953,7 @@ TK_DEVNI unsigned mode_decision(const Team t, const FrameJob<PIX>& J, TeamWs<PIX
         set_cand(p, nd.merge[k], k, M_MERGE);
         for (int tb = 0; tb <= max_tb - 1; tb++) {
           p.tb_param = (int8_t)tb;
-          unsigned cost = rdo_trial(t, J, ws, nd, p, lambda, tb > 0, min_cost);
+          unsigned cost = rdo_trial<PIX, SP>(t, J, ws, nd, p, lambda, tb > 0, min_cost);
           if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
         }
       }
@@ -915,7 +964,7 @@ TK_DEVNI unsigned mode_decision(const Team t, const FrameJob<PIX>& J, TeamWs<PIX
       unsigned sad_intra = 0xffffffffu;
       if (intra_inter_sad) {
         int im;
-        sad_intra = intra_sad_search(t, J, ws, nd, J.num_intra_modes, &im);
+        sad_intra = intra_sad_search<PIX, SP>(t, J, ws, nd, J.num_intra_modes, &im);
         sad_intra += (unsigned)(int)mul_add_nofma(J.sqrt_lambda, 2.0, 0.5);
       }
       // uni-prediction per reference
@@ -938,7 +987,7 @@ TK_DEVNI unsigned mode_decision(const Team t, const FrameJob<PIX>& J, TeamWs<PIX
         mv_center[r] = mvp;
         unsigned sad_inter = 0xffffffffu;
         for (int part = 0; part < max_pb; part++) {
-          unsigned sad = search_inter(t, J, ws, nd.ypos, nd.xpos, size, oy, ws->org_sy, r, mv_center[r], mvp, mv_all[part], part, J.sign[r]);
+          unsigned sad = search_inter<PIX, SP>(t, J, ws, nd.ypos, nd.xpos, size, oy, ws->org_sy, r, mv_center[r], mvp, mv_all[part], part, J.sign[r]);
           add_cands4(t, ws, r, mv_all[part]);
           mv_center[r] = mv_all[0][0];
           sad_inter = sad < sad_inter ? sad : sad_inter;
@@ -958,7 +1007,7 @@ TK_DEVNI unsigned mode_decision(const Team t, const FrameJob<PIX>& J, TeamWs<PIX
             p.tb_param = (int8_t)tb;
             // worst/best cost feed only the encoder_speed 2 reference shortcut; where that is inactive the
             // exact costs of losing trials are never used and the trial may be pruned
-            unsigned cost = rdo_trial(t, J, ws, nd, p, lambda, tb > min_tb, (c.encoder_speed < 2 || c.enable_bipred) ? min_cost : 0xffffffffu);
+            unsigned cost = rdo_trial<PIX, SP>(t, J, ws, nd, p, lambda, tb > min_tb, (c.encoder_speed < 2 || c.enable_bipred) ? min_cost : 0xffffffffu);
             worst_cost = cost > worst_cost ? cost : worst_cost;
             best_cost = cost < best_cost ? cost : best_cost;
             if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
@@ -978,34 +1027,34 @@ TK_DEVNI unsigned mode_decision(const Team t, const FrameJob<PIX>& J, TeamWs<PIX
       if (J.num_ref > 1 && c.enable_bipred && do_inter) {
         int r0, r1;
         mv_t a0[4], a1[4];
-        search_bipred(t, J, ws, nd, 0, mv_center, mvp, &r0, &r1, a0, a1);
+        search_bipred<PIX, SP>(t, J, ws, nd, 0, mv_center, mvp, &r0, &r1, a0, a1);
         p.mode = M_BIPRED;
         p.pb_part = P_NONE;
         p.ref0 = (int8_t)r0; p.ref1 = (int8_t)r1;
         for (int i = 0; i < 4; i++) { p.mv0[i] = a0[i]; p.mv1[i] = a1[i]; }
         for (int tb = 0; tb <= max_tb - 1; tb++) {
           p.tb_param = (int8_t)tb;
-          unsigned cost = rdo_trial(t, J, ws, nd, p, lambda, tb > 0, min_cost);
+          unsigned cost = rdo_trial<PIX, SP>(t, J, ws, nd, p, lambda, tb > 0, min_cost);
           if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
         }
         if (J.frame_type == F_B && c.encoder_speed == 0) {
           // joint +mv / -mv search (search_bipred_prediction_params me_mode 1, encode_block.c:1708-1737, 2052-2068)
           const int ri0 = J.interp_ref ? 1 : 0, ri1 = J.interp_ref ? 2 : 1;
-          const Plane3<PIX>& f0 = J.ref[ri0];
-          const Plane3<PIX>& f1 = J.ref[ri1];
+          const Plane3<PIX> f0 = lds_ld(&J.ref[ri0]);
+          const Plane3<PIX> f1 = lds_ld(&J.ref[ri1]);
           MeArgs a;
           a.cb_size = size; a.ostride = ws->org_sy; a.width = size; a.height = size; a.rstride = f0.sy; a.sign = 0;
           a.fwidth = c.width; a.fheight = c.height; a.xpos = nd.xpos; a.ypos = nd.ypos; a.enable_bipred = 1;
           a.bitdepth = c.bitdepth; a.lam = J.sqrt_lambda; a.speed = c.encoder_speed; a.pu_x = nd.xpos; a.pu_y = nd.ypos;
           mv_t mvb;
-          motion_estimate_bi(t, ws->mep, oy, f0.y + nd.ypos * f0.sy + nd.xpos, f1.y + nd.ypos * f1.sy + nd.xpos, a, mv_center[ri0],
+          motion_estimate_bi<PIX, SP>(t, ws->mep, oy, f0.y + nd.ypos * f0.sy + nd.xpos, f1.y + nd.ypos * f1.sy + nd.xpos, a, mv_center[ri0],
                              mvp, ri0, &mvb);
           p.mode = M_BIPRED;
           p.pb_part = P_NONE;
           p.ref0 = (int8_t)ri0; p.ref1 = (int8_t)ri1;
           for (int i = 0; i < 4; i++) { p.mv0[i] = mvb; p.mv1[i] = mvb; }
           p.tb_param = 0;
-          unsigned cost = rdo_trial(t, J, ws, nd, p, lambda);
+          unsigned cost = rdo_trial<PIX, SP>(t, J, ws, nd, p, lambda);
           if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
         }
       }
@@ -1028,7 +1077,7 @@ TK_DEVNI unsigned mode_decision(const Team t, const FrameJob<PIX>& J, TeamWs<PIX
         for (int tb = 0; tb <= max_tb - 1; tb++) {
           p.tb_param = (int8_t)tb;
           // only a cost below both the best intra cost and the best overall cost can change the outcome
-          unsigned cost = rdo_trial(t, J, ws, nd, p, lambda, 0, min_intra < min_cost ? min_intra : min_cost);
+          unsigned cost = rdo_trial<PIX, SP>(t, J, ws, nd, p, lambda, 0, min_intra < min_cost ? min_intra : min_cost);
           tbc[tb] = cost;
           if (cost < min_intra) { min_intra = cost; intra_mode = m; improved = 1; }
         }
@@ -1041,11 +1090,11 @@ TK_DEVNI unsigned mode_decision(const Team t, const FrameJob<PIX>& J, TeamWs<PIX
         if (cost < min_cost) { min_cost = cost; p.cbp_y = p.cbp_u = p.cbp_v = 0; if (t.rank == 0) keep_best(nd, p); }
       }
     } else {
-      intra_sad_search(t, J, ws, nd, J.num_intra_modes, &intra_mode);
+      intra_sad_search<PIX, SP>(t, J, ws, nd, J.num_intra_modes, &intra_mode);
       p.intra_mode = (int8_t)intra_mode;
       for (int tb = 0; tb <= max_tb - 1; tb++) {
         p.tb_param = (int8_t)tb;
-        unsigned cost = rdo_trial(t, J, ws, nd, p, lambda);
+        unsigned cost = rdo_trial<PIX, SP>(t, J, ws, nd, p, lambda);
         if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
       }
     }
@@ -1087,81 +1136,84 @@ template <typename PIX> struct MdCtx {
   unsigned long long mykey;  // best key among this wave's trials
 };
 
-template <typename PIX>
-TK_DEV void par_trial(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, MdCtx<PIX>& M, BlkParam& p, unsigned order, int reuse_pred) {
-  const unsigned cost = rdo_trial(t, J, ws, *M.nd, p, J.lambda, reuse_pred, 0xffffffffu, &M.sh->bestkey, order);
+template <typename PIX, int SP>
+TK_DEV void par_trial(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& M, BlkParam& p, unsigned order, int reuse_pred) {
+  const unsigned cost = rdo_trial<PIX, SP>(t, J, ws, *M.nd, p, J.lambda, reuse_pred, 0xffffffffu, &M.sh->bestkey, order);
   if (cost == (unsigned)kCostInit) return;  // pruned: cannot have the smallest key
   const unsigned long long key = ((unsigned long long)cost << 32) | order;
   if (key < M.mykey) {
     M.mykey = key;
     if (t.rank == 0) {
-      M.sh->wbest[M.wg.wave] = normalize_best(*M.nd, p);
-      M.sh->wkey[M.wg.wave] = key;
+      lds_st(&M.sh->wbest[M.wg.wave], normalize_best(*M.nd, p));
+      *ldsc(&M.sh->wkey[M.wg.wave]) = key;
       wg_min64(&M.sh->bestkey, key);
     }
     t.sync();
   }
 }
 
-template <typename PIX>
-TK_DEVNI void md_item_bipred(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, MdCtx<PIX>& M) {
-  const EncCfg& c = J.cfg;
-  Node& nd = *M.nd;
+template <typename PIX, int SP>
+TK_DEVNI void md_item_bipred(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& M) {
+  const auto& c = J.cfg;
+  Node& nd_ = *M.nd;
+  const auto ndl = ldsc(&nd_);
+  struct { int size, ypos, xpos; } nd = {TKU(ndl->size), TKU(ndl->ypos), TKU(ndl->xpos)};
   const int size = nd.size;
   const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
-  const mv_t mvp = M.sh->mvp;
+  const mv_t mvp = lds_ld(&M.sh->mvp);
   mv_t mv_center[kMaxRefs];
-  for (int r = 0; r < kMaxRefs; r++) mv_center[r] = M.sh->mv_center[r];
+  for (int r = 0; r < kMaxRefs; r++) mv_center[r] = lds_ld(&M.sh->mv_center[r]);
   int r0, r1;
   mv_t a0[4], a1[4];
-  search_bipred(t, J, ws, nd, 0, mv_center, mvp, &r0, &r1, a0, a1);
+  search_bipred<PIX, SP>(t, J, ws, nd_, 0, mv_center, mvp, &r0, &r1, a0, a1);
   BlkParam p = blank_param();
   p.mode = M_BIPRED; p.pb_part = P_NONE;
   p.ref0 = (int8_t)r0; p.ref1 = (int8_t)r1;
   for (int i = 0; i < 4; i++) { p.mv0[i] = a0[i]; p.mv1[i] = a1[i]; }
   for (int tb = 0; tb <= max_tb - 1; tb++) {
     p.tb_param = (int8_t)tb;
-    par_trial(t, J, ws, M, p, 54u + (unsigned)tb, tb > 0);
+    par_trial<PIX, SP>(t, J, ws, M, p, 54u + (unsigned)tb, tb > 0);
   }
   if (J.frame_type == F_B) {
     // joint +mv / -mv search (search_bipred_prediction_params me_mode 1, encode_block.c:1708-1737, 2052-2068)
     const int ri0 = J.interp_ref ? 1 : 0, ri1 = J.interp_ref ? 2 : 1;
-    const Plane3<PIX>& f0 = J.ref[ri0];
-    const Plane3<PIX>& f1 = J.ref[ri1];
+    const Plane3<PIX> f0 = lds_ld(&J.ref[ri0]);
+    const Plane3<PIX> f1 = lds_ld(&J.ref[ri1]);
     const PIX* oy = ws->org_y;
     MeArgs a;
     a.cb_size = size; a.ostride = ws->org_sy; a.width = size; a.height = size; a.rstride = f0.sy; a.sign = 0;
     a.fwidth = c.width; a.fheight = c.height; a.xpos = nd.xpos; a.ypos = nd.ypos; a.enable_bipred = 1;
     a.bitdepth = c.bitdepth; a.lam = J.sqrt_lambda; a.speed = c.encoder_speed; a.pu_x = nd.xpos; a.pu_y = nd.ypos;
     mv_t mvb;
-    motion_estimate_bi(t, ws->mep, oy, f0.y + nd.ypos * f0.sy + nd.xpos, f1.y + nd.ypos * f1.sy + nd.xpos, a, mv_center[ri0], mvp, ri0, &mvb);
+    motion_estimate_bi<PIX, SP>(t, ws->mep, oy, f0.y + nd.ypos * f0.sy + nd.xpos, f1.y + nd.ypos * f1.sy + nd.xpos, a, mv_center[ri0], mvp, ri0, &mvb);
     p.mode = M_BIPRED; p.pb_part = P_NONE;
     p.ref0 = (int8_t)ri0; p.ref1 = (int8_t)ri1;
     for (int i = 0; i < 4; i++) { p.mv0[i] = mvb; p.mv1[i] = mvb; }
     p.tb_param = 0;
-    par_trial(t, J, ws, M, p, 56u, 0);
+    par_trial<PIX, SP>(t, J, ws, M, p, 56u, 0);
   }
 }
 
-template <typename PIX>
-TK_DEVNI void md_item_ref(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, MdCtx<PIX>& M, int r) {
-  const EncCfg& c = J.cfg;
-  Node& nd = *M.nd;
+template <typename PIX, int SP>
+TK_DEVNI void md_item_ref(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& M, int r) {
+  const auto& c = J.cfg;
+  const auto ndl = ldsc(M.nd);
+  struct { int size, ypos, xpos; } nd = {TKU(ndl->size), TKU(ndl->ypos), TKU(ndl->xpos)};
   const int size = nd.size;
   const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
   const int max_pb = c.enable_pb_split ? 4 : 1;
-  const mv_t mvp = M.sh->mvp;
+  const mv_t mvp = lds_ld(&M.sh->mvp);
   const PIX* oy = ws->org_y;
   if (t.rank == 0) add_mvcand(ws->mep, r, mvp);
   t.sync();
   mv_t mv_center = mvp;
   mv_t mv_all[4][4];
   for (int part = 0; part < max_pb; part++) {
-    search_inter(t, J, ws, nd.ypos, nd.xpos, size, oy, ws->org_sy, r, mv_center, mvp, mv_all[part], part, J.sign[r]);
+    search_inter<PIX, SP>(t, J, ws, nd.ypos, nd.xpos, size, oy, ws->org_sy, r, mv_center, mvp, mv_all[part], part, J.sign[r]);
     add_cands4(t, ws, r, mv_all[part]);
     mv_center = mv_all[0][0];
   }
-  if (t.rank == 0) M.sh->mv_center[r] = mv_center;
+  if (t.rank == 0) lds_st(&M.sh->mv_center[r], mv_center);
   BlkParam p = blank_param();
   p.mode = M_INTER;
   p.ref0 = p.ref1 = (int8_t)r;
@@ -1181,7 +1233,7 @@ TK_DEVNI void md_item_ref(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
     for (int i = 0; i < 4; i++) { p.mv0[i] = mv_all[part][i]; p.mv1[i] = mv_all[part][i]; }
     for (int tb = -1; tb <= max_tb - 1; tb++) {
       p.tb_param = (int8_t)tb;
-      par_trial(t, J, ws, M, p, 6u + 12u * (unsigned)r + 3u * (unsigned)part + (unsigned)(tb + 1), tb > -1);
+      par_trial<PIX, SP>(t, J, ws, M, p, 6u + 12u * (unsigned)r + 3u * (unsigned)part + (unsigned)(tb + 1), tb > -1);
     }
   }
 }
@@ -1191,15 +1243,18 @@ TK_DEVNI void md_item_ref(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
 // list and keeps the first strictly smaller SAD (encode_block.c:1770-1816).  The searches of one step are independent
 // (each touches only its own candidate list), so wave w takes reference w; the leader (wave 0) builds 2*org - pred before
 // and reduces in reference order after each step - the very scan of the reference.  Then the two trials (tb 0 / 1).
-template <typename PIX>
-TK_DEVNI void bipred_par(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, MdCtx<PIX>& M) {
-  const EncCfg& c = J.cfg;
-  WgShared* sh = M.sh;
-  Node& nd = *M.nd;
+template <typename PIX, int SP>
+TK_DEVNI void bipred_par(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& M) {
+  const auto& c = J.cfg;
+  WgShared* sh_ = M.sh;
+  const auto sh = ldsc(sh_);
+  const auto ndl = ldsc(M.nd);
+  struct { int size, ypos, xpos, bw, bh; } nd = {TKU(ndl->size), TKU(ndl->ypos), TKU(ndl->xpos), TKU(ndl->bw), TKU(ndl->bh)};
+  const auto lists = ldsc(lds_ld(&ws->mep->lists));
   const int size = nd.size;
   const int num_iter = c.encoder_speed == 0 ? 2 : 1;
   const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
-  const mv_t mvp = sh->mvp;
+  const mv_t mvp = lds_ld(&sh_->mvp);
   // A step whose inputs - reference and vector of the other list, hence 2*org - pred; and the candidate list of every
   // reference - equal those of the previous step of the same list finds the same SADs again, none of which is below
   // min_sad any more (the earlier step left min_sad <= all of them): it changes nothing and is skipped (about a third of
@@ -1211,12 +1266,12 @@ TK_DEVNI void bipred_par(const Wg wg, const Team t, const FrameJob<PIX>& J, Team
       const int step = 2 * n + (1 - list);
       if (wg.wave == 0) {
         mv_t mo[4];
-        for (int i = 0; i < 4; i++) mo[i] = list ? sh->bp_min0[i] : sh->bp_min1[i];
+        for (int i = 0; i < 4; i++) mo[i] = lds_ld(list ? &sh_->bp_min0[i] : &sh_->bp_min1[i]);
         const int ref_o = list ? sh->bp_ref0 : sh->bp_ref1;
         int same = n > 0 && prev_ref[list] == ref_o;
         for (int i = 0; i < 4; i++) same = same && prev_mv[list][i].x == mo[i].x && prev_mv[list][i].y == mo[i].y;
         for (int r = 0; r < J.num_ref; r++) {
-          const int cnt = ws->mep->lists->mvcand_num[r];
+          const int cnt = lists->mvcand_num[r];
           same = same && prev_cnt[list][r] == cnt;
           prev_cnt[list][r] = cnt;
         }
@@ -1225,15 +1280,17 @@ TK_DEVNI void bipred_par(const Wg wg, const Team t, const FrameJob<PIX>& J, Team
         same = tk_uniform(same);
         if (t.rank == 0) sh->bp_skip[step] = same;
         if (!same) {
-          pred_inter_yuv(t, J.ref[ref_o], ws->pred_y, ws->pred_u, ws->pred_v, nd.ypos, nd.xpos, size, nd.bw, nd.bh, mo, J.sign[ref_o], c.width,
+          pred_inter_yuv<SP>(t, lds_ld(&J.ref[ref_o]), ws->pred_y, ws->pred_u, ws->pred_v, nd.ypos, nd.xpos, size, nd.bw, nd.bh, mo, J.sign[ref_o], c.width,
                          c.height, c.enable_bipred, 0, c.bitdepth);
           t.sync();
-          const PIX* oy = ws->org_y;
+          const auto oy = spc<SP>(ws->org_y);
+          const auto py = spc<SP>(ws->pred_y);
+          const auto o8 = spc<SP>(ws->org8);
           const int osy = ws->org_sy;
           for (int k = t.rank; k < size * size; k += t.size) {
             int i, j;
             split2(mk_pow2(size), k, i, j);
-            ws->org8[k] = (PIX)sat_pix(2 * (int)oy[i * osy + j] - (int)ws->pred_y[k], c.bitdepth);
+            o8[k] = (PIX)sat_pix(2 * (int)oy[i * osy + j] - (int)py[k], c.bitdepth);
           }
           if (t.rank == 0) sh->bp_org8 = ws->org8;
         }
@@ -1241,12 +1298,12 @@ TK_DEVNI void bipred_par(const Wg wg, const Team t, const FrameJob<PIX>& J, Team
       }
       wg.barrier();
       if (team_bcast0(t, sh->bp_skip[step])) continue;  // uniform over the workgroup
-      const PIX* org8 = (const PIX*)sh->bp_org8;
+      const PIX* org8 = (const PIX*)sh->bp_org8;   // the leader's buffer: same address space as this wave's (same block size)
       for (int r = wg.wave; r < J.num_ref; r += wg.nwaves) {
         mv_t mv_all[4];
-        const unsigned sad = search_inter(t, J, ws, nd.ypos, nd.xpos, size, org8, size, r, sh->mv_center[r], mvp, mv_all, 0, J.sign[r]);
+        const unsigned sad = search_inter<PIX, SP>(t, J, ws, nd.ypos, nd.xpos, size, org8, size, r, lds_ld(&sh_->mv_center[r]), mvp, mv_all, 0, J.sign[r]);
         add_cands4(t, ws, r, mv_all);
-        if (t.rank == 0) { sh->bp_sad[r] = sad; for (int i = 0; i < 4; i++) sh->bp_mv[r][i] = mv_all[i]; }
+        if (t.rank == 0) { sh->bp_sad[r] = sad; for (int i = 0; i < 4; i++) lds_st(&sh_->bp_mv[r][i], mv_all[i]); }
       }
       t.sync();
       wg.barrier();
@@ -1255,8 +1312,8 @@ TK_DEVNI void bipred_par(const Wg wg, const Team t, const FrameJob<PIX>& J, Team
           for (int r = 0; r < J.num_ref; r++)
             if (sh->bp_sad[r] < sh->bp_min_sad) {
               sh->bp_min_sad = sh->bp_sad[r];
-              if (list) { sh->bp_ref1 = r; for (int i = 0; i < 4; i++) sh->bp_min1[i] = sh->bp_mv[r][i]; }
-              else { sh->bp_ref0 = r; for (int i = 0; i < 4; i++) sh->bp_min0[i] = sh->bp_mv[r][i]; }
+              if (list) { sh->bp_ref1 = r; for (int i = 0; i < 4; i++) lds_st(&sh_->bp_min1[i], lds_ld(&sh_->bp_mv[r][i])); }
+              else { sh->bp_ref0 = r; for (int i = 0; i < 4; i++) lds_st(&sh_->bp_min0[i], lds_ld(&sh_->bp_mv[r][i])); }
             }
         t.sync();
       }
@@ -1268,66 +1325,76 @@ TK_DEVNI void bipred_par(const Wg wg, const Team t, const FrameJob<PIX>& J, Team
       BlkParam p = blank_param();
       p.mode = M_BIPRED; p.pb_part = P_NONE;
       p.ref0 = (int8_t)sh->bp_ref0; p.ref1 = (int8_t)sh->bp_ref1;
-      for (int i = 0; i < 4; i++) { p.mv0[i] = sh->bp_min0[i]; p.mv1[i] = sh->bp_min1[i]; }
+      for (int i = 0; i < 4; i++) { p.mv0[i] = lds_ld(&sh_->bp_min0[i]); p.mv1[i] = lds_ld(&sh_->bp_min1[i]); }
       p.tb_param = (int8_t)tb;
-      par_trial(t, J, ws, M, p, 54u + (unsigned)tb, 0);
+      par_trial<PIX, SP>(t, J, ws, M, p, 54u + (unsigned)tb, 0);
     }
 }
 
 // Executed by every wave of the workgroup between the fork and the join barrier.
-template <typename PIX>
-TK_DEVNI void md_worker(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws) {
-  WgShared* sh = ws->sh;
+template <typename PIX, int SP>
+TK_DEVNI void md_worker_sp(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws) {
+  WgShared* sh_ = ws->sh;
+  const auto sh = ldsc(sh_);
   MdCtx<PIX> M;
-  M.wg = wg; M.sh = sh; M.nd = &sh->stack[sh->node]; M.mykey = ~0ull;
-  ws_select(ws, tk_uniform(M.nd->size));
-  org_select(t, J, ws, tk_uniform(M.nd->size), M.nd->ypos, M.nd->xpos, M.nd->bw, M.nd->bh, 0);
-  const EncCfg& c = J.cfg;
+  M.wg = wg; M.sh = sh_; M.nd = &sh_->stack[sh->node]; M.mykey = ~0ull;
+  const auto ndl = ldsc(M.nd);
+  ws_select(ws, tk_uniform(ndl->size));
+  org_select(t, J, ws, tk_uniform(ndl->size), ndl->ypos, ndl->xpos, ndl->bw, ndl->bh, 0);
+  const auto& c = J.cfg;
   const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
   const int n_items = sh->n_items;
   for (;;) {
     int i = 0;
-    if (t.rank == 0) i = wg_fetch_add(&sh->next_item, 1);
+    if (t.rank == 0) i = wg_fetch_add(&sh_->next_item, 1);
     i = team_bcast0(t, i);
     if (i >= n_items) break;
-    const MdItem it = sh->items[i];
-    const int kind = team_bcast0(t, it.kind), ia = team_bcast0(t, it.a), ib = team_bcast0(t, it.b);
+    const int kind = team_bcast0(t, sh->items[i].kind), ia = team_bcast0(t, sh->items[i].a), ib = team_bcast0(t, sh->items[i].b);
     if (kind == MD_SKIP) {
       BlkParam p = blank_param();
-      set_cand(p, M.nd->skip[ia], ia, M_SKIP);
-      par_trial(t, J, ws, M, p, (unsigned)ia, 0);
+      set_cand(p, lds_ld(&M.nd->skip[ia]), ia, M_SKIP);
+      par_trial<PIX, SP>(t, J, ws, M, p, (unsigned)ia, 0);
     } else if (kind == MD_MERGE) {
       BlkParam p = blank_param();
-      set_cand(p, M.nd->merge[ia], ia, M_MERGE);
+      set_cand(p, lds_ld(&M.nd->merge[ia]), ia, M_MERGE);
       for (int tb = 0; tb <= max_tb - 1; tb++) {
         p.tb_param = (int8_t)tb;
-        par_trial(t, J, ws, M, p, 2u + 2u * (unsigned)ia + (unsigned)tb, tb > 0);
+        par_trial<PIX, SP>(t, J, ws, M, p, 2u + 2u * (unsigned)ia + (unsigned)tb, tb > 0);
       }
     } else if (kind == MD_INTRA) {
       BlkParam p = blank_param();
       p.mode = M_INTRA; p.intra_mode = (int8_t)ia; p.tb_param = (int8_t)ib;
-      par_trial(t, J, ws, M, p, 57u + 2u * (unsigned)ia + (unsigned)ib, 0);
+      par_trial<PIX, SP>(t, J, ws, M, p, 57u + 2u * (unsigned)ia + (unsigned)ib, 0);
     } else if (kind == MD_REF) {
-      md_item_ref(t, J, ws, M, ia);
+      md_item_ref<PIX, SP>(t, J, ws, M, ia);
       t.sync();
       int done = 0;
-      if (t.rank == 0) done = wg_fetch_add(&sh->refs_done, 1) + 1;
+      if (t.rank == 0) done = wg_fetch_add(&sh_->refs_done, 1) + 1;
       done = team_bcast0(t, done);
       if (done == sh->n_ref_items && sh->do_bipred == 1) {
-        md_item_bipred(t, J, ws, M);
+        md_item_bipred<PIX, SP>(t, J, ws, M);
       }
     }
   }
   if (sh->do_bipred == 2) {  // uniform over the workgroup: every wave takes part (same number of barriers)
     t.sync();
     wg.barrier();            // every reference search has finished: mv_center[] and the candidate lists are final
-    bipred_par(wg, t, J, ws, M);
+    bipred_par<PIX, SP>(wg, t, J, ws, M);
   }
+}
+// The decision code exists twice: for coding blocks whose sample buffers live in LDS (up to kLdsBlk) and for the larger ones
+// (global scratch); see tk_common.h SP_LDS / SP_GLOBAL.
+template <typename PIX>
+TK_DEV void md_worker(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws) {
+  const auto sh = ldsc(ws->sh);
+  const int size = tk_uniform(ldsc(&ws->sh->stack[sh->node])->size);
+  if (size <= kLdsBlk) md_worker_sp<PIX, SP_LDS>(wg, t, J, ws);
+  else md_worker_sp<PIX, SP_GLOBAL>(wg, t, J, ws);
 }
 
 // Parked waves: woken by the master at every fork until it posts WG_CMD_EXIT at the end of the superblock.
 template <typename PIX>
-TK_DEV void wg_helper_loop(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws) {
+TK_DEV void wg_helper_loop(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws) {
   for (;;) {
     wg.barrier();
     const int cmd = team_bcast0(t, ws->sh->cmd);
@@ -1344,23 +1411,26 @@ TK_DEV void wg_helper_loop(const Wg wg, const Team t, const FrameJob<PIX>& J, Te
 
 // Master side.  Result in nd.best; returns min cost.
 template <typename PIX>
-TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, int node) {
-  const EncCfg& c = J.cfg;
-  WgShared* sh = ws->sh;
-  Node& nd = sh->stack[node];
+TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int node) {
+  const auto& c = J.cfg;
+  WgShared* sh_ = ws->sh;
+  const auto sh = ldsc(sh_);
+  const auto nd = ldsc(&sh_->stack[node]);
   const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
   const int inter = J.frame_type != F_I;
   mv_t mvp = mk_mv(0, 0);
-  if (inter) mvp = get_mv_pred(J.cells, J.cell_stride, nd.ypos, nd.xpos, c.width, c.height, nd.size, kMaxSb);
+  if (inter) mvp = get_mv_pred(J.cells, J.cell_stride, nd->ypos, nd->xpos, c.width, c.height, nd->size, kMaxSb);
   t.sync();
   if (t.rank == 0) {
     int n = 0;
-    auto push = [&](int kind, int a, int b) { MdItem it; it.kind = (int8_t)kind; it.a = (int8_t)a; it.b = (int8_t)b; it.pad = 0; sh->items[n++] = it; };
+    auto push = [&](int kind, int a, int b) { sh->items[n].kind = (int8_t)kind; sh->items[n].a = (int8_t)a; sh->items[n].b = (int8_t)b; sh->items[n].pad = 0; n++; };
+    static_assert(2 + 2 + kMaxRefs + 2 * kNumIntraModes <= kMdMaxItems, "work queue too small");
+    static_assert(6 + 12 * kMaxRefs <= 54, "evaluation-order layout: the reference trials must end before the bi-prediction trials");
     if (inter) {
-      for (int k = 0; k < nd.syn.num_skip; k++) push(MD_SKIP, k, 0);
-      for (int k = 0; k < nd.syn.num_merge; k++) push(MD_MERGE, k, 0);
+      for (int k = 0; k < nd->syn.num_skip; k++) push(MD_SKIP, k, 0);
+      for (int k = 0; k < nd->syn.num_merge; k++) push(MD_MERGE, k, 0);
       for (int r = 0; r < J.num_ref; r++) push(MD_REF, r, 0);
-      nd.syn.mvp = mvp;
+      nd->syn.mvp.x = mvp.x; nd->syn.mvp.y = mvp.y;
     }
     for (int m = 0; m < J.num_intra_modes; m++)
       for (int tb = 0; tb <= max_tb - 1; tb++) push(MD_INTRA, m, tb);
@@ -1368,8 +1438,8 @@ TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, const FrameJob<PI
     sh->refs_done = 0; sh->n_ref_items = inter ? J.num_ref : 0;
     sh->do_bipred = (inter && J.num_ref > 1 && c.enable_bipred) ? (J.frame_type == F_P ? 2 : 1) : 0;
     sh->bp_min_sad = 1u << 30; sh->bp_ref0 = 0; sh->bp_ref1 = 0;
-    for (int i = 0; i < 4; i++) { sh->bp_min0[i] = mvp; sh->bp_min1[i] = mvp; }
-    sh->node = node; sh->mvp = mvp;
+    for (int i = 0; i < 4; i++) { lds_st(&sh_->bp_min0[i], mvp); lds_st(&sh_->bp_min1[i], mvp); }
+    sh->node = node; lds_st(&sh_->mvp, mvp);
     sh->bestkey = ~0ull;
     for (int w = 0; w < kWaves; w++) sh->wkey[w] = ~0ull;
     sh->cmd = WG_CMD_MD;
@@ -1390,7 +1460,7 @@ TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, const FrameJob<PI
     if (k < best) { best = k; bw = w; }
   }
   if (best == ~0ull) return kCostInit;
-  if (t.rank == 0) nd.best = sh->wbest[bw];
+  if (t.rank == 0) lds_st(&sh_->stack[node].best, lds_ld(&sh_->wbest[bw]));
   t.sync();
   return (unsigned)(best >> 32);
 }
@@ -1398,9 +1468,14 @@ TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, const FrameJob<PI
 // ---------------------------------------------------------------------------------
 // Early skip (encode_block.c:2123-2392)
 // ---------------------------------------------------------------------------------
-template <typename PIX>
-TK_DEV int early_skip_sub(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const PIX* org, int ostride,
-                          const PIX* pred, int pstride, int size, int qp, float thr) {
+template <typename PIX, int SP>
+TK_DEV int early_skip_sub(const Team t, JobR<PIX> J, WsP<PIX> ws, const PIX* org_, int ostride,
+                          const PIX* pred_, int pstride, int size, int qp, float thr) {
+  const auto org = spc<SP>(org_);
+  const auto pred = spc<SP>(pred_);
+  const auto xin = ldsc(ws->xfp->in);
+  const auto xcoef = ldsc(ws->xfp->coef);
+  const auto xflag = ldsc(&ws->xfp->flag);
   // luma: 2x2 average + (N/2) transform (size > 4 always here), threshold 0.5*thr
   const int bd = J.cfg.bitdepth;
   const int s2 = size / 2;
@@ -1411,7 +1486,7 @@ TK_DEV int early_skip_sub(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
     int b = (int16_t)((int)org[(2 * i) * ostride + 2 * j + 1] - (int)pred[(2 * i) * pstride + 2 * j + 1]);
     int cc = (int16_t)((int)org[(2 * i + 1) * ostride + 2 * j] - (int)pred[(2 * i + 1) * pstride + 2 * j]);
     int d = (int16_t)((int)org[(2 * i + 1) * ostride + 2 * j + 1] - (int)pred[(2 * i + 1) * pstride + 2 * j + 1]);
-    ws->xfp->in[j * s2 + i] = (int16_t)((a + b + cc + d + 2) >> 2);  // transposed (fwd_core layout)
+    xin[j * s2 + i] = (int16_t)((a + b + cc + d + 2) >> 2);  // transposed (fwd_core layout)
   }
   t.sync();
   fwd_transform_block(t, ws->xfp, s2, bd);
@@ -1419,25 +1494,28 @@ TK_DEV int early_skip_sub(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
   const double fql = (double)(1 << shift2) / (double)quant_scale(qp % 6);
   const double rel = 0.5 * thr;  // float -> double promotion as in the reference
   const int threshold = (int)(rel * fql);
-  if (t.rank == 0) ws->xfp->flag = 0;
+  if (t.rank == 0) *xflag = 0;
   t.sync();
   int f = 0;
   for (int k = t.rank; k < s2 * s2; k += t.size)
-    if (iabs((int)ws->xfp->coef[k]) > threshold) f = 1;
+    if (iabs((int)xcoef[k]) > threshold) f = 1;
   if (f) team_or((unsigned*)&ws->xfp->flag, 1u);
   t.sync();
-  int r = ws->xfp->flag;
+  int r = *xflag;
   t.sync();
   return r != 0;
 }
 
-template <typename PIX>
-TK_DEV int early_skip_subC(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const PIX* org, int ostride,
-                           const PIX* pred, int pstride, int size, int qp, float thr) {
+template <typename PIX, int SP>
+TK_DEV int early_skip_subC(const Team t, JobR<PIX> J, WsP<PIX> ws, const PIX* org_, int ostride,
+                           const PIX* pred_, int pstride, int size, int qp, float thr) {
+  const auto org = spc<SP>(org_);
+  const auto pred = spc<SP>(pred_);
+  const auto xflag = ldsc(&ws->xfp->flag);
   const int shift2 = 21 - 5 + qp / 6;
   const double fql = (double)(1 << shift2) / (double)quant_scale(qp % 6);
   const int threshold = ((int)(thr * fql)) << (J.cfg.bitdepth - 8);
-  if (t.rank == 0) ws->xfp->flag = 0;
+  if (t.rank == 0) *xflag = 0;
   t.sync();
   // calc_cbp as the reference EXECUTES it, i.e. calc_cbp_simd (enc/enc_kernels.c:827-907, selected at
   // encode_block.c:2225 because use_simd = 1): int16 column sums of the residual; for 16/8 wide
@@ -1461,14 +1539,14 @@ TK_DEV int early_skip_subC(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws
   }
   if (f) team_or((unsigned*)&ws->xfp->flag, 1u);
   t.sync();
-  int r = ws->xfp->flag;
+  int r = *xflag;
   t.sync();
   return r != 0;
 }
 
-template <typename PIX>
-TK_DEVNI int check_early_skip(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, const Node& nd, const BlkParam& p) {
-  const EncCfg& c = J.cfg;
+template <typename PIX, int SP>
+TK_DEVNI int check_early_skip(const Team t, JobR<PIX> J, WsP<PIX> ws, const Node& nd, const BlkParam& p) {
+  const auto& c = J.cfg;
   const int size = nd.size, size0 = size < 32 ? size : 32;
   const int qpY = J.qp, qpC = TK_TAB.chroma_qp[qpY];
   float thr = c.early_skip_thr;
@@ -1480,24 +1558,24 @@ TK_DEVNI int check_early_skip(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>*
       struct { int ypos, xpos; } sub = {nd.ypos + i, nd.xpos + j};
       const int yc = sub.ypos >> 1, xc = sub.xpos >> 1;
       if (p.dir == 2) {
-        pred_inter_yuv(t, J.ref[p.ref0], ws->p0_y, ws->p0_u, ws->p0_v, sub.ypos, sub.xpos, size0, size0, size0, p.mv0,
+        pred_inter_yuv<SP>(t, lds_ld(&J.ref[p.ref0]), ws->p0_y, ws->p0_u, ws->p0_v, sub.ypos, sub.xpos, size0, size0, size0, p.mv0,
                        J.sign_ge[p.ref0], c.width, c.height, c.enable_bipred, 0, c.bitdepth);
-        pred_inter_yuv(t, J.ref[p.ref1], ws->p1_y, ws->p1_u, ws->p1_v, sub.ypos, sub.xpos, size0, size0, size0, p.mv1,
+        pred_inter_yuv<SP>(t, lds_ld(&J.ref[p.ref1]), ws->p1_y, ws->p1_u, ws->p1_v, sub.ypos, sub.xpos, size0, size0, size0, p.mv1,
                        J.sign_ge[p.ref1], c.width, c.height, c.enable_bipred, 0, c.bitdepth);
         t.sync();
-        average_yuv(t, ws->pred_y, ws->pred_u, ws->pred_v, ws->p0_y, ws->p0_u, ws->p0_v, ws->p1_y, ws->p1_u, ws->p1_v,
+        average_yuv<SP>(t, ws->pred_y, ws->pred_u, ws->pred_v, ws->p0_y, ws->p0_u, ws->p0_v, ws->p1_y, ws->p1_u, ws->p1_v,
                     size0, size0, size0);
       } else {
-        pred_inter_yuv(t, J.ref[p.ref0], ws->pred_y, ws->pred_u, ws->pred_v, sub.ypos, sub.xpos, size0, size0, size0,
+        pred_inter_yuv<SP>(t, lds_ld(&J.ref[p.ref0]), ws->pred_y, ws->pred_u, ws->pred_v, sub.ypos, sub.xpos, size0, size0, size0,
                        p.mv0, J.sign[p.ref0], c.width, c.height, c.enable_bipred, 0, c.bitdepth);
       }
       t.sync();
-      significant = early_skip_sub(t, J, ws, ws->org_y + i * ws->org_sy + j, ws->org_sy, ws->pred_y, size0,
+      significant = early_skip_sub<PIX, SP>(t, J, ws, ws->org_y + i * ws->org_sy + j, ws->org_sy, ws->pred_y, size0,
                                    size0, qpY, thr);
       if (!significant)
-        significant = early_skip_subC(t, J, ws, ws->org_u + (i >> 1) * ws->org_sc + (j >> 1), ws->org_sc, ws->pred_u, size0c, size0c, qpC, thr);
+        significant = early_skip_subC<PIX, SP>(t, J, ws, ws->org_u + (i >> 1) * ws->org_sc + (j >> 1), ws->org_sc, ws->pred_u, size0c, size0c, qpC, thr);
       if (!significant)
-        significant = early_skip_subC(t, J, ws, ws->org_v + (i >> 1) * ws->org_sc + (j >> 1), ws->org_sc, ws->pred_v, size0c, size0c, qpC, thr);
+        significant = early_skip_subC<PIX, SP>(t, J, ws, ws->org_v + (i >> 1) * ws->org_sc + (j >> 1), ws->org_sc, ws->pred_v, size0c, size0c, qpC, thr);
     }
   return !significant;
 }
@@ -1505,25 +1583,25 @@ TK_DEVNI int check_early_skip(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>*
 // ---------------------------------------------------------------------------------
 // Final encode of a CB: recompute (encode_block final), write recon + cell state, emit bits.
 // ---------------------------------------------------------------------------------
-template <typename PIX>
-TK_DEVNI int final_encode(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, Node& nd, BitSink& out) {
+template <typename PIX, int SP>
+TK_DEVNI int final_encode(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd, BitSink& out) {
   TK_PROF_T0();
-  BlkParam p = nd.best;
+  BlkParam p = lds_ld(&nd.best);
   BitSink cnt;
   cnt.buf = nullptr; cnt.pos = 0; cnt.cap = 0; cnt.emit = 0; cnt.ovf = 0;
-  int nbits = encode_block(t, J, ws, nd, p, cnt);
+  int nbits = encode_block<PIX, SP>(t, J, ws, nd, p, cnt);
   // bits (one lane), then recon copy and cells (all lanes)
   if (t.rank == 0) {
     BitSink w = out;
-    bs_block(w, nd.syn, p, ws->coef_y, ws->coef_u, ws->coef_v, nullptr);
+    bs_block_t<true>(w, lds_ld(&nd.syn), p, ws->coef_y, ws->coef_u, ws->coef_v, nullptr, nullptr);
     out.ovf |= w.ovf;
   }
   out.pos += nbits;
   const int size = nd.size, sc = size >> 1;
   const int yc = nd.ypos >> 1, xc = nd.xpos >> 1;
-  copy_block(t, J.rec.y + nd.ypos * J.rec.sy + nd.xpos, J.rec.sy, ws->rec_y, size, nd.bw, nd.bh);
-  copy_block(t, J.rec.u + yc * J.rec.sc + xc, J.rec.sc, ws->rec_u, sc, nd.bw >> 1, nd.bh >> 1);
-  copy_block(t, J.rec.v + yc * J.rec.sc + xc, J.rec.sc, ws->rec_v, sc, nd.bw >> 1, nd.bh >> 1);
+  copy_block<SP_GLOBAL, SP>(t, J.rec.y + nd.ypos * J.rec.sy + nd.xpos, J.rec.sy, ws->rec_y, size, nd.bw, nd.bh);
+  copy_block<SP_GLOBAL, SP>(t, J.rec.u + yc * J.rec.sc + xc, J.rec.sc, ws->rec_u, sc, nd.bw >> 1, nd.bh >> 1);
+  copy_block<SP_GLOBAL, SP>(t, J.rec.v + yc * J.rec.sc + xc, J.rec.sc, ws->rec_v, sc, nd.bw >> 1, nd.bh >> 1);
   // copy_deblock_data (encode_block.c:1568-1613)
   const int tbs = p.tb_param > 0 ? 1 : 0;
   const int pb = p.mode == M_INTER ? p.pb_part : P_NONE;
@@ -1558,13 +1636,17 @@ TK_DEVNI int final_encode(const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws,
 // Runs on the master wave (wg.wave == 0); the other waves of the workgroup sit in wg_helper_loop meanwhile.  The
 // shared tables (ws->sh->tabs) must have been filled (xform_tables_fill).
 template <typename PIX>
-TK_DEV void process_sb(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamWs<PIX>* ws, int sb_y, int sb_x, BitSink& out) {
+TK_DEV void process_sb(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int sb_y, int sb_x, BitSink& out) {
   TK_PROF_T0();
-  const EncCfg& c = J.cfg;
+  const auto& c = J.cfg;
   const int fw = c.width, fh = c.height;
   if (t.rank == 0)
   { MeLists* L = ws->mep->lists; for (int r = 0; r < kMaxRefs; r++) { L->mvcand_num[r] = 0; L->mvcand_mask[r] = 0; } L->best_ref = -1; }
   t.sync();
+  if (J.stats && J.frame_type != F_I && t.rank == 0) {
+    team_add64(&J.stats[2], 1ull);
+    team_add64(&J.stats[3], (unsigned long long)(tmin((int)kMaxSb, fw - sb_x) * tmin((int)kMaxSb, fh - sb_y)));
+  }
   int sp = 0;
   unsigned ret = 0;  // value "returned" by the node that was just popped
   int have_ret = 0;
@@ -1605,6 +1687,7 @@ TK_DEV void process_sb(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamWs
       t.sync();
       org_select(t, J, ws, tk_uniform(size), ypos, xpos, tk_uniform(nd.bw), tk_uniform(nd.bh), 1);
       // ---- early skip
+      const int lds_blk = tk_uniform(size <= kLdsBlk);   // address space of this block's sample buffers (SP_LDS / SP_GLOBAL instances)
       if (nd.encode_this_size && J.frame_type != F_I && c.early_skip_thr > 0.0f) {
         unsigned min_cost = kCostInit;
         int any = 0;
@@ -1613,18 +1696,22 @@ TK_DEV void process_sb(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamWs
         for (int k = 0; k < nd.syn.num_skip; k++) {
           set_cand(p, nd.skip[k], k, M_SKIP);
           TK_PROF_T0();
-          int es_ = check_early_skip(t, J, ws, nd, p);
+          int es_ = lds_blk ? check_early_skip<PIX, SP_LDS>(t, J, ws, nd, p) : check_early_skip<PIX, SP_GLOBAL>(t, J, ws, nd, p);
           TK_PROF_ADD(ws, PF_ESKIP);
           if (es_) {
             any = 1;
-            unsigned cost = rdo_trial(t, J, ws, nd, p, J.lambda);
+            unsigned cost = lds_blk ? rdo_trial<PIX, SP_LDS>(t, J, ws, nd, p, J.lambda) : rdo_trial<PIX, SP_GLOBAL>(t, J, ws, nd, p, J.lambda);
             if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); t.sync(); }
           }
         }
         if (any) {
-          int nbits = final_encode(t, J, ws, nd, out);
+          if (J.stats && t.rank == 0) {
+            team_add64(&J.stats[0], (unsigned long long)(nd.bw * nd.bh));
+            if (nd.size == kMaxSb) team_add64(&J.stats[1], 1ull);
+          }
+          int nbits = lds_blk ? final_encode<PIX, SP_LDS>(t, J, ws, nd, out) : final_encode<PIX, SP_GLOBAL>(t, J, ws, nd, out);
           // reference recomputes cost_calc on the final recon: identical to min_cost of that candidate
-          ret = rd_cost(t, J, ws, nd, nbits, J.lambda);
+          ret = lds_blk ? rd_cost<PIX, SP_LDS>(t, J, ws, nd, nbits, J.lambda) : rd_cost<PIX, SP_GLOBAL>(t, J, ws, nd, nbits, J.lambda);
 #if TK_HOST
           if (getenv("THOR_DBG")) fprintf(stderr, "F %d y %d x %d s %d ES mode %d idx %d cost %u bits %d\n", J.frame_num, nd.ypos, nd.xpos, nd.size, nd.best.mode, nd.best.skip_idx, ret, nbits);
 #endif
@@ -1692,7 +1779,7 @@ TK_DEV void process_sb(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamWs
         if (!nd.md_done) {
           const int rect = nd.bw != nd.size || nd.bh != nd.size;
           if (c.encoder_speed == 0 && c.intra_rdo && !rect) cost = mode_decision_par(wg, t, J, ws, sp);
-          else cost = mode_decision(t, J, ws, nd);
+          else cost = nd.size <= kLdsBlk ? mode_decision<PIX, SP_LDS>(t, J, ws, nd) : mode_decision<PIX, SP_GLOBAL>(t, J, ws, nd);
           t.sync();
 #if TK_HOST
           if (getenv("THOR_DBG")) fprintf(stderr, "F %d y %d x %d s %d RDO mode %d cost %u small %u ref %d part %d tb %d mv %d %d\n", J.frame_num, nd.ypos, nd.xpos, nd.size, nd.best.mode, cost, nd.cost_small, nd.best.ref0, nd.best.pb_part, nd.best.tb_param, nd.best.mv0[0].x, nd.best.mv0[0].y);
@@ -1724,7 +1811,8 @@ TK_DEV void process_sb(const Wg wg, const Team t, const FrameJob<PIX>& J, TeamWs
         } else cost = nd.cost_this;
         if (cost <= nd.cost_small) {
           out.pos = nd.bitpos0;
-          final_encode(t, J, ws, nd, out);
+          if (nd.size <= kLdsBlk) final_encode<PIX, SP_LDS>(t, J, ws, nd, out);
+          else final_encode<PIX, SP_GLOBAL>(t, J, ws, nd, out);
         }
       }
       ret = cost < nd.cost_small ? cost : nd.cost_small;

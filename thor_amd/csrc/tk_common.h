@@ -381,6 +381,51 @@ typedef TK_LDS int16_t lds_i16;
 #else
 #define TK_GLOBAL __attribute__((address_space(1)))
 #endif
+// Address space of a block of data as a compile-time property.  The engine's pointers are generic; a generic load/store
+// (flat_*) of data that lives in LDS goes through the texture path (several hundred cycles, ticks vmcnt AND lgkmcnt) where a
+// ds_read takes ~100.  The sample blocks / original samples / chroma coefficient buffers of a coding block live in LDS for
+// blocks up to kLdsBlk and in global memory above; the decision code is therefore instantiated twice (SP = SP_LDS /
+// SP_GLOBAL, chosen once per block decision) and the leaf loops re-type their pointers with spc<SP>().  Workspace structures
+// that ALWAYS live in LDS on the device (XformWs, MeWs, WgShared, ...) are re-typed with ldsc().  Identity on the host.
+enum { SP_GLOBAL = 0, SP_LDS = 1 };
+#if TK_HOST
+template <int SP, class T> TK_DEV T* spc(T* p) { return p; }
+template <class T> TK_DEV T* ldsc(T* p) { return p; }
+TK_DEV int tk_is_lds(const void*) { return 0; }
+#else
+template <int SP, class T> struct SpT;
+template <class T> struct SpT<0, T> { typedef TK_GLOBAL T* ptr; };
+template <class T> struct SpT<1, T> { typedef TK_LDS T* ptr; };
+template <int SP, class T> TK_DEV typename SpT<SP, T>::ptr spc(T* p) {
+  if constexpr (SP == SP_LDS) return (TK_LDS T*)(uint32_t)(uintptr_t)p;  // generic LDS address = aperture | offset
+  else return (TK_GLOBAL T*)p;
+}
+template <class T> TK_DEV TK_LDS T* ldsc(T* p) { return (TK_LDS T*)(uint32_t)(uintptr_t)p; }
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
+TK_DEV int tk_is_lds(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void*)p) ? 1 : 0;
+#else
+  (void)p;
+  return 0;  // host pass of the HIP compilation: never executed
+#endif
+}
+#endif
+// Whole-object load / store of a trivially copyable object that lives in LDS on the device (ds_read / ds_write of its bytes).
+template <class T> TK_DEV T lds_ld(const T* p) {
+  T v;
+  __builtin_memcpy(&v, ldsc(p), sizeof(T));
+  return v;
+}
+template <class T> TK_DEV void lds_st(T* p, const T& v) { __builtin_memcpy(ldsc(p), &v, sizeof(T)); }
+#if !TK_HOST
+template <class T> TK_DEV T lds_ld(const TK_LDS T* p) {  // already LDS-typed
+  T v;
+  __builtin_memcpy(&v, p, sizeof(T));
+  return v;
+}
+template <class T> TK_DEV void lds_st(TK_LDS T* p, const T& v) { __builtin_memcpy(p, &v, sizeof(T)); }
+#endif
 template <class T> TK_DEV const TK_GLOBAL T* gptr(const T* p) { return (const TK_GLOBAL T*)p; }
 template <class T> TK_DEV TK_GLOBAL T* gptr(T* p) { return (TK_GLOBAL T*)p; }
 typedef uint32_t __attribute__((aligned(1), may_alias)) u32_unaligned;
@@ -554,6 +599,10 @@ template <typename PIX> struct FrameJob {
   uint8_t* scratch;        // per-team scratch arena, scratch_bytes each
   size_t scratch_bytes;
   long long* prof;         // optional cycle-counter sink (THOR_PROF builds), 16 slots
+  // content statistics of the inter frames (SURVEY 8d "always log the fraction of SBs that early-skipped"), engine-wide,
+  // may be nullptr: [0] luma pixels coded by the early-skip shortcut (any block size), [1] superblocks that early-skipped
+  // as a whole 128x128 block, [2] superblocks processed, [3] luma pixels processed
+  unsigned long long* stats;
 };
 
 }  // namespace tk

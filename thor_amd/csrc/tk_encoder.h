@@ -365,6 +365,7 @@ template <typename PIX> class Engine {
   backend::GatherItem* d_items = nullptr;
   bool external_interp = false;  // drop-in mode: the caller uploads st[s].interp itself
   bool raw_frames = false;  // drop-in mode: no sequence header / framing; caller consumes st[s].bits
+  unsigned long long* d_stats = nullptr;  // FrameJob::stats (4 counters + spare)
   long long* d_prof = nullptr;  // 32 cycle counters summed over all superblocks (THOR_PROF builds)
   idev::Job<PIX>* d_ijobs = nullptr;
   std::vector<idev::Job<PIX>> h_ijobs;
@@ -440,6 +441,8 @@ template <typename PIX> class Engine {
     d_cjobs = (CdefJob<PIX>*)backend::dev_alloc(sizeof(CdefJob<PIX>) * S);
     h_cjobs.resize(S);
     d_prof = (long long*)backend::dev_alloc(32 * sizeof(long long));
+    d_stats = (unsigned long long*)backend::dev_alloc(8 * sizeof(unsigned long long));
+    backend::dev_memset(d_stats, 0, 8 * sizeof(unsigned long long));
     if (p.interp_ref && !external_interp) { d_ijobs = (idev::Job<PIX>*)backend::dev_alloc(sizeof(idev::Job<PIX>) * S); h_ijobs.resize(S); }
   }
   size_t clpf_stat_words() const { return 4 * ((size_t)(sp.width / 8) * (sp.height / 8) + 2 * (size_t)(sp.width / 16) * (sp.height / 16)); }
@@ -464,6 +467,7 @@ template <typename PIX> class Engine {
     backend::dev_free(d_cjobs); d_cjobs = nullptr;
     backend::dev_free(d_ljobs); d_ljobs = nullptr;
     backend::dev_free(d_prof); d_prof = nullptr;
+    backend::dev_free(d_stats); d_stats = nullptr;
     backend::dev_free(d_ijobs); d_ijobs = nullptr;
   }
 
@@ -595,6 +599,7 @@ template <typename PIX> class Engine {
       J.sb_bits = q.sb_bits; J.sb_words = kSbWords; J.sb_nbits = q.sb_nbits; J.sb_status = q.sb_status;
       J.scratch = q.scratch; J.scratch_bytes = ws_bytes;
       J.prof = d_prof;
+      J.stats = d_stats;
       if (f.frame_type == F_I) backend::dev_memset(q.cells, 0, (size_t)(sp.width / 4) * (sp.height / 4) * sizeof(DbCell));
     }
     backend::h2d(d_jobs, h_jobs.data(), sizeof(FrameJob<PIX>) * S);

@@ -71,32 +71,35 @@ TK_DEV unsigned mv_cost(double lam, int dy, int dx) {
 
 // add_mvcandidate (encode_block.c:69-82) - call from ONE lane.
 TK_DEV void add_mvcand(MeWs* w_, int r, mv_t mv) {
-  MeLists* w = w_->lists;
+  const auto w = ldsc(lds_ld(&w_->lists));
   mv_t imv = mk_mv((mv.x + 2) >> 2, (mv.y + 2) >> 2);
   unsigned long long m = 1ull << ((((int)imv.y << 3) ^ (int)imv.x) & 63);
   if (!(m & w->mvcand_mask[r])) {
-    w->mvcand[r][w->mvcand_num[r]] = imv;
-    w->mvcand_num[r] += 1;
+    const int n = w->mvcand_num[r];
+    w->mvcand[r][n].x = imv.x; w->mvcand[r][n].y = imv.y;
+    w->mvcand_num[r] = n + 1;
   }
   w->mvcand_mask[r] |= m;
 }
 
 // |a-b| summed over 4 horizontally adjacent samples (a: 4-sample aligned, b: any alignment).
-template <typename PIX> TK_DEV int sad4(const PIX* a, const PIX* b) {
-  return iabs((int)a[0] - (int)b[0]) + iabs((int)a[1] - (int)b[1]) + iabs((int)a[2] - (int)b[2]) + iabs((int)a[3] - (int)b[3]);
-}
+// a: original block in address space SP (4-sample aligned), b: reference plane (global)
+template <int SP, typename PIX> TK_DEV int sad4(const PIX* a, const PIX* b) {
 #if !TK_HOST
-template <> __device__ __forceinline__ int sad4<uint8_t>(const uint8_t* a, const uint8_t* b) {
-  uint32_t va;
-  __builtin_memcpy(&va, a, 4);  // a: original block (frame plane, or a per-wave block that may live in LDS); b: reference plane
-  return (int)__builtin_amdgcn_sad_u8(va, gload32(b), 0u);  // v_sad_u8: 4 byte-SADs per lane-op
-}
+  if constexpr (sizeof(PIX) == 1) {
+    const uint32_t va = *(const typename SpT<SP, const uint32_t>::ptr)spc<SP>(a);
+    return (int)__builtin_amdgcn_sad_u8(va, gload32(b), 0u);  // v_sad_u8: 4 byte-SADs per lane-op
+  }
 #endif
+  const auto as = spc<SP>(a);
+  return iabs((int)as[0] - (int)b[0]) + iabs((int)as[1] - (int)b[1]) + iabs((int)as[2] - (int)b[2]) + iabs((int)as[3] - (int)b[3]);
+}
 
 // sad[c] = SAD(org block, block at base(c)) for c < ncand; full-pel candidates given as pointers.
 // Work item = (candidate, row, group of 4 samples).
-template <typename PIX, class F>
-TK_DEV void sad_many_ptr(const Team t, int* sad, int ncand, const PIX* org, int ostride, int w, int h, int rstride, F base) {
+template <int SP, typename PIX, class F>
+TK_DEV void sad_many_ptr(const Team t, int* sad_, int ncand, const PIX* org, int ostride, int w, int h, int rstride, F base) {
+  const auto sad = ldsc(sad_);
   // G lanes cooperate on one candidate (G = min(team, items per candidate), a power of two), P = team/G
   // candidates are evaluated per pass; partial sums are combined with xor-shuffles (no atomics).
   const int gpr = w >> 2, nit = h * gpr;
@@ -109,11 +112,11 @@ TK_DEV void sad_many_ptr(const Team t, int* sad, int ncand, const PIX* org, int 
     int la = 0, lb = 0;
     if (ca < ncand) {
       const PIX* b = base(ca);
-      for (int r = sub; r < nit; r += G) { int i = r >> lg, g = r & (gpr - 1); la += sad4(org + i * ostride + 4 * g, b + i * rstride + 4 * g); }
+      for (int r = sub; r < nit; r += G) { int i = r >> lg, g = r & (gpr - 1); la += sad4<SP>(org + i * ostride + 4 * g, b + i * rstride + 4 * g); }
     }
     if (cb < ncand) {
       const PIX* b = base(cb);
-      for (int r = sub; r < nit; r += G) { int i = r >> lg, g = r & (gpr - 1); lb += sad4(org + i * ostride + 4 * g, b + i * rstride + 4 * g); }
+      for (int r = sub; r < nit; r += G) { int i = r >> lg, g = r & (gpr - 1); lb += sad4<SP>(org + i * ostride + 4 * g, b + i * rstride + 4 * g); }
     }
     for (int d = G >> 1; d >= 1; d >>= 1) { la += team_shfl_xor(t, la, d); lb += team_shfl_xor(t, lb, d); }
     if (sub == 0) {
@@ -154,9 +157,14 @@ TK_DEV unsigned long long eval_min(const Team t, int n, int nit, PrepF prep, Ite
 
 // 4-sample load helpers for the packed SAD
 template <typename PIX> struct Px4 { PIX v[4]; };
-template <typename PIX> TK_DEV Px4<PIX> ld4(const PIX* p) {  // any address space (the original block may live in LDS)
+template <int SP, typename PIX> TK_DEV Px4<PIX> ld4(const PIX* p) {  // p: original block in address space SP, 4-sample aligned
   Px4<PIX> r;
+#if TK_HOST
   __builtin_memcpy(&r, p, sizeof(r));
+#else
+  if constexpr (sizeof(PIX) == 1) { const uint32_t v = *(const typename SpT<SP, const uint32_t>::ptr)spc<SP>(p); __builtin_memcpy(&r, &v, 4); }
+  else { const unsigned long long v = *(const typename SpT<SP, const unsigned long long>::ptr)spc<SP>(p); __builtin_memcpy(&r, &v, 8); }
+#endif
   return r;
 }
 template <typename PIX> TK_DEV Px4<PIX> ld4g(const PIX* p) {  // p: global memory (reference plane)
@@ -186,7 +194,7 @@ template <> __device__ __forceinline__ int sad4v<uint8_t>(const Px4<uint8_t>& a,
 // candidate list is one pass; G = items/16 lanes share a candidate for larger PUs (xor-shuffle
 // reduction).  All reference loads of a pass are issued before the first use.
 // cand(c) -> {clipped mv, pointer to the displaced reference block}; returns min (cost<<32 | index).
-template <typename PIX, class CandF, class CostF>
+template <int SP, typename PIX, class CandF, class CostF>
 TK_DEV unsigned long long eval_fullpel(const Team t, int n, const PIX* org, int ostride, int rstride, int width, int height,
                                        CandF cand, CostF cost, const MeWin& win) {
   const int gpr = width >> 2, lg = ilog2((unsigned)gpr), nit = height * gpr;
@@ -209,7 +217,7 @@ TK_DEV unsigned long long eval_fullpel(const Team t, int n, const PIX* org, int 
     for (int k = 0; k < 16; k++)
       if (k < ipl) {
         const int r = sub + k * G, i = r >> lg, g = r & (gpr - 1);
-        o[k] = ld4(org + i * ostride + 4 * g);
+        o[k] = ld4<SP>(org + i * ostride + 4 * g);
       }
   }
   for (int c0 = 0; c0 < n; c0 += 2 * P) {
@@ -240,7 +248,7 @@ TK_DEV unsigned long long eval_fullpel(const Team t, int n, const PIX* org, int 
             for (int k = 0; k < 16; k++)
               if (k < cnt) {
                 const int r = sub + (k0 + k) * G, i = r >> lg, g = r & (gpr - 1);
-                if (!hoist) o[k] = ld4(org + i * ostride + 4 * g);
+                if (!hoist) o[k] = ld4<SP>(org + i * ostride + 4 * g);
                 uint32_t ov;
                 __builtin_memcpy(&ov, &o[k], 4);
                 const int off = i * win.Ww + 4 * g;
@@ -267,7 +275,7 @@ TK_DEV unsigned long long eval_fullpel(const Team t, int n, const PIX* org, int 
         for (int k = 0; k < 16; k++)
           if (k < cnt) {
             const int r = sub + (k0 + k) * G, i = r >> lg, g = r & (gpr - 1);
-            if (!hoist) o[k] = ld4(org + i * ostride + 4 * g);
+            if (!hoist) o[k] = ld4<SP>(org + i * ostride + 4 * g);
             a[k] = ld4g(xa.p + i * rstride + 4 * g);
             if (vb) b[k] = ld4g(xb.p + i * rstride + 4 * g);
           }
@@ -307,7 +315,8 @@ struct MeArgs {
 // sad_calc_fasthalf_simd enc_kernels.c:330, sad_calc_fastquarter :286-415): the SADs of the 8 half-
 // (quarter-) pel neighbours of the centre built from rounding (avg) and truncating (rdavg) byte averages;
 // returns the smallest of them and its offset.  Lanes split the samples, 8 shuffle reductions.
-template <typename PIX> TK_DEV unsigned fast_halfpel(const Team t, const PIX* a, const PIX* b, int as, int bs, int width, int height, int* bx, int* by) {
+template <int SP, typename PIX> TK_DEV unsigned fast_halfpel(const Team t, const PIX* a_, const PIX* b, int as, int bs, int width, int height, int* bx, int* by) {
+  const auto a = spc<SP>(a_);
   int tl = 0, tr = 0, br = 0, bl = 0, top = 0, right = 0, down = 0, left = 0;
   const Pow2 dw = mk_pow2(width);
   for (int r = t.rank; r < width * height; r += t.size) {
@@ -345,7 +354,8 @@ template <typename PIX> TK_DEV unsigned fast_halfpel(const Team t, const PIX* a,
   return utop;
 }
 
-template <typename PIX> TK_DEV unsigned fast_quarterpel(const Team t, const PIX* o_, const PIX* r_, int os, int rs, int width, int height, int* bx, int* by) {
+template <int SP, typename PIX> TK_DEV unsigned fast_quarterpel(const Team t, const PIX* o__, const PIX* r_, int os, int rs, int width, int height, int* bx, int* by) {
+  const auto o_ = spc<SP>(o__);
   int tl = 0, tr = 0, br = 0, bl = 0, top = 0, right = 0, down = 0, left = 0;
   const int hx = *bx, hy = *by;  // half-pel offset chosen before (0 or +-2): selects the interpolation pattern
   const Pow2 dw = mk_pow2(width);
@@ -395,10 +405,17 @@ template <typename PIX> TK_DEV unsigned fast_quarterpel(const Team t, const PIX*
   return utop;
 }
 
-template <typename PIX>
-TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const PIX* ref, const MeArgs& a_in, mv_t mvc,
+// SP: address space of the original-sample block `org` (LDS copy for coding blocks up to kLdsBlk and their 2*org-pred
+// blocks, frame plane / global scratch above); w always lives in LDS on the device.
+template <typename PIX, int SP>
+TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const PIX* ref, const MeArgs& a_in, mv_t mvc,
                                 mv_t mvp, int ref_idx, mv_t* mv_out) {
   TK_PROF_T0();
+  const auto w = ldsc(w_);
+  const auto lists = ldsc(lds_ld(&w_->lists));
+  const auto orgs = spc<SP>(org);
+  auto cmv_get = [&](int c) -> mv_t { return mk_mv(w->cmv[c].x, w->cmv[c].y); };
+  auto cmv_set = [&](int c, mv_t m) { w->cmv[c].x = m.x; w->cmv[c].y = m.y; };
 #ifdef THOR_EXP_UNIFORM
   MeArgs a_u;
   a_u.cb_size = tk_uniform(a_in.cb_size); a_u.ostride = tk_uniform(a_in.ostride); a_u.width = tk_uniform(a_in.width);
@@ -419,11 +436,6 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
   unsigned min_sad = kCostInit;
   mv_t mv_opt = mk_mv(0, 0);
   mv_t mv_ref = mk_mv(((mvc.x + 2) >> 2) << 2, ((mvc.y + 2) >> 2) << 2);
-  auto fullpel = [&](int c) -> const PIX* {
-    mv_t m = w->cmv[c];
-    return ref + (s * (m.y >> 2)) * a.rstride + s * (m.x >> 2);
-  };
-
   struct FP { mv_t mv; const PIX* p; int dx, dy; };
   auto fp_cost = [&](const FP& x, int sad) -> unsigned {
     return ((unsigned)sad >> sh) + mv_cost(a.lam, x.mv.y - mvp.y, x.mv.x - mvp.x);
@@ -450,14 +462,14 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
       auto widepel = [&](int c5) -> const PIX* {
         int c = c5 / 5, o = c5 - c * 5;
         int off = o == 0 ? -3 : o == 1 ? -1 : o == 2 ? 0 : o == 3 ? 1 : 3;
-        mv_t mm = w->cmv[base + c];
+        mv_t mm = cmv_get(base + c);
         return ref + (s * (mm.y >> 2)) * a.rstride + s * (mm.x >> 2) + off;
       };
-      sad_many_ptr(t, w->sad, m * 5, org, a.ostride, a.width, a.height, a.rstride, widepel);
+      sad_many_ptr<SP>(t, w_->sad, m * 5, org, a.ostride, a.width, a.height, a.rstride, widepel);
       unsigned long long k = ~0ull;
       for (int lc = t.rank; lc < m; lc += t.size) {
         const int c = base + lc;
-        mv_t mm = w->cmv[c];
+        mv_t mm = cmv_get(c);
         int x = 0;
         unsigned best = 1u << 31;
         for (int o = 0; o < 5; o++) {
@@ -465,7 +477,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
           if (v < best) { best = v; x = o == 0 ? -3 : o == 1 ? -1 : o == 2 ? 0 : o == 3 ? 1 : 3; }
         }
         mm.x = (int16_t)(mm.x + ((s * x) << 2));
-        w->cmv[c] = mm;  // adjusted mv, looked up again if this candidate wins
+        cmv_set(c, mm);  // adjusted mv, looked up again if this candidate wins
         unsigned long long kk = ((unsigned long long)((best >> sh) + mv_cost(a.lam, mm.y - mvp.y, mm.x - mvp.x)) << 32) | (unsigned)c;
         k = kk < k ? kk : k;
       }
@@ -481,10 +493,10 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
   win.on = 0; win.w32 = nullptr; win.ox = win.oy = win.Ww = win.Wh = 0;
 #if TK_ME_WINDOW
   if constexpr (sizeof(PIX) == 1) {
-    if (w->win && a.cb_size <= kMeWinMaxCb && a.speed == 0) {
+    if (w_->win && a.cb_size <= kMeWinMaxCb && a.speed == 0) {
       win.Ww = a.width + 2 * kMeWinR; win.Wh = a.height + 2 * kMeWinR;
       win.ox = s * (mv_ref.x >> 2) - kMeWinR; win.oy = s * (mv_ref.y >> 2) - kMeWinR;
-      win.w32 = w->win;
+      win.w32 = w_->win;
       win.on = 1;
       const int wpr = win.Ww >> 2, total = wpr * win.Wh;
       t.sync();
@@ -495,9 +507,9 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
 #if TK_HOST
         uint32_t v;
         __builtin_memcpy(&v, ref + ay * a.rstride + ax, 4);
-        w->win[k] = v;
+        w_->win[k] = v;
 #else
-        ((TK_LDS uint32_t*)w->win)[k] = gload32(ref + ay * a.rstride + ax);
+        ((TK_LDS uint32_t*)w_->win)[k] = gload32(ref + ay * a.rstride + ax);
 #endif
       }
       t.sync();
@@ -516,13 +528,13 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
     };
     if (step == 32 && a.cb_size == 16 && a.speed == 1) {  // first ring by widesad at encoder_speed 1
       t.sync();
-      for (int c = t.rank; c < n; c += t.size) w->cmv[c] = tele(c).mv;
+      for (int c = t.rank; c < n; c += t.size) cmv_set(c, tele(c).mv);
       t.sync();
       unsigned long long k = eval_wide(n);
-      if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = w->cmv[(int)(unsigned)k]; }
+      if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = cmv_get((int)(unsigned)k); }
       t.sync();
     } else {
-      unsigned long long k = eval_fullpel(t, n, org, a.ostride, a.rstride, a.width, a.height, tele, fp_cost, win);
+      unsigned long long k = eval_fullpel<SP>(t, n, org, a.ostride, a.rstride, a.width, a.height, tele, fp_cost, win);
       if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = tele((int)(unsigned)k).mv; }
     }
     mv_ref = mv_opt;
@@ -534,22 +546,22 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
 #endif
   // --- candidate list (encode_block.c:564-581)
   {
-    const int n = TKU(w->lists->mvcand_num[ref_idx]);
+    const int n = TKU(lists->mvcand_num[ref_idx]);
     if (n > 0) {
       const int wide = a.cb_size == 16;
       for (int c = t.rank; c < n; c += t.size) {
-        mv_t m = w->lists->mvcand[ref_idx][c];
-        w->cmv[c] = clip_mv(mk_mv(m.x << 2, m.y << 2), a.ypos, a.xpos, a.fwidth, a.fheight, a.cb_size, a.cb_size, a.sign);
+        const mv_t m = mk_mv(lists->mvcand[ref_idx][c].x, lists->mvcand[ref_idx][c].y);
+        cmv_set(c, clip_mv(mk_mv(m.x << 2, m.y << 2), a.ypos, a.xpos, a.fwidth, a.fheight, a.cb_size, a.cb_size, a.sign));
       }
       t.sync();
       if (wide) {
         unsigned long long bestk = eval_wide(n);
-        if ((unsigned)(bestk >> 32) < min_sad) { min_sad = (unsigned)(bestk >> 32); mv_opt = w->cmv[(int)(unsigned)bestk]; }
+        if ((unsigned)(bestk >> 32) < min_sad) { min_sad = (unsigned)(bestk >> 32); mv_opt = cmv_get((int)(unsigned)bestk); }
         t.sync();
       } else {
-        auto cl = [&](int c) -> FP { return mk_fp(w->cmv[c]); };  // cmv already clipped: clip_mv is idempotent
-        unsigned long long k = eval_fullpel(t, n, org, a.ostride, a.rstride, a.width, a.height, cl, fp_cost, win);
-        if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = w->cmv[(int)(unsigned)k]; }
+        auto cl = [&](int c) -> FP { return mk_fp(cmv_get(c)); };  // cmv already clipped: clip_mv is idempotent
+        unsigned long long k = eval_fullpel<SP>(t, n, org, a.ostride, a.rstride, a.width, a.height, cl, fp_cost, win);
+        if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = cmv_get((int)(unsigned)k); }
         t.sync();
       }
     }
@@ -574,7 +586,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
         return mk_fp(mk_mv(centre.x + ox * 4, centre.y + oy * 4));
       };
       int which = -1;
-      unsigned long long k = eval_fullpel(t, n, org, a.ostride, a.rstride, a.width, a.height, hex, fp_cost, win);
+      unsigned long long k = eval_fullpel<SP>(t, n, org, a.ostride, a.rstride, a.width, a.height, hex, fp_cost, win);
       if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); which = (int)(unsigned)k; mv_opt = hex(which).mv; }
       int best_dir = which < 0 ? -1 : (start + which) % 6;
       mv_ref = mv_opt;
@@ -599,28 +611,28 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
     const int d = pass == 0 ? 2 : 1;
     const mv_t base = pass == 0 ? mv_ref : mv_opt;
     // order: (0,-d) (-d,0) (d,0) (0,d) (-d,-d) (-d,d) (d,-d) (d,d) as (y,x)
-    struct SP { mv_t mv; SubPel sp; };
-    auto sub_prep = [&](int c) -> SP {
+    struct SPc { mv_t mv; SubPel sp; };
+    auto sub_prep = [&](int c) -> SPc {
       int oy = c == 0 ? 0 : c == 1 ? -d : c == 2 ? d : c == 3 ? 0 : c == 4 ? -d : c == 5 ? -d : d;
       int ox = c == 0 ? -d : c == 1 ? 0 : c == 2 ? 0 : c == 3 ? d : c == 4 ? -d : c == 5 ? d : c == 6 ? -d : d;
-      SP x;
+      SPc x;
       x.mv = mk_mv(base.x + ox, base.y + oy);
       x.sp = luma_setup(x.mv, a.sign, a.width, a.height, a.fwidth, a.fheight, a.xpos, a.ypos, a.enable_bipred);
       return x;
     };
     const Pow2 dw = mk_pow2(a.width);
-    auto sub_item = [&](const SP& x, int r) -> int {
+    auto sub_item = [&](const SPc& x, int r) -> int {
       int i, j;
       split2(dw, r, i, j);
-      return iabs((int)org[i * a.ostride + j] - luma_sample(ref, a.rstride, i, j, x.sp, a.enable_bipred, a.bitdepth));
+      return iabs((int)orgs[i * a.ostride + j] - luma_sample(ref, a.rstride, i, j, x.sp, a.enable_bipred, a.bitdepth));
     };
-    auto sub_cost = [&](int, const SP& x, int sad) -> unsigned {
+    auto sub_cost = [&](int, const SPc& x, int sad) -> unsigned {
       return ((unsigned)sad >> sh) + mv_cost(a.lam, x.mv.y - mvp.y, x.mv.x - mvp.x);
     };
     // Fast path: all eight candidates read from the 8x8 window around the centre's integer position (always,
     // except when luma_setup's frame-edge clamps pull a candidate further away).
     TK_PROF_MARK(ps0_);
-    SP cand[8];
+    SPc cand[8];
     const SubPel ctr = luma_setup(base, a.sign, a.width, a.height, a.fwidth, a.fheight, a.xpos, a.ypos, a.enable_bipred);
     int in_window = 1;
     for (int c = 0; c < 8; c++) {
@@ -651,7 +663,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
         const PIX* p0 = ref + (i + ctr.ver_int - 3) * a.rstride + (j + ctr.hor_int - 3);
         WinRow<PIX> win[8];
         for (int q = 0; q < 8; q++) win_load(p0 + q * a.rstride, win[q]);
-        const int o = (int)org[i * a.ostride + j];
+        const int o = (int)orgs[i * a.ostride + j];
         if constexpr (sizeof(PIX) == 1) {
           for (int q = 0; q < 8; q++) win[q] = win_bias(win[q]);
           for (int c = 0; c < 8; c++) {
@@ -690,13 +702,13 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
     // pricing the half-pel vector, so for a backward reference the rate term sees the negated vector.
     mv_t mr = mk_mv(mv_ref.x * s, mv_ref.y * s);
     int spx = 0, spy = 0, xd_hp = 0, yd_hp = 0, xd_qp = 0, yd_qp = 0;
-    unsigned sad = fast_halfpel(t, org, ref + (mr.y >> 2) * a.rstride + (mr.x >> 2), a.ostride, a.rstride, a.width, a.height, &spx, &spy) >> sh;
+    unsigned sad = fast_halfpel<SP>(t, org, ref + (mr.y >> 2) * a.rstride + (mr.x >> 2), a.ostride, a.rstride, a.width, a.height, &spx, &spy) >> sh;
     sad += mv_cost(a.lam, mr.y + s * spy - mvp.y, mr.x + s * spx - mvp.x);
     if (sad < cmin) { cmin = sad; xd_hp = s * spx; yd_hp = s * spy; }
     spx = xd_hp; spy = yd_hp;
     mr = mk_mv(mv_opt.x + s * spx, mv_opt.y + s * spy);
     mv_opt = mk_mv(mv_opt.x + xd_hp, mv_opt.y + yd_hp);
-    sad = fast_quarterpel(t, org, ref + (s * (mr.y >> 2)) * a.rstride + s * (mr.x >> 2), a.ostride, a.rstride, a.width, a.height, &spx, &spy) >> sh;
+    sad = fast_quarterpel<SP>(t, org, ref + (s * (mr.y >> 2)) * a.rstride + s * (mr.x >> 2), a.ostride, a.rstride, a.width, a.height, &spx, &spy) >> sh;
     sad += mv_cost(a.lam, mr.y + s * spy - mvp.y, mr.x + s * spx - mvp.x);
     if (sad < cmin) { cmin = sad; xd_qp = s * spx; yd_qp = s * spy; }
     mv_opt = mk_mv(mv_opt.x + xd_qp, mv_opt.y + yd_qp);
@@ -714,9 +726,11 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w, const PIX* org, const P
 // and (0,0) without touching the count) and its use of the list's full-pel entries
 // as quarter-pel vectors.  The vector is clipped for ref0's sign and then AGAIN for ref1's sign; ref0 is
 // predicted with the once-clipped vector, ref1 and the cost use the twice-clipped one.
-template <typename PIX>
-TK_DEVNI unsigned motion_estimate_bi(const Team t, MeWs* w, const PIX* org, const PIX* ref0, const PIX* ref1, const MeArgs& a,
+template <typename PIX, int SP>
+TK_DEVNI unsigned motion_estimate_bi(const Team t, MeWs* w_, const PIX* org_, const PIX* ref0, const PIX* ref1, const MeArgs& a,
                                     mv_t mvc, mv_t mvp, int r_idx0, mv_t* mv_out) {
+  const auto org = spc<SP>(org_);
+  const auto lists = ldsc(lds_ld(&w_->lists));
   const int sh = a.bitdepth - 8;
   const int size = a.cb_size;
   unsigned min_sad = kCostInit;
@@ -774,13 +788,13 @@ TK_DEVNI unsigned motion_estimate_bi(const Team t, MeWs* w, const PIX* org, cons
   // extra candidates (+ side effect on the shared list)
   t.sync();
   if (t.rank == 0) {
-    for (int idx = w->lists->mvcand_num[r_idx0]; idx < 4; idx++) w->lists->mvcand[r_idx0][idx] = mk_mv(0, 0);
-    w->lists->mvcand[r_idx0][4] = mvp;
-    w->lists->mvcand[r_idx0][5] = mk_mv(0, 0);
+    for (int idx = lists->mvcand_num[r_idx0]; idx < 4; idx++) { lists->mvcand[r_idx0][idx].x = 0; lists->mvcand[r_idx0][idx].y = 0; }
+    lists->mvcand[r_idx0][4].x = mvp.x; lists->mvcand[r_idx0][4].y = mvp.y;
+    lists->mvcand[r_idx0][5].x = 0; lists->mvcand[r_idx0][5].y = 0;
   }
   t.sync();
   {
-    auto cand = [&](int c) -> BI { return mk_bi(w->lists->mvcand[r_idx0][c]); };
+    auto cand = [&](int c) -> BI { return mk_bi(mk_mv(lists->mvcand[r_idx0][c].x, lists->mvcand[r_idx0][c].y)); };
     unsigned long long k = eval_min(t, 6, size * size, cand, bi_item, bi_cost);
     if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = cand((int)(unsigned)k).mv; }
   }

@@ -225,9 +225,10 @@ TK_DEV int luma_sample_win8(const WinRow<uint8_t> w[6], const SubPel& s, const P
 }
 
 // get_inter_prediction_luma for a whole PU (team-parallel over samples).
-template <typename PIX>
-TK_DEV void pred_luma(const Team t, PIX* dst, int dstride, const PIX* ref, int rstride, int width, int height, mv_t mv,
+template <int SP, typename PIX>
+TK_DEV void pred_luma(const Team t, PIX* dst_, int dstride, const PIX* ref, int rstride, int width, int height, mv_t mv,
                       int sign, int bipred, int pic_w, int pic_h, int xpos, int ypos, int bitdepth) {
+  const auto dst = spc<SP>(dst_);
   SubPel s = luma_setup(mv, sign, width, height, pic_w, pic_h, xpos, ypos, bipred);
   const Div2 pw = mk_div(width);  // rectangular frame-edge skip blocks have non power-of-two widths
   for (int k = t.rank; k < width * height; k += t.size) {
@@ -237,9 +238,10 @@ TK_DEV void pred_luma(const Team t, PIX* dst, int dstride, const PIX* ref, int r
   }
 }
 
-template <typename PIX>
-TK_DEV void pred_chroma(const Team t, PIX* dst, int dstride, const PIX* ref, int rstride, int width, int height,
+template <int SP, typename PIX>
+TK_DEV void pred_chroma(const Team t, PIX* dst_, int dstride, const PIX* ref, int rstride, int width, int height,
                         mv_t mv, int sign, int pic_w2, int pic_h2, int xpos, int ypos, int bitdepth) {
+  const auto dst = spc<SP>(dst_);
   int mx = sign ? -mv.x : mv.x, my = sign ? -mv.y : mv.y;
   int vf = my & 7, hf = mx & 7;
   int vi = my >> 3, hi = mx >> 3;
@@ -269,8 +271,9 @@ TK_DEV void pred_chroma(const Team t, PIX* dst, int dstride, const PIX* ref, int
 
 // get_inter_prediction_yuv (inter_prediction.c:185-226), 4:2:0.  dst planes are compact blocks
 // of stride `size` (luma) / size/2 (chroma).  `split`: 1 => four quadrant PUs with mv_arr[0..3].
-template <typename PIX>
-TK_DEVNI void pred_inter_yuv(const Team t, const Plane3<PIX>& ref, PIX* py, PIX* pu, PIX* pv, int ypos, int xpos,
+// SP: address space of the destination blocks py / pu / pv
+template <int SP, typename PIX>
+TK_DEVNI void pred_inter_yuv(const Team t, const Plane3<PIX> ref, PIX* py, PIX* pu, PIX* pv, int ypos, int xpos,
                            int size, int bw, int bh, const mv_t* mv_arr, int sign, int pic_w, int pic_h,
                            int enable_bipred, int split, int bitdepth) {
   const int div = split + 1;
@@ -287,19 +290,22 @@ TK_DEVNI void pred_inter_yuv(const Team t, const Plane3<PIX>& ref, PIX* py, PIX*
     int offrY = idy * bheight * ref.sy + idx * bwidth;
     int offrC = ((idy * bheight * ref.sc) >> 1) + ((idx * bwidth) >> 1);
     mv_t mv = clip_mv(mv_arr[index], ypos, xpos, pic_w, pic_h, bwidth, bheight, sign);
-    pred_luma(t, py + offpY, pstride, ry + offrY, ref.sy, bwidth, bheight, mv, sign, enable_bipred, pic_w, pic_h,
+    pred_luma<SP>(t, py + offpY, pstride, ry + offrY, ref.sy, bwidth, bheight, mv, sign, enable_bipred, pic_w, pic_h,
               xpos, ypos, bitdepth);
-    pred_chroma(t, pu + offpC, pstride >> 1, ru + offrC, ref.sc, bwidth >> 1, bheight >> 1, mv, sign, pic_w >> 1,
+    pred_chroma<SP>(t, pu + offpC, pstride >> 1, ru + offrC, ref.sc, bwidth >> 1, bheight >> 1, mv, sign, pic_w >> 1,
                 pic_h >> 1, xc, yc, bitdepth);
-    pred_chroma(t, pv + offpC, pstride >> 1, rv + offrC, ref.sc, bwidth >> 1, bheight >> 1, mv, sign, pic_w >> 1,
+    pred_chroma<SP>(t, pv + offpC, pstride >> 1, rv + offrC, ref.sc, bwidth >> 1, bheight >> 1, mv, sign, pic_w >> 1,
                 pic_h >> 1, xc, yc, bitdepth);
   }
 }
 
 // average_blocks_all: truncating (a+b)>>1 (inter_prediction.c:228-247).
-template <typename PIX>
-TK_DEV void average_yuv(const Team t, PIX* dy, PIX* du, PIX* dv, const PIX* ay, const PIX* au, const PIX* av,
-                        const PIX* by, const PIX* bu, const PIX* bv, int size, int bw, int bh) {
+template <int SP, typename PIX>
+TK_DEV void average_yuv(const Team t, PIX* dy_, PIX* du_, PIX* dv_, const PIX* ay_, const PIX* au_, const PIX* av_,
+                        const PIX* by_, const PIX* bu_, const PIX* bv_, int size, int bw, int bh) {
+  const auto dy = spc<SP>(dy_); const auto du = spc<SP>(du_); const auto dv = spc<SP>(dv_);
+  const auto ay = spc<SP>(ay_); const auto au = spc<SP>(au_); const auto av = spc<SP>(av_);
+  const auto by = spc<SP>(by_); const auto bu = spc<SP>(bu_); const auto bv = spc<SP>(bv_);
   for (int k = t.rank; k < bw * bh; k += t.size) {
     int i, j;
     split2(mk_div(bw), k, i, j);
@@ -328,7 +334,8 @@ template <typename PIX> struct IntraEdge {
 // make_top_and_left (intra_prediction.c:57-183).  rec_frame points at the CB's top-left sample in
 // the reconstructed frame; rblock at the TU's top-left in the CB-local recon block (tb_split only);
 // (i, j) = TU offset inside the CB; (ypos, xpos) = CB position in this plane.
-template <typename PIX>
+// SP: address space of rblock (the coding block's own reconstruction buffer)
+template <int SP, typename PIX>
 TK_DEV void make_edges(const Team t, IntraEdge<PIX>* e, const PIX* rec_frame, int fstride, const PIX* rblock,
                        int rbstride, int i, int j, int ypos, int xpos, int size, int cb_upright, int cb_downleft,
                        int tb_split, int bitdepth) {
@@ -351,34 +358,38 @@ TK_DEV void make_edges(const Team t, IntraEdge<PIX>* e, const PIX* rec_frame, in
   const int toplen = upright ? size + 1 : size;
   const int top_from_block = tb_split && i != 0;
   const int left_from_block = tb_split && j != 0;
-  const PIX* trow = top_from_block ? (rblock - rbstride) : (rec_frame - fstride + j);
-  const PIX* const rblock_g = rblock;  // CB-local recon block: per-wave scratch, in LDS for small CBs
+  const auto rblock_g = spc<SP>(rblock);  // CB-local recon block: per-wave scratch, in LDS for small CBs
   const TK_GLOBAL PIX* const frame_g = gptr(rec_frame);
+  const auto e_top = ldsc(e->top);
+  const auto e_left = ldsc(e->left);
   // tb_split==0 => i==j==0 so (rec_frame - fstride + j) is the reference's &rec_frame[-fstride+j].
   const int top_dflt = (ypos + i == 0);
   const int left_dflt = (xpos + j == 0);
   for (int k = t.rank; k < len; k += t.size) {
     PIX tv, lv;
     if (top_dflt) tv = dflt;
-    else tv = trow[k < toplen ? k : toplen - 1];
+    else {
+      const int kk = k < toplen ? k : toplen - 1;
+      tv = top_from_block ? rblock_g[kk - rbstride] : frame_g[kk - fstride + j];
+    }
     if (left_dflt) lv = dflt;
     else {
       int kk = k < leftlen ? k : leftlen - 1;
       lv = left_from_block ? rblock_g[kk * rbstride - 1] : frame_g[(i + kk) * fstride - 1];
     }
-    ((TK_LDS PIX*)e->top)[k] = tv;
-    ((TK_LDS PIX*)e->left)[k] = lv;
+    e_top[k] = tv;
+    e_left[k] = lv;
   }
   if (t.rank == 0) {
     PIX tl;
     if (top_dflt) {
       tl = left_dflt ? dflt : (left_from_block ? rblock_g[-1] : frame_g[i * fstride - 1]);  // = left[0]
     } else if (!top_from_block) {
-      tl = xpos > 0 ? frame_g[-fstride + j - 1] : trow[0];
+      tl = xpos > 0 ? frame_g[-fstride + j - 1] : frame_g[-fstride + j];
     } else {
-      tl = xpos > 0 ? (j > 0 ? rblock_g[-rbstride - 1] : frame_g[(i - 1) * fstride - 1]) : trow[0];
+      tl = xpos > 0 ? (j > 0 ? rblock_g[-rbstride - 1] : frame_g[(i - 1) * fstride - 1]) : rblock_g[-rbstride];
     }
-    e->top_left = tl;
+    *ldsc(&e->top_left) = tl;
   }
   t.sync();
 }
@@ -395,17 +406,19 @@ template <typename PIX> TK_DEV int f5(const PIX* a, int k, int size) {
 
 // get_intra_prediction (intra_prediction.c:403-428) - writes size x size at dst (stride dstride).
 // (ypos, xpos) = TU position in this plane (only the ==0 tests matter, for DC).
-template <typename PIX>
-TK_DEV void pred_intra(const Team t, const IntraEdge<PIX>* e, int ypos, int xpos, int size, PIX* dst, int dstride,
+template <int SP, typename PIX>
+TK_DEV void pred_intra(const Team t, const IntraEdge<PIX>* e, int ypos, int xpos, int size, PIX* dst_, int dstride,
                        int mode, int bitdepth) {
+  PIX* dst = dst_;
 #ifdef THOR_EXP_UNIFORM
   e = tk_uniform_ptr(e); dst = tk_uniform_ptr(dst); ypos = tk_uniform(ypos); xpos = tk_uniform(xpos); size = tk_uniform(size);
   dstride = tk_uniform(dstride); mode = tk_uniform(mode); bitdepth = tk_uniform(bitdepth);
 #endif
   typedef TK_LDS PIX lpix;  // the edge arrays live in LDS on the device (see tk_common.h)
-  const lpix* left = (const lpix*)e->left;
-  const lpix* top = (const lpix*)e->top;
-  const int tl = e->top_left;
+  const lpix* left = (const lpix*)ldsc(e->left);
+  const lpix* top = (const lpix*)ldsc(e->top);
+  const int tl = *ldsc(&e->top_left);
+  const auto dsts = spc<SP>(dst);
   int dc = 0, tlF = 0, tlP = 0;
   if (mode == 0 || mode > 9) {
     const lpix* a = xpos != 0 ? left : top;
@@ -460,7 +473,7 @@ TK_DEV void pred_intra(const Team t, const IntraEdge<PIX>* e, int ypos, int xpos
       } break;
       default: v = dc; break;
     }
-    dst[i * dstride + j] = (PIX)v;
+    dsts[i * dstride + j] = (PIX)v;
   }
 }
 

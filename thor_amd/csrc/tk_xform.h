@@ -37,6 +37,14 @@ struct XformTabs {
   int16_t dct32[1024];
   int16_t izz[336];
 };
+// The transform stages take the basis from Team::izz (which points at XformTabs::izz of the workgroup's tables): no pointer
+// load from the workspace per stage.  Host simulation: Team::izz is unused, the tables come from ws->tabs.
+static_assert(offsetof(XformTabs, izz) == 1024 * sizeof(int16_t), "dct32 must directly precede izz");
+#if TK_HOST
+#define TK_DCT32(t, ws) ((ws)->tabs->dct32)
+#else
+#define TK_DCT32(t, ws) (TK_LDS_PTR((t).izz) - 1024)
+#endif
 struct XformWs {
   // `in`: (down-scaled) residual fed to the core transform, TRANSPOSED: in[col*size1 + row].  It is dead
   // after forward stage 1, so the inverse transform's stage-1 buffer (itmp, [coef col i][sample j],
@@ -61,9 +69,11 @@ TK_DEV void xform_tables_fill(XformTabs* tb, int rank, int size) {
 TK_DEV void fwd_core(const Team t, XformWs* ws, int size1, int qsize, int shift_1);
 
 // Forward transform of (org - pred) -> ws->coef (qsize x qsize compact).
-template <typename PIX>
-TK_DEV void fwd_transform(const Team t, XformWs* ws, const PIX* org, int ostride, const PIX* pred, int pstride,
+template <typename PIX, int SP>
+TK_DEV void fwd_transform(const Team t, XformWs* ws, const PIX* org_, int ostride, const PIX* pred_, int pstride,
                           int size, int fast, int bitdepth) {
+  const auto org = spc<SP>(org_);
+  const auto pred = spc<SP>(pred_);
   const int qsize = size < kMaxQuant ? size : kMaxQuant;
   int size1 = size, scale = 1;
   if (size > (32 >> fast)) {
@@ -102,7 +112,7 @@ TK_DEV void fwd_core(const Team t, XformWs* ws, int size1, int qsize, int shift_
   const int shift_2 = ilog2(size1) + 5;
   const int add_2 = 1 << (shift_2 - 1);
   const lds_i16* const in = TK_LDS_PTR(ws->in);
-  const lds_i16* const dct = TK_LDS_PTR(ws->tabs->dct32);
+  const lds_i16* const dct = TK_DCT32(t, ws);
   lds_i16* const tmp = TK_LDS_PTR(ws->tmp);
   lds_i16* const coef = TK_LDS_PTR(ws->coef);
   const Pow2 d1 = mk_pow2(size1), dq = mk_pow2(qsize);
@@ -147,7 +157,9 @@ TK_DEV void fwd_transform_block(const Team t, XformWs* ws, int size, int bitdept
 // {identity, ->0, ->1} (never a swap, because the level under mode 1 is >= the level under mode 0),
 // so the state entering a position is the target of the nearest earlier constant transition; a
 // ballot + count-leading-zeros finds it.  With W = 1 this is literally the reference's serial loop.
-TK_DEV int quantize_team(const Team t, XformWs* ws, int16_t* coefq, int qp, int size, int intra_block) {
+template <int SC>
+TK_DEV int quantize_team(const Team t, XformWs* ws, int16_t* coefq_, int qp, int size, int intra_block) {
+  const auto coefq = spc<SC>(coefq_);
   const int qsize = size < kMaxQuant ? size : kMaxQuant;
   const int N = qsize * qsize;
   const IzzRef izzr = izz_ref(t, qsize);
@@ -197,7 +209,9 @@ TK_DEV int quantize_team(const Team t, XformWs* ws, int16_t* coefq, int qp, int 
 }
 
 // dequantize (common_block.c:45-73): coefq -> ws->rcoef, int16 truncation as in the reference.
-TK_DEV void dequantize(const Team t, XformWs* ws, const int16_t* coefq, int qp, int size) {
+template <int SC>
+TK_DEV void dequantize(const Team t, XformWs* ws, const int16_t* coefq_, int qp, int size) {
+  const auto coefq = spc<SC>(coefq_);
   const int qsize = size < kMaxQuant ? size : kMaxQuant;
   const int lshift = qp / 6, rshift = ilog2(size) - 1;
   const int64_t scale = dequant_scale(qp % 6);
@@ -213,15 +227,17 @@ TK_DEV void dequantize(const Team t, XformWs* ws, const int16_t* coefq, int qp, 
 }
 
 // inverse transform of ws->rcoef + prediction -> rec (saturated), replicating for 64/128.
-template <typename PIX>
-TK_DEV void inv_transform_recon(const Team t, XformWs* ws, const PIX* pred, int pstride, PIX* rec, int rstride,
+template <typename PIX, int SP>
+TK_DEV void inv_transform_recon(const Team t, XformWs* ws, const PIX* pred_, int pstride, PIX* rec_, int rstride,
                                 int size, int bitdepth) {
+  const auto pred = spc<SP>(pred_);
+  const auto rec = spc<SP>(rec_);
   const int n = size < 32 ? size : 32;
   const int scale = size / n;
   const int qsize = n < kMaxQuant ? n : kMaxQuant;
   const int rs = 5 - ilog2((unsigned)n);
   lds_i16* const itmp = TK_LDS_PTR(ws->in);  // aliases `in`
-  const lds_i16* const dct = TK_LDS_PTR(ws->tabs->dct32);
+  const lds_i16* const dct = TK_DCT32(t, ws);
   const lds_i16* const rcoef = TK_LDS_PTR(ws->coef);
   const int shift_2 = 20 - bitdepth, add_2 = 1 << (shift_2 - 1);
   const int mstride = (1 << rs) << 5;  // basis row pitch in the 32-point table
@@ -262,11 +278,13 @@ TK_DEV void inv_transform_recon(const Team t, XformWs* ws, const PIX* pred, int 
   t.sync();
 }
 
-template <typename PIX>
-TK_DEV void copy_block(const Team t, PIX* dst, int dstride, const PIX* src, int sstride, int w, int h) {
+template <int SD, int SS, typename PIX>
+TK_DEV void copy_block(const Team t, PIX* dst_, int dstride, const PIX* src_, int sstride, int w, int h) {
 #ifdef THOR_EXP_UNIFORM
-  dst = tk_uniform_ptr(dst); src = tk_uniform_ptr(src); dstride = tk_uniform(dstride); sstride = tk_uniform(sstride); w = tk_uniform(w); h = tk_uniform(h);
+  dst_ = tk_uniform_ptr(dst_); src_ = tk_uniform_ptr(src_); dstride = tk_uniform(dstride); sstride = tk_uniform(sstride); w = tk_uniform(w); h = tk_uniform(h);
 #endif
+  const auto dst = spc<SD>(dst_);
+  const auto src = spc<SS>(src_);
   if ((w & (w - 1)) == 0) {
     const Pow2 pw = mk_pow2(w);
     for (int k = t.rank; k < w * h; k += t.size) {
@@ -284,8 +302,9 @@ TK_DEV void copy_block(const Team t, PIX* dst, int dstride, const PIX* src, int 
 
 // One transform unit: residual -> T -> Q -> (IQ -> IT -> recon | recon = pred). Returns cbp bit.
 // coeff_type: bit0 chroma, bit1 = (frame_type == I) [sic: frame type, Appendix B.6].
-template <typename PIX>
-TK_DEVNI int code_tu(const Team t, XformWs* ws, const PIX* org, int ostride, const PIX* pred, int pstride, PIX* rec,
+// SP: address space of org / pred / rec (all three belong to the same coding block), SC: of coefq.
+template <typename PIX, int SP, int SC>
+TK_DEVNI int code_tu_sp(const Team t, XformWs* ws, const PIX* org, int ostride, const PIX* pred, int pstride, PIX* rec,
                    int rstride, int size, int qp, int coeff_type, int fast, int16_t* coefq, int bitdepth) {
 #ifdef THOR_EXP_UNIFORM
   org = tk_uniform_ptr(org); pred = tk_uniform_ptr(pred); rec = tk_uniform_ptr(rec); coefq = tk_uniform_ptr(coefq); ws = tk_uniform_ptr(ws);
@@ -293,24 +312,33 @@ TK_DEVNI int code_tu(const Team t, XformWs* ws, const PIX* org, int ostride, con
   qp = tk_uniform(qp); coeff_type = tk_uniform(coeff_type); fast = tk_uniform(fast); bitdepth = tk_uniform(bitdepth);
 #endif
   TK_PROF_T0();
-  fwd_transform(t, ws, org, ostride, pred, pstride, size, fast, bitdepth);
+  fwd_transform<PIX, SP>(t, ws, org, ostride, pred, pstride, size, fast, bitdepth);
   TK_PROF_ADD(ws, 30);
   TK_PROF_MARK(pq0_);
-  int cbp = quantize_team(t, ws, coefq, qp, size, (coeff_type >> 1) & 1);
+  int cbp = quantize_team<SC>(t, ws, coefq, qp, size, (coeff_type >> 1) & 1);
   TK_PROF_ACC(ws, 12, pq0_);
   if (cbp) {
     TK_PROF_MARK(pi0_);
-    dequantize(t, ws, coefq, qp, size);
-    inv_transform_recon(t, ws, pred, pstride, rec, rstride, size, bitdepth);
+    dequantize<SC>(t, ws, coefq, qp, size);
+    inv_transform_recon<PIX, SP>(t, ws, pred, pstride, rec, rstride, size, bitdepth);
     TK_PROF_ACC(ws, 31, pi0_);
   } else {
-    copy_block(t, rec, rstride, pred, pstride, size, size);
+    copy_block<SP, SP>(t, rec, rstride, pred, pstride, size, size);
     t.sync();
   }
   TK_PROF_ADD(ws, (size <= 4 ? 16 : size == 8 ? 17 : size == 16 ? 18 : size == 32 ? 19 : 20));
   TK_PROF_CNT(ws, (size <= 4 ? 21 : size == 8 ? 22 : size == 16 ? 23 : size == 32 ? 24 : 25));
   TK_PROF_ADD(ws, 6);
   return cbp;
+}
+// Entry point for callers that do not know the spaces at compile time (KAT kernels): wave-uniform run-time selection.
+template <typename PIX>
+TK_DEV int code_tu(const Team t, XformWs* ws, const PIX* org, int ostride, const PIX* pred, int pstride, PIX* rec,
+                   int rstride, int size, int qp, int coeff_type, int fast, int16_t* coefq, int bitdepth) {
+  const int lb = tk_uniform(tk_is_lds(pred)), lc = tk_uniform(tk_is_lds(coefq));
+  if (lb) return code_tu_sp<PIX, SP_LDS, SP_LDS>(t, ws, org, ostride, pred, pstride, rec, rstride, size, qp, coeff_type, fast, coefq, bitdepth);
+  if (lc) return code_tu_sp<PIX, SP_GLOBAL, SP_LDS>(t, ws, org, ostride, pred, pstride, rec, rstride, size, qp, coeff_type, fast, coefq, bitdepth);
+  return code_tu_sp<PIX, SP_GLOBAL, SP_GLOBAL>(t, ws, org, ostride, pred, pstride, rec, rstride, size, qp, coeff_type, fast, coefq, bitdepth);
 }
 
 }  // namespace tk
