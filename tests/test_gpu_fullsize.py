@@ -6,6 +6,8 @@ an hour of CPU for these, so they are not run live).  Clips come from the seeded
   * 3840x2160 10-bit through the uint16 path (I P P) + a full 16-frame HDB16 sub-GOP at 416x240 10-bit   - config 5
   * 1920x1080 I+4P: all four references + bi-prediction over them                                         - config 2
   * 64 closed 1080p streams in one lock-step run, every stream against its own per-chunk reference run     - 8e / the bench regime
+  * round 3, the frames the bench times: 3840x2160 I+5P (4 references + bi-prediction), 1080p 14 frames across HQperiod, and
+    the 64-stream set with 6 frames per stream
 """
 import json
 import os
@@ -37,13 +39,25 @@ def _frames(c):
 
 
 @pytest.mark.parametrize('name', [n for n in ('1080p_ldb_n5_q32', '4k_ldb_n2_q32', '4k_hdb16_10bit_n3_q32', 'hdb16_416x240_10bit_n17_q32',
-                                              '4k_ra_n9_q27') if n in BIG])
+                                              '4k_ra_n9_q27', '4k_ldb_n6_q32', '1080p_ldb_n14_q32') if n in BIG])
 def test_full_size_configuration_matches_reference_golden(name):
     c = BIG[name]
     bits, rec = _encode(c, [_frames(c)])
     assert len(bits[0]) == c['bit_bytes']
     assert md5(bits[0]) == c['bit_md5'], 'bitstream differs from the reference'
     assert md5(rec[0]) == c['rec_md5'], 'reconstruction differs from the reference'
+
+
+def test_64_streams_1080p_six_frames_each_equals_its_reference_chunk():
+    """The frames bench.py TIMES with the driver's flags: 64 different 1080p streams, I + 5 P - P 4 and P 5 search all four
+    references and run the lock-step bi-prediction search over them - each stream hashed against its own reference run."""
+    names = ['1080p_stream%02d_n6_q32' % s for s in range(64)]
+    if names[0] not in BIG:
+        pytest.skip('6-frame chunk goldens not generated')
+    c0 = BIG[names[0]]
+    bits, rec = _encode(c0, [_frames(BIG[n]) for n in names])
+    bad = [n for i, n in enumerate(names) if md5(bits[i]) != BIG[n]['bit_md5'] or md5(rec[i]) != BIG[n]['rec_md5']]
+    assert not bad, f'{len(bad)} of 64 streams differ from their reference chunk: {bad[:4]}'
 
 
 def test_64_streams_1080p_each_equals_its_reference_chunk():

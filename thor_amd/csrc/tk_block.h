@@ -177,9 +177,6 @@ template <typename PIX> TK_DEV TeamWs<PIX> make_ws(SmallWs<PIX>* s, WgShared* sh
   TeamWs<PIX> w;
   w.xfp = &s->xf; w.mep = &s->me; w.edgep = &s->edge;
   w.sh = sh; s->xf.tabs = &sh->tabs; s->me.lists = &sh->lists;
-  // the search window lives in the transform workspace (in | tmp | coef: 3584 contiguous bytes), idle during a motion search
-  static_assert(offsetof(XformWs, flag) - offsetof(XformWs, in) >= (size_t)kMeWinBytes + 4, "search window does not fit the transform workspace");
-  s->me.win = sizeof(PIX) == 1 ? (uint32_t*)s->xf.in : nullptr;
   w.coef_y = s->coef_y; w.coef_u = s->coef_u; w.coef_v = s->coef_v;
   w.coef_u_small = s->coef_u; w.coef_v_small = s->coef_v; w.coef_u_big = g->coef_u_big; w.coef_v_big = g->coef_v_big;
   w.acc = s->acc; w.stack = sh->stack; w.prof = s->prof;

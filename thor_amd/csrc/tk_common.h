@@ -20,6 +20,10 @@
 #define THOR_EXP_UNIFORM 1
 #endif
 
+// Wave reductions through DPP + v_readlane instead of ds_bpermute shuffles: +5 % on the MI355X (profiles/r03_call2_findings.md)
+#ifndef TK_DPP
+#define TK_DPP 1
+#endif
 #if defined(THOR_HOSTSIM)
 #include <string.h>
 #include <stdlib.h>
@@ -81,6 +85,8 @@ struct Team {
   inline void block_sync() const {}
 #else
   __device__ __forceinline__ void sync() const {
+    // (a wavefront-scope fence, with or without s_waitcnt lgkmcnt(0), measured the same as this within noise on the MI355X:
+    // profiles/r03_call2_findings.md - the waits on outstanding stores are not what the waves spend their time on)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -172,6 +178,53 @@ TK_DEV void team_or(unsigned* p, unsigned v) {
 #endif
 }
 
+#if !TK_HOST
+// Wave-level reductions without the LDS crossbar: DPP moves inside the 16-lane rows (xor 1, xor 2, then the half-row and
+// row mirrors, which equal xor 4 / xor 8 once the lower levels are uniform), v_readlane across the four rows.  A
+// ds_bpermute (what __shfl_xor compiles to) is an LDS-pipe round trip per step; a DPP operand is part of the VALU op.
+// Full EXEC required (team-cooperative code runs its reductions in uniform control flow).
+template <int CTRL> __device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+enum { DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140 };
+__device__ __forceinline__ int row_sum_dpp(int v) {
+  v += dpp_mov<DPP_XOR1>(v); v += dpp_mov<DPP_XOR2>(v); v += dpp_mov<DPP_HALF_MIRROR>(v); v += dpp_mov<DPP_MIRROR>(v);
+  return v;
+}
+__device__ __forceinline__ int wave_sum_dpp(int v) {
+  v = row_sum_dpp(v);
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned v) {
+  auto mn = [](unsigned a, unsigned b) { return a < b ? a : b; };
+  v = mn(v, (unsigned)dpp_mov<DPP_XOR1>((int)v)); v = mn(v, (unsigned)dpp_mov<DPP_XOR2>((int)v));
+  v = mn(v, (unsigned)dpp_mov<DPP_HALF_MIRROR>((int)v)); v = mn(v, (unsigned)dpp_mov<DPP_MIRROR>((int)v));
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return mn(mn(a, b), mn(c, d));
+}
+__device__ __forceinline__ int wave_max_i32_dpp(int v) {
+  auto mx = [](int a, int b) { return a > b ? a : b; };
+  v = mx(v, dpp_mov<DPP_XOR1>(v)); v = mx(v, dpp_mov<DPP_XOR2>(v)); v = mx(v, dpp_mov<DPP_HALF_MIRROR>(v)); v = mx(v, dpp_mov<DPP_MIRROR>(v));
+  return mx(mx(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), mx(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+template <int CTRL> __device__ __forceinline__ unsigned long long dpp_mov64(unsigned long long v) {
+  const unsigned lo = (unsigned)dpp_mov<CTRL>((int)(unsigned)v), hi = (unsigned)dpp_mov<CTRL>((int)(unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long wave_min64_dpp(unsigned long long v) {
+  auto mn = [](unsigned long long a, unsigned long long b) { return a < b ? a : b; };
+  v = mn(v, dpp_mov64<DPP_XOR1>(v)); v = mn(v, dpp_mov64<DPP_XOR2>(v)); v = mn(v, dpp_mov64<DPP_HALF_MIRROR>(v)); v = mn(v, dpp_mov64<DPP_MIRROR>(v));
+  return mn(mn(readlane64(v, 0), readlane64(v, 16)), mn(readlane64(v, 32), readlane64(v, 48)));
+}
+__device__ __forceinline__ unsigned long long wave_sum64_dpp(unsigned long long v) {
+  v += dpp_mov64<DPP_XOR1>(v); v += dpp_mov64<DPP_XOR2>(v); v += dpp_mov64<DPP_HALF_MIRROR>(v); v += dpp_mov64<DPP_MIRROR>(v);
+  return readlane64(v, 0) + readlane64(v, 16) + readlane64(v, 32) + readlane64(v, 48);
+}
+#endif
+
 // Cross-lane helpers.  A team of 1 lane (host simulation) degenerates to the identity, so code
 // written against them is also the serial algorithm.
 TK_DEV unsigned long long team_ballot(const Team t, int pred) {
@@ -201,8 +254,12 @@ TK_DEV int team_sum(const Team t, int v) {
   return v;
 #else
   (void)t;
+#if TK_DPP
+  return wave_sum_dpp(v);
+#else
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
   return v;
+#endif
 #endif
 }
 TK_DEV int team_max(const Team t, int v) {
@@ -217,8 +274,12 @@ TK_DEV int team_max(const Team t, int v) {
   return v;
 #else
   (void)t;
+#if TK_DPP
+  return wave_max_i32_dpp(v);
+#else
   for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(v, d); v = o > v ? o : v; }
   return v;
+#endif
 #endif
 }
 TK_DEV int team_shfl_xor(const Team t, int v, int d) {
@@ -236,6 +297,22 @@ TK_DEV int team_shfl_xor(const Team t, int v, int d) {
   return __shfl_xor(v, d);
 #endif
 }
+// sum over aligned groups of G lanes (G a power of two <= team size), result in every lane of the group
+TK_DEV int team_group_sum(const Team t, int v, int G) {
+#if !TK_HOST && TK_DPP
+  (void)t;
+  if (G >= 2) v += dpp_mov<DPP_XOR1>(v);
+  if (G >= 4) v += dpp_mov<DPP_XOR2>(v);
+  if (G >= 8) v += dpp_mov<DPP_HALF_MIRROR>(v);
+  if (G >= 16) v += dpp_mov<DPP_MIRROR>(v);
+  if (G >= 32) v += __shfl_xor(v, 16);
+  if (G >= 64) v += __shfl_xor(v, 32);
+  return v;
+#else
+  for (int d = G >> 1; d >= 1; d >>= 1) v += team_shfl_xor(t, v, d);
+  return v;
+#endif
+}
 TK_DEV unsigned long long team_min64(const Team t, unsigned long long v) {
 #if TK_LANES
   const unsigned long long* g = hostlanes::exchange_begin(v);
@@ -248,11 +325,15 @@ TK_DEV unsigned long long team_min64(const Team t, unsigned long long v) {
   return v;
 #else
   (void)t;
+#if TK_DPP
+  return wave_min64_dpp(v);
+#else
   for (int d = 32; d >= 1; d >>= 1) {
     unsigned long long o = __shfl_xor(v, d);
     v = o < v ? o : v;
   }
   return v;
+#endif
 #endif
 }
 // Value known to be identical in every lane of the team: on the device it is moved to a scalar register so that
@@ -332,8 +413,12 @@ TK_DEV unsigned long long team_sum64(const Team t, unsigned long long v) {
   return v;
 #else
   (void)t;
+#if TK_DPP
+  return wave_sum64_dpp(v);
+#else
   for (int d = 32; d >= 1; d >>= 1) v += (unsigned long long)__shfl_xor(v, d);
   return v;
+#endif
 #endif
 }
 // index of the highest set bit of m strictly below `rank`, or -1

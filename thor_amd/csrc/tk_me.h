@@ -27,35 +27,7 @@ struct MeWs {  // per wavefront
   mv_t cmv[64];
   MeLists* lists;
   long long* prof;
-  // LDS search window of the full-pel search (8-bit samples, coding blocks up to 16x16): kMeWinBytes of per-wave LDS
-  // that nothing else uses during a motion search (it aliases the transform workspace, see make_ws); nullptr: off
-  uint32_t* win;
 };
-enum { kMeWinR = 20, kMeWinMaxCb = 16, kMeWinBytes = (kMeWinMaxCb + 2 * kMeWinR) * (kMeWinMaxCb + 2 * kMeWinR) };
-// Off by default: measured 9 % SLOWER than the gather path on the MI355X (profiles/r02_ab_variants.md) although it is
-// bit-exact there (the full -m gpu suite passed with it); -DTK_ME_WINDOW=1 builds it.
-#ifndef TK_ME_WINDOW
-#define TK_ME_WINDOW 0
-#endif
-// The window: Ww x Wh samples of the reference plane around the search centre, row pitch Ww bytes (a multiple of 4),
-// origin (ox, oy) relative to the PU's co-located reference position.
-struct MeWin {
-  const uint32_t* w32;
-  int ox, oy, Ww, Wh;
-  int on;
-};
-// 4 samples at byte offset `off` of the window (any alignment): two aligned dwords + v_alignbyte
-TK_DEV uint32_t win_ld4(const uint32_t* w32, int off) {
-#if TK_HOST
-  const uint32_t lo = w32[off >> 2], hi = w32[(off >> 2) + 1];
-  return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * (off & 3)));
-#else
-  const TK_LDS uint32_t* l = (const TK_LDS uint32_t*)w32;
-  const uint32_t lo = l[off >> 2], hi = l[(off >> 2) + 1];
-  return __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(off & 3));
-#endif
-}
-
 TK_DEV int mv_len1(int a) {
   a = iabs(a);
   if (a < 1) return 2;
@@ -118,7 +90,7 @@ TK_DEV void sad_many_ptr(const Team t, int* sad_, int ncand, const PIX* org, int
       const PIX* b = base(cb);
       for (int r = sub; r < nit; r += G) { int i = r >> lg, g = r & (gpr - 1); lb += sad4<SP>(org + i * ostride + 4 * g, b + i * rstride + 4 * g); }
     }
-    for (int d = G >> 1; d >= 1; d >>= 1) { la += team_shfl_xor(t, la, d); lb += team_shfl_xor(t, lb, d); }
+    la = team_group_sum(t, la, G); lb = team_group_sum(t, lb, G);
     if (sub == 0) {
       if (ca < ncand) sad[ca] = la;
       if (cb < ncand) sad[cb] = lb;
@@ -146,7 +118,7 @@ TK_DEV unsigned long long eval_min(const Team t, int n, int nit, PrepF prep, Ite
     int la = 0, lb = 0;
     if (va) for (int r = sub; r < nit; r += G) la += item(xa, r);
     if (vb) for (int r = sub; r < nit; r += G) lb += item(xb, r);
-    for (int d = G >> 1; d >= 1; d >>= 1) { la += team_shfl_xor(t, la, d); lb += team_shfl_xor(t, lb, d); }
+    la = team_group_sum(t, la, G); lb = team_group_sum(t, lb, G);
     if (sub == 0) {
       if (va) { unsigned long long k = ((unsigned long long)cost(ca, xa, la) << 32) | (unsigned)ca; best = k < best ? k : best; }
       if (vb) { unsigned long long k = ((unsigned long long)cost(cb, xb, lb) << 32) | (unsigned)cb; best = k < best ? k : best; }
@@ -189,110 +161,121 @@ template <> __device__ __forceinline__ int sad4v<uint8_t>(const Px4<uint8_t>& a,
 }
 #endif
 
-// Full-pel candidate evaluation.  Each lane owns up to 16 four-sample groups of a candidate (a whole
-// 8x8 / 4x4 PU), so small PUs need no cross-lane reduction at all and a complete telescope stage or
-// candidate list is one pass; G = items/16 lanes share a candidate for larger PUs (xor-shuffle
-// reduction).  All reference loads of a pass are issued before the first use.
-// cand(c) -> {clipped mv, pointer to the displaced reference block}; returns min (cost<<32 | index).
+// Row segment of a block: up to 16 bytes (16 8-bit / 8 16-bit samples) held in four dwords, unused dwords zero.
+struct Seg16 { uint32_t d[4]; };
+typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
+typedef u32x4 __attribute__((aligned(1), may_alias)) u32x4_unaligned;
+typedef u32x2 __attribute__((aligned(1), may_alias)) u32x2_unaligned;
+// nbytes (4, 8 or 16; wave-uniform) bytes at p.  SP: address space of p; LDS / scratch blocks are aligned to the segment size,
+// frame planes (global) may be read at any byte offset.
+template <int SP> TK_DEV Seg16 seg_load(const void* p, int nbytes) {
+  Seg16 r;
+  r.d[0] = r.d[1] = r.d[2] = r.d[3] = 0;
+#if TK_HOST
+  __builtin_memcpy(&r, p, (size_t)nbytes);
+#else
+  if constexpr (SP == SP_LDS) {
+    const auto q = (const TK_LDS uint8_t*)(uint32_t)(uintptr_t)p;
+    if (nbytes == 16) { const u32x4 v = *(const TK_LDS u32x4*)q; r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w; }
+    else if (nbytes == 8) { const u32x2 v = *(const TK_LDS u32x2*)q; r.d[0] = v.x; r.d[1] = v.y; }
+    else r.d[0] = *(const TK_LDS uint32_t*)q;
+  } else {
+    const auto q = (const TK_GLOBAL uint8_t*)p;
+    if (nbytes == 16) { const u32x4 v = *(const TK_GLOBAL u32x4_unaligned*)q; r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w; }
+    else if (nbytes == 8) { const u32x2 v = *(const TK_GLOBAL u32x2_unaligned*)q; r.d[0] = v.x; r.d[1] = v.y; }
+    else r.d[0] = *(const TK_GLOBAL u32_unaligned*)q;
+  }
+#endif
+  return r;
+}
+// sum of absolute sample differences of two segments (zero-padded dwords contribute nothing)
+template <typename PIX> TK_DEV int seg_sad(const Seg16& a, const Seg16& b, int acc) {
+#if TK_HOST
+  const PIX* x = (const PIX*)a.d;
+  const PIX* y = (const PIX*)b.d;
+  for (int k = 0; k < (int)(16 / sizeof(PIX)); k++) acc += iabs((int)x[k] - (int)y[k]);
+  return acc;
+#else
+  unsigned s = (unsigned)acc;
+  if constexpr (sizeof(PIX) == 1) { for (int k = 0; k < 4; k++) s = __builtin_amdgcn_sad_u8(a.d[k], b.d[k], s); }    // 4 samples per lane-op
+  else { for (int k = 0; k < 4; k++) s = __builtin_amdgcn_sad_u16(a.d[k], b.d[k], s); }                             // 2 samples per lane-op
+  return (int)s;
+#endif
+}
+
+// Full-pel candidate evaluation: min over the n candidates of (cost << 32 | index) - the first candidate in evaluation order
+// among those with the smallest cost, i.e. the winner of the reference's sequential strict-'<' scan.
+// Work item = one row segment of a candidate block (up to 16 bytes: ONE vector-memory instruction per lane instead of one
+// per four samples).  PUs of up to `team size` segments (8-bit: everything up to 32x32): one segment per lane and
+// candidate, G = segments-per-candidate lanes form a group, team/G candidates are evaluated side by side and up to four such
+// candidate sets are in flight per lane; the group sum is a DPP butterfly.  Larger PUs: the whole team works on one
+// candidate, four segments per lane in flight.  cand(c) -> {clipped mv, pointer to the displaced reference block}.
 template <int SP, typename PIX, class CandF, class CostF>
 TK_DEV unsigned long long eval_fullpel(const Team t, int n, const PIX* org, int ostride, int rstride, int width, int height,
-                                       CandF cand, CostF cost, const MeWin& win) {
-  const int gpr = width >> 2, lg = ilog2((unsigned)gpr), nit = height * gpr;
-  int G = nit >> 4;
-  if (G < 1) G = 1;
-  if (G > t.size) G = t.size;
-  const int ipl = nit / G;            // items per lane: 1, 2, 4, 8 or 16 (PUs are at most 64x64 samples)
+                                       CandF cand, CostF cost) {
+  const int kSeg = 16 / (int)sizeof(PIX);
+  const int lw = width < kSeg ? width : kSeg;        // samples per segment
+  const int nb = lw * (int)sizeof(PIX);              // bytes per segment: 4, 8 or 16
+  const int lgr = ilog2((unsigned)(width / lw));     // log2(segments per row)
+  const int nit = height << lgr;                     // segments per candidate
+  const int G = nit < t.size ? nit : t.size;
   const int P = t.size / G;
   const int slot = t.rank / G, sub = t.rank - slot * G;
   unsigned long long best = ~0ull;
-  // A lane's items do not depend on the candidate: when they fit (ipl <= 16, i.e. always with a 64-lane team,
-  // PUs being at most 64x64) its share of the original block is fetched once and kept in registers for all
-  // passes; a smaller team (host simulation) walks its items in chunks of 16 and reloads.
-  const int hoist = ipl <= 16;
-  Px4<PIX> o[16];
-  if (hoist) {
+  if (nit <= t.size) {
+    const int i = sub >> lgr, j = (sub & ((1 << lgr) - 1)) * lw;
+    const Seg16 o = seg_load<SP>(org + i * ostride + j, nb);
+    const int roff = i * rstride + j;
+    for (int c0 = 0; c0 < n; c0 += 4 * P) {
+      Seg16 r[4];
+      decltype(cand(0)) x[4];
 #if !TK_HOST
 #pragma unroll
 #endif
-    for (int k = 0; k < 16; k++)
-      if (k < ipl) {
-        const int r = sub + k * G, i = r >> lg, g = r & (gpr - 1);
-        o[k] = ld4<SP>(org + i * ostride + 4 * g);
-      }
-  }
-  for (int c0 = 0; c0 < n; c0 += 2 * P) {
-    const int ca = c0 + slot, cb = c0 + P + slot;
-    const int va = ca < n, vb = cb < n;
-    auto xa = cand(va ? ca : 0);
-    auto xb = cand(vb ? cb : 0);
-    int sa = 0, sb = 0;
-    // LDS path when EVERY candidate block of this pass lies inside the staged window (wave-uniform decision)
-    int use_win = 0;
-    if (sizeof(PIX) == 1 && win.on) {
-      const int ina = xa.dx >= win.ox && xa.dx + width <= win.ox + win.Ww && xa.dy >= win.oy && xa.dy + height <= win.oy + win.Wh;
-      const int inb = xb.dx >= win.ox && xb.dx + width <= win.ox + win.Ww && xb.dy >= win.oy && xb.dy + height <= win.oy + win.Wh;
-      use_win = team_ballot(t, (va && !ina) || (vb && !inb)) == 0ull;
-#if TK_HOST && defined(THOR_WIN_STAT)
-      { extern long long g_win_stat[2]; g_win_stat[use_win ? 1 : 0]++; }
-#endif
-    }
-    if (use_win) {
-      if constexpr (sizeof(PIX) == 1) {
-        if (va) {
-          const int ba = (xa.dy - win.oy) * win.Ww + (xa.dx - win.ox), bb = (xb.dy - win.oy) * win.Ww + (xb.dx - win.ox);
-          for (int k0 = 0; k0 < ipl; k0 += 16) {
-            const int cnt = ipl - k0 < 16 ? ipl - k0 : 16;
-#if !TK_HOST
-#pragma unroll
-#endif
-            for (int k = 0; k < 16; k++)
-              if (k < cnt) {
-                const int r = sub + (k0 + k) * G, i = r >> lg, g = r & (gpr - 1);
-                if (!hoist) o[k] = ld4<SP>(org + i * ostride + 4 * g);
-                uint32_t ov;
-                __builtin_memcpy(&ov, &o[k], 4);
-                const int off = i * win.Ww + 4 * g;
-#if TK_HOST
-                auto sad32 = [](uint32_t x, uint32_t y) { int s2 = 0; for (int q = 0; q < 4; q++) s2 += iabs((int)((x >> (8 * q)) & 255u) - (int)((y >> (8 * q)) & 255u)); return s2; };
-                sa += sad32(ov, win_ld4(win.w32, ba + off));
-                if (vb) sb += sad32(ov, win_ld4(win.w32, bb + off));
-#else
-                sa = (int)__builtin_amdgcn_sad_u8(ov, win_ld4(win.w32, ba + off), (unsigned)sa);
-                if (vb) sb = (int)__builtin_amdgcn_sad_u8(ov, win_ld4(win.w32, bb + off), (unsigned)sb);
-#endif
-              }
-          }
+      for (int u = 0; u < 4; u++)
+        if (c0 + u * P < n) {  // uniform
+          const int c = c0 + u * P + slot;
+          x[u] = cand(c < n ? c : 0);
+          r[u] = seg_load<SP_GLOBAL>(x[u].p + roff, nb);
         }
-      }
-    } else
-    if (va) {
-      for (int k0 = 0; k0 < ipl; k0 += 16) {
-        const int cnt = ipl - k0 < 16 ? ipl - k0 : 16;
-        Px4<PIX> a[16], b[16];
 #if !TK_HOST
 #pragma unroll
 #endif
-        for (int k = 0; k < 16; k++)
-          if (k < cnt) {
-            const int r = sub + (k0 + k) * G, i = r >> lg, g = r & (gpr - 1);
-            if (!hoist) o[k] = ld4<SP>(org + i * ostride + 4 * g);
-            a[k] = ld4g(xa.p + i * rstride + 4 * g);
-            if (vb) b[k] = ld4g(xb.p + i * rstride + 4 * g);
-          }
-#if !TK_HOST
-#pragma unroll
-#endif
-        for (int k = 0; k < 16; k++)
-          if (k < cnt) {
-            sa += sad4v(o[k], a[k]);
-            if (vb) sb += sad4v(o[k], b[k]);
-          }
-      }
+      for (int u = 0; u < 4; u++)
+        if (c0 + u * P < n) {
+          const int c = c0 + u * P + slot;
+          const int sad = team_group_sum(t, seg_sad<PIX>(o, r[u], 0), G);
+          unsigned long long k = ((unsigned long long)cost(x[u], sad) << 32) | (unsigned)c;
+          if (!(c < n && sub == 0)) k = ~0ull;
+          best = k < best ? k : best;
+        }
     }
-    for (int d = G >> 1; d >= 1; d >>= 1) { sa += team_shfl_xor(t, sa, d); sb += team_shfl_xor(t, sb, d); }
-    if (sub == 0) {
-      if (va) { unsigned long long k = ((unsigned long long)cost(xa, sa) << 32) | (unsigned)ca; best = k < best ? k : best; }
-      if (vb) { unsigned long long k = ((unsigned long long)cost(xb, sb) << 32) | (unsigned)cb; best = k < best ? k : best; }
+  } else {
+    const int ipl = nit / G;  // a multiple of 4 except on teams smaller than a wavefront (host simulation)
+    for (int c = 0; c < n; c++) {
+      const auto x = cand(c);
+      int sad = 0;
+      for (int k0 = 0; k0 < ipl; k0 += 4) {
+        Seg16 o[4], r[4];
+#if !TK_HOST
+#pragma unroll
+#endif
+        for (int k = 0; k < 4; k++)
+          if (k0 + k < ipl) {
+            const int q = sub + (k0 + k) * G, i = q >> lgr, j = (q & ((1 << lgr) - 1)) * lw;
+            o[k] = seg_load<SP>(org + i * ostride + j, nb);
+            r[k] = seg_load<SP_GLOBAL>(x.p + i * rstride + j, nb);
+          }
+#if !TK_HOST
+#pragma unroll
+#endif
+        for (int k = 0; k < 4; k++)
+          if (k0 + k < ipl) sad = seg_sad<PIX>(o[k], r[k], sad);
+      }
+      sad = team_group_sum(t, sad, G);
+      const unsigned long long k = ((unsigned long long)cost(x, sad) << 32) | (unsigned)c;
+      best = k < best ? k : best;
     }
   }
   return TKU64(team_min64(t, best));
@@ -487,35 +470,6 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
     }
     return bestk;
   };
-  // --- stage the search window in LDS: rows of Ww bytes read with coalesced dword loads (clamped into the padded plane;
-  // clamped cells are never part of a candidate block, which clip_mv keeps inside frame +-144)
-  MeWin win;
-  win.on = 0; win.w32 = nullptr; win.ox = win.oy = win.Ww = win.Wh = 0;
-#if TK_ME_WINDOW
-  if constexpr (sizeof(PIX) == 1) {
-    if (w_->win && a.cb_size <= kMeWinMaxCb && a.speed == 0) {
-      win.Ww = a.width + 2 * kMeWinR; win.Wh = a.height + 2 * kMeWinR;
-      win.ox = s * (mv_ref.x >> 2) - kMeWinR; win.oy = s * (mv_ref.y >> 2) - kMeWinR;
-      win.w32 = w_->win;
-      win.on = 1;
-      const int wpr = win.Ww >> 2, total = wpr * win.Wh;
-      t.sync();
-      for (int k = t.rank; k < total; k += t.size) {
-        const int row = k / wpr, c4 = k - row * wpr;
-        const int ay = clampi(a.pu_y + win.oy + row, -kPadY, a.fheight + kPadY - 1) - a.pu_y;
-        const int ax = clampi(a.pu_x + win.ox + 4 * c4, -kPadY, a.fwidth + kPadY - 4) - a.pu_x;
-#if TK_HOST
-        uint32_t v;
-        __builtin_memcpy(&v, ref + ay * a.rstride + ax, 4);
-        w_->win[k] = v;
-#else
-        ((TK_LDS uint32_t*)w_->win)[k] = gload32(ref + ay * a.rstride + ax);
-#endif
-      }
-      t.sync();
-    }
-  }
-#endif
   // --- telescope (encode_block.c:529-561); encoder_speed > 0 keeps it only for 16x16 CBs with bipred on
   if ((a.cb_size == 16 && a.enable_bipred) || a.speed == 0)
   for (int step = 32; step >= 4; step >>= 1) {
@@ -534,7 +488,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
       if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = cmv_get((int)(unsigned)k); }
       t.sync();
     } else {
-      unsigned long long k = eval_fullpel<SP>(t, n, org, a.ostride, a.rstride, a.width, a.height, tele, fp_cost, win);
+      unsigned long long k = eval_fullpel<SP>(t, n, org, a.ostride, a.rstride, a.width, a.height, tele, fp_cost);
       if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = tele((int)(unsigned)k).mv; }
     }
     mv_ref = mv_opt;
@@ -560,7 +514,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
         t.sync();
       } else {
         auto cl = [&](int c) -> FP { return mk_fp(cmv_get(c)); };  // cmv already clipped: clip_mv is idempotent
-        unsigned long long k = eval_fullpel<SP>(t, n, org, a.ostride, a.rstride, a.width, a.height, cl, fp_cost, win);
+        unsigned long long k = eval_fullpel<SP>(t, n, org, a.ostride, a.rstride, a.width, a.height, cl, fp_cost);
         if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = cmv_get((int)(unsigned)k); }
         t.sync();
       }
@@ -586,7 +540,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
         return mk_fp(mk_mv(centre.x + ox * 4, centre.y + oy * 4));
       };
       int which = -1;
-      unsigned long long k = eval_fullpel<SP>(t, n, org, a.ostride, a.rstride, a.width, a.height, hex, fp_cost, win);
+      unsigned long long k = eval_fullpel<SP>(t, n, org, a.ostride, a.rstride, a.width, a.height, hex, fp_cost);
       if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); which = (int)(unsigned)k; mv_opt = hex(which).mv; }
       int best_dir = which < 0 ? -1 : (start + which) % 6;
       mv_ref = mv_opt;
