@@ -98,7 +98,11 @@ template <typename PIX> __global__ __launch_bounds__(kWgThreads, TK_OCC) void k_
   JobR<PIX> J = *ldsc(&sJ);
   const unsigned total = (unsigned)A.S * (unsigned)A.nsb;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+#ifdef THOR_PROF
+  const Wg wg{wave, kWaves, sws[wave].prof};
+#else
   const Wg wg{wave, kWaves};
+#endif
   __shared__ TeamWs<PIX> s_view[kWaves];   // per-wave view of the workspaces: in LDS so that the callees read it with ds_read
   lds_st(&s_view[wave], make_ws(&sws[wave], &sh, (BigWs<PIX>*)(A.pool + ((size_t)blockIdx.x * kWaves + wave) * A.slot_bytes)));
   WsP<PIX> ws = ldsc(&s_view[wave]);

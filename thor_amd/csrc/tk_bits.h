@@ -14,27 +14,40 @@ struct BitSink {
   int cap;        // capacity in bits
   int emit;       // 0: count only
   int ovf;
+  // emission state between bs_open() and bs_close(): the bits of the word being assembled (`fill` = pos & 31 of them, in the
+  // low bits of `acc`).  Complete words are stored without reading the buffer back - the single-lane emission of a block
+  // is a chain of register operations plus fire-and-forget stores instead of a global read-modify-write per syntax element.
+  uint32_t acc = 0;
+  int fill = 0;
 };
+// Start / finish emitting at b.pos (one lane).  Bits of the last word beyond the end position are unspecified (they always
+// were: positions are rewound and re-emitted during the quadtree walk; consumers read pos bits).
+TK_DEV void bs_open(BitSink& b) {
+  b.fill = b.pos & 31;
+  b.acc = (b.emit && b.fill && b.pos < b.cap) ? b.buf[b.pos >> 5] >> (32 - b.fill) : 0u;
+}
+TK_DEV void bs_close(BitSink& b) {
+  if (b.emit && b.fill && !b.ovf) b.buf[b.pos >> 5] = b.acc << (32 - b.fill);
+}
 
 // E = false: counting only (the emission code is not even compiled into the caller: the counting instances are the ones
-// every RDO trial runs, and the instruction cache is shared by all wavefronts of two CUs).
+// every RDO trial runs).  E = true: between bs_open() and bs_close().
 template <bool E> TK_DEV void bs_put_t(BitSink& b, int n, uint32_t val) {
   if (E && b.emit && n > 0) {
     if (b.pos + n > b.cap) {
       b.ovf = 1;
     } else {
-      uint32_t msk = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+      const uint32_t msk = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
       val &= msk;
-      int w = b.pos >> 5, off = b.pos & 31, room = 32 - off;
-      if (n <= room) {
-        int sh = room - n;
-        b.buf[w] = (b.buf[w] & ~(msk << sh)) | (val << sh);
+      const int room = 32 - b.fill;
+      if (n < room) {
+        b.acc = (b.acc << n) | val;
+        b.fill += n;
       } else {
-        int lo = n - room;  // bits that spill into the next word
-        uint32_t mroom = room >= 32 ? 0xffffffffu : ((1u << room) - 1u);
-        b.buf[w] = (b.buf[w] & ~mroom) | (val >> lo);
-        uint32_t mlo = (1u << lo) - 1u;
-        b.buf[w + 1] = (b.buf[w + 1] & ~(mlo << (32 - lo))) | ((val & mlo) << (32 - lo));
+        const int lo = n - room;  // bits that go to the next word
+        b.buf[b.pos >> 5] = (room >= 32 ? 0u : (b.acc << room)) | (val >> lo);
+        b.acc = lo ? (val & ((1u << lo) - 1u)) : 0u;
+        b.fill = lo;
       }
     }
   }

@@ -177,6 +177,9 @@ template <typename PIX> TK_DEV TeamWs<PIX> make_ws(SmallWs<PIX>* s, WgShared* sh
   TeamWs<PIX> w;
   w.xfp = &s->xf; w.mep = &s->me; w.edgep = &s->edge;
   w.sh = sh; s->xf.tabs = &sh->tabs; s->me.lists = &sh->lists;
+  // the search window of a motion search lives in the transform workspace (in | tmp | coef: contiguous), idle during a search
+  static_assert(offsetof(XformWs, flag) - offsetof(XformWs, in) >= (size_t)kMeWinBytes, "search window does not fit the transform workspace");
+  s->me.win = sizeof(PIX) == 1 ? (uint32_t*)s->xf.in : nullptr;
   w.coef_y = s->coef_y; w.coef_u = s->coef_u; w.coef_v = s->coef_v;
   w.coef_u_small = s->coef_u; w.coef_v_small = s->coef_v; w.coef_u_big = g->coef_u_big; w.coef_v_big = g->coef_v_big;
   w.acc = s->acc; w.stack = sh->stack; w.prof = s->prof;
@@ -841,7 +844,7 @@ TK_DEVNI void search_bipred(const Team t, JobR<PIX> J, WsP<PIX> ws, const Node& 
         if (tk_uniform(same)) continue;
       }
       pred_inter_yuv<SP>(t, lds_ld(&J.ref[ref_o]), ws->pred_y, ws->pred_u, ws->pred_v, nd.ypos, nd.xpos, size, nd.bw, nd.bh,
-                     list ? min0 : min1, J.sign[ref_o], c.width, c.height, c.enable_bipred, part > 0, c.bitdepth);
+                     list ? min0 : min1, J.sign[ref_o], c.width, c.height, c.enable_bipred, part > 0, c.bitdepth, 1);
       t.sync();
       {
         const auto o8 = spc<SP>(ws->org8);
@@ -932,7 +935,6 @@ TK_DEVNI unsigned mode_decision(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd
   p.tb_param = 0; p.tb_split = 0; p.cbp_y = p.cbp_u = p.cbp_v = 0;
   for (int i = 0; i < 4; i++) { p.mv0[i] = mk_mv(0, 0); p.mv1[i] = mk_mv(0, 0); }
 
-  TK_PROF_MARK(pm0_);
   if (J.frame_type != F_I) {
     p.tb_param = 0;
     p.pb_part = P_NONE;
@@ -942,10 +944,8 @@ TK_DEVNI unsigned mode_decision(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd
       if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
     }
   }
-  TK_PROF_ACC(ws, 29, pm0_);
   if ((size < 128 || c.encoder_speed == 0) && !rect) {
     if (J.frame_type != F_I) {
-      TK_PROF_MARK(pm1_);
       for (int k = 0; k < nd.syn.num_merge; k++) {
         set_cand(p, nd.merge[k], k, M_MERGE);
         for (int tb = 0; tb <= max_tb - 1; tb++) {
@@ -954,8 +954,6 @@ TK_DEVNI unsigned mode_decision(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd
           if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
         }
       }
-      TK_PROF_ACC(ws, 29, pm1_);
-      TK_PROF_MARK(pu0_);
       // encoder_speed > 0: intra-vs-inter pre-decision by SAD (encode_block.c:1943-1947, 1990-1993)
       const int intra_inter_sad = c.encoder_speed > 0;
       unsigned sad_intra = 0xffffffffu;
@@ -1018,8 +1016,6 @@ TK_DEVNI unsigned mode_decision(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd
         if (t.rank == 0) ws->mep->lists->best_ref = 0;
         t.sync();
       }
-      TK_PROF_ACC(ws, 27, pu0_);
-      TK_PROF_MARK(pb0_);
       // bi-prediction
       if (J.num_ref > 1 && c.enable_bipred && do_inter) {
         int r0, r1;
@@ -1055,9 +1051,7 @@ TK_DEVNI unsigned mode_decision(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd
           if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
         }
       }
-      TK_PROF_ACC(ws, 28, pb0_);
     }
-    TK_PROF_MARK(pi0_);
     // intra (encode_block.c:2070-2114).  The reference re-encodes the winning mode for both
     // tb_param values after the search; those trials are repeats of trials already made (same inputs,
     // deterministic), so their costs are taken from the search instead of being recomputed.
@@ -1095,7 +1089,6 @@ TK_DEVNI unsigned mode_decision(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd
         if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); }
       }
     }
-    TK_PROF_ACC(ws, 26, pi0_);
   }
   return min_cost;
 }
@@ -1278,7 +1271,7 @@ TK_DEVNI void bipred_par(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, Md
         if (t.rank == 0) sh->bp_skip[step] = same;
         if (!same) {
           pred_inter_yuv<SP>(t, lds_ld(&J.ref[ref_o]), ws->pred_y, ws->pred_u, ws->pred_v, nd.ypos, nd.xpos, size, nd.bw, nd.bh, mo, J.sign[ref_o], c.width,
-                         c.height, c.enable_bipred, 0, c.bitdepth);
+                         c.height, c.enable_bipred, 0, c.bitdepth, 1);
           t.sync();
           const auto oy = spc<SP>(ws->org_y);
           const auto py = spc<SP>(ws->pred_y);
@@ -1375,8 +1368,10 @@ TK_DEVNI void md_worker_sp(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws) 
   }
   if (sh->do_bipred == 2) {  // uniform over the workgroup: every wave takes part (same number of barriers)
     t.sync();
+    TK_PROF_MARK(pb_);
     wg.barrier();            // every reference search has finished: mv_center[] and the candidate lists are final
     bipred_par<PIX, SP>(wg, t, J, ws, M);
+    TK_PROF_ACC(ws, 27, pb_);
   }
 }
 // The decision code exists twice: for coding blocks whose sample buffers live in LDS (up to kLdsBlk) and for the larger ones
@@ -1393,7 +1388,9 @@ TK_DEV void md_worker(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws) {
 template <typename PIX>
 TK_DEV void wg_helper_loop(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws) {
   for (;;) {
+    TK_PROF_MARK(ph_);
     wg.barrier();
+    TK_PROF_ACC(ws, 28, ph_);   // parked while the master works alone (quadtree walk, early skip, final encodes)
     const int cmd = team_bcast0(t, ws->sh->cmd);
     if (cmd == WG_CMD_EXIT) { wg.barrier(); break; }  // second barrier: every wave has read the command before the master reuses it
 #ifdef THOR_PROF
@@ -1590,7 +1587,9 @@ TK_DEVNI int final_encode(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd, BitS
   // bits (one lane), then recon copy and cells (all lanes)
   if (t.rank == 0) {
     BitSink w = out;
+    bs_open(w);
     bs_block_t<true>(w, lds_ld(&nd.syn), p, ws->coef_y, ws->coef_u, ws->coef_v, nullptr, nullptr);
+    bs_close(w);
     out.ovf |= w.ovf;
   }
   out.pos += nbits;
@@ -1722,7 +1721,9 @@ TK_DEV void process_sb(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int 
       if (size > kMinBlk && !top_down) {
         if (t.rank == 0) {
           BitSink w = out;
+          bs_open(w);
           bs_super_mode(w, nd.syn, 0, 0, 1);
+          bs_close(w);
           out.ovf |= w.ovf;
           nd.cost_small = 0;
         }
@@ -1788,7 +1789,9 @@ TK_DEV void process_sb(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int 
             out.pos = nd.bitpos0;
             if (t.rank == 0) {
               BitSink w = out;
+              bs_open(w);
               bs_super_mode(w, nd.syn, 0, 0, 1);
+              bs_close(w);
               out.ovf |= w.ovf;
               nd.cost_small = 0;
               nd.md_done = 1;

@@ -118,7 +118,14 @@ namespace hostwaves { void barrier(); }
 #endif
 struct Wg {
   int wave, nwaves;
-#if !TK_HOST
+#if !TK_HOST && defined(THOR_PROF)
+  long long* prof;  // this wave's cycle counters: slot 26 = time spent in workgroup barriers
+  __device__ __forceinline__ void barrier() const {
+    const long long t0 = (long long)__builtin_readcyclecounter();
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) prof[26] += (long long)__builtin_readcyclecounter() - t0;
+  }
+#elif !TK_HOST
   __device__ __forceinline__ void barrier() const { __syncthreads(); }
 #elif defined(THOR_HOSTSIM_WAVES)
   inline void barrier() const { hostwaves::barrier(); }

@@ -27,6 +27,7 @@ struct MeWs {  // per wavefront
   mv_t cmv[64];
   MeLists* lists;
   long long* prof;
+  uint32_t* win;  // kMeWinBytes of per-wave LDS for the search window (8-bit samples), nullptr: none (see MeWin below)
 };
 TK_DEV int mv_len1(int a) {
   a = iabs(a);
@@ -167,69 +168,102 @@ typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
 typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
 typedef u32x4 __attribute__((aligned(1), may_alias)) u32x4_unaligned;
 typedef u32x2 __attribute__((aligned(1), may_alias)) u32x2_unaligned;
-// nbytes (4, 8 or 16; wave-uniform) bytes at p.  SP: address space of p; LDS / scratch blocks are aligned to the segment size,
-// frame planes (global) may be read at any byte offset.
-template <int SP> TK_DEV Seg16 seg_load(const void* p, int nbytes) {
+// NB (4, 8 or 16) bytes at p.  SP: address space of p; LDS / scratch blocks are aligned to the segment size, frame planes
+// (global) may be read at any byte offset.
+template <int SP, int NB> TK_DEV Seg16 seg_load(const void* p) {
   Seg16 r;
   r.d[0] = r.d[1] = r.d[2] = r.d[3] = 0;
 #if TK_HOST
-  __builtin_memcpy(&r, p, (size_t)nbytes);
+  __builtin_memcpy(&r, p, (size_t)NB);
 #else
   if constexpr (SP == SP_LDS) {
     const auto q = (const TK_LDS uint8_t*)(uint32_t)(uintptr_t)p;
-    if (nbytes == 16) { const u32x4 v = *(const TK_LDS u32x4*)q; r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w; }
-    else if (nbytes == 8) { const u32x2 v = *(const TK_LDS u32x2*)q; r.d[0] = v.x; r.d[1] = v.y; }
+    if constexpr (NB == 16) { const u32x4 v = *(const TK_LDS u32x4*)q; r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w; }
+    else if constexpr (NB == 8) { const u32x2 v = *(const TK_LDS u32x2*)q; r.d[0] = v.x; r.d[1] = v.y; }
     else r.d[0] = *(const TK_LDS uint32_t*)q;
   } else {
     const auto q = (const TK_GLOBAL uint8_t*)p;
-    if (nbytes == 16) { const u32x4 v = *(const TK_GLOBAL u32x4_unaligned*)q; r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w; }
-    else if (nbytes == 8) { const u32x2 v = *(const TK_GLOBAL u32x2_unaligned*)q; r.d[0] = v.x; r.d[1] = v.y; }
+    if constexpr (NB == 16) { const u32x4 v = *(const TK_GLOBAL u32x4_unaligned*)q; r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w; }
+    else if constexpr (NB == 8) { const u32x2 v = *(const TK_GLOBAL u32x2_unaligned*)q; r.d[0] = v.x; r.d[1] = v.y; }
     else r.d[0] = *(const TK_GLOBAL u32_unaligned*)q;
   }
 #endif
   return r;
 }
-// sum of absolute sample differences of two segments (zero-padded dwords contribute nothing)
-template <typename PIX> TK_DEV int seg_sad(const Seg16& a, const Seg16& b, int acc) {
+// sum of absolute sample differences of two NB-byte segments, added to acc
+template <typename PIX, int NB> TK_DEV int seg_sad(const Seg16& a, const Seg16& b, int acc) {
 #if TK_HOST
   const PIX* x = (const PIX*)a.d;
   const PIX* y = (const PIX*)b.d;
-  for (int k = 0; k < (int)(16 / sizeof(PIX)); k++) acc += iabs((int)x[k] - (int)y[k]);
+  for (int k = 0; k < (int)(NB / sizeof(PIX)); k++) acc += iabs((int)x[k] - (int)y[k]);
   return acc;
 #else
   unsigned s = (unsigned)acc;
-  if constexpr (sizeof(PIX) == 1) { for (int k = 0; k < 4; k++) s = __builtin_amdgcn_sad_u8(a.d[k], b.d[k], s); }    // 4 samples per lane-op
-  else { for (int k = 0; k < 4; k++) s = __builtin_amdgcn_sad_u16(a.d[k], b.d[k], s); }                             // 2 samples per lane-op
+  if constexpr (sizeof(PIX) == 1) { for (int k = 0; k < NB / 4; k++) s = __builtin_amdgcn_sad_u8(a.d[k], b.d[k], s); }    // 4 samples per lane-op
+  else { for (int k = 0; k < NB / 4; k++) s = __builtin_amdgcn_sad_u16(a.d[k], b.d[k], s); }                             // 2 samples per lane-op
   return (int)s;
 #endif
 }
 
-// Full-pel candidate evaluation: min over the n candidates of (cost << 32 | index) - the first candidate in evaluation order
-// among those with the smallest cost, i.e. the winner of the reference's sequential strict-'<' scan.
-// Work item = one row segment of a candidate block (up to 16 bytes: ONE vector-memory instruction per lane instead of one
-// per four samples).  PUs of up to `team size` segments (8-bit: everything up to 32x32): one segment per lane and
-// candidate, G = segments-per-candidate lanes form a group, team/G candidates are evaluated side by side and up to four such
-// candidate sets are in flight per lane; the group sum is a DPP butterfly.  Larger PUs: the whole team works on one
-// candidate, four segments per lane in flight.  cand(c) -> {clipped mv, pointer to the displaced reference block}.
-template <int SP, typename PIX, class CandF, class CostF>
-TK_DEV unsigned long long eval_fullpel(const Team t, int n, const PIX* org, int ostride, int rstride, int width, int height,
-                                       CandF cand, CostF cost) {
-  const int kSeg = 16 / (int)sizeof(PIX);
-  const int lw = width < kSeg ? width : kSeg;        // samples per segment
-  const int nb = lw * (int)sizeof(PIX);              // bytes per segment: 4, 8 or 16
-  const int lgr = ilog2((unsigned)(width / lw));     // log2(segments per row)
-  const int nit = height << lgr;                     // segments per candidate
-  const int G = nit < t.size ? nit : t.size;
-  const int P = t.size / G;
-  const int slot = t.rank / G, sub = t.rank - slot * G;
-  unsigned long long best = ~0ull;
+// LDS search window of one motion search (8-bit samples, PUs up to 16x16): the (w + 2R) x (h + 2R) samples of the reference
+// plane around the search centre, staged once per search with coalesced 16-byte row loads; the telescope, candidate-list,
+// 5-offset, hexagon and sub-pel passes whose blocks lie inside read it with aligned ds_read + v_alignbyte instead of
+// gathering from the vector L1 (whose tag look-ups - one per lane and row - are what the waves queue for; profiles/r03_*).
+// Row pitch = width + 4 bytes: consecutive rows start in different banks.  Origin (ox, oy) is relative to the PU's
+// co-located position in the reference plane.  The window lives in the wave's transform workspace (idle during a search).
+struct MeWin {
+  const uint32_t* w32;
+  int ox, oy, Ww, Wh, pitch;
+  int on;
+};
+enum { kMeWinR = 20, kMeWinMaxPu = 16, kMeWinBytes = (kMeWinMaxPu + 2 * kMeWinR + 4) * (kMeWinMaxPu + 2 * kMeWinR) + 4 };
+// NB bytes at byte offset `off` of the window (any alignment): NB/4 + 1 aligned dwords, funnel-shifted
+template <int NB> TK_DEV Seg16 win_seg(const uint32_t* w32, int off) {
+  Seg16 r;
+  r.d[0] = r.d[1] = r.d[2] = r.d[3] = 0;
+  const int d = off >> 2;
+  const unsigned sh = (unsigned)(off & 3);
+  uint32_t a[NB / 4 + 1];
+#if TK_HOST
+  for (int k = 0; k <= NB / 4; k++) a[k] = w32[d + k];
+  for (int k = 0; k < NB / 4; k++) r.d[k] = (uint32_t)((((unsigned long long)a[k + 1] << 32) | a[k]) >> (8 * sh));
+#else
+  const TK_LDS uint32_t* l = (const TK_LDS uint32_t*)(uint32_t)(uintptr_t)w32 + d;
+#pragma unroll
+  for (int k = 0; k <= NB / 4; k++) a[k] = l[k];
+#pragma unroll
+  for (int k = 0; k < NB / 4; k++) r.d[k] = __builtin_amdgcn_alignbyte(a[k + 1], a[k], sh);
+#endif
+  return r;
+}
+
+// Core of the full-pel passes: SAD of the org block against n candidate blocks; sink(c, x, sad, mine) is called in every lane
+// for every evaluated candidate slot (mine = this lane reports candidate c: first lane of its group, c < n).
+// Work item = one row segment of a candidate block (up to 16 bytes: ONE memory instruction per lane instead of one per four
+// samples).  PUs of up to `team size` segments (8-bit: everything up to 32x32): one segment per lane and candidate,
+// G = segments-per-candidate lanes form a group, team/G candidates are evaluated side by side and up to four such candidate
+// sets are in flight per lane; the group sum is a DPP butterfly.  Larger PUs: the whole team works on one candidate, four
+// segments per lane in flight.  cand(c) -> {clipped mv, displacement (dx, dy), pointer to the displaced reference block}.
+// An iteration whose candidate blocks all lie inside the staged window reads LDS, otherwise the reference plane.
+template <int SP, typename PIX, int NB, class CandF, class SinkF>
+TK_DEV void seg_sads_nb(const Team t, int n, const PIX* org, int ostride, int rstride, int width, int height, const MeWin& win,
+                        CandF cand, SinkF sink) {
+  const int lw = NB / (int)sizeof(PIX);              // samples per segment
+  const int lgr = TKU(ilog2((unsigned)(width / lw)));   // log2(segments per row)
+  const int nit = height << lgr;                       // segments per candidate
+  const int G = nit < t.size ? nit : t.size;           // powers of two, wave-uniform
+  const int lgG = TKU(ilog2((unsigned)G));
+  const int P = t.size >> lgG;
+  const int slot = t.rank >> lgG, sub = t.rank & (G - 1);
   if (nit <= t.size) {
     const int i = sub >> lgr, j = (sub & ((1 << lgr) - 1)) * lw;
-    const Seg16 o = seg_load<SP>(org + i * ostride + j, nb);
+    const Seg16 o = seg_load<SP, NB>(org + i * ostride + j);
     const int roff = i * rstride + j;
+    const int woff = (i - win.oy) * win.pitch + (j - win.ox);
     for (int c0 = 0; c0 < n; c0 += 4 * P) {
       Seg16 r[4];
       decltype(cand(0)) x[4];
+      int outside = 0;
 #if !TK_HOST
 #pragma unroll
 #endif
@@ -237,22 +271,35 @@ TK_DEV unsigned long long eval_fullpel(const Team t, int n, const PIX* org, int 
         if (c0 + u * P < n) {  // uniform
           const int c = c0 + u * P + slot;
           x[u] = cand(c < n ? c : 0);
-          r[u] = seg_load<SP_GLOBAL>(x[u].p + roff, nb);
+          if (sizeof(PIX) == 1)
+            outside |= c < n && !(x[u].dx >= win.ox && x[u].dx + width <= win.ox + win.Ww && x[u].dy >= win.oy && x[u].dy + height <= win.oy + win.Wh);
         }
+      const int use_win = sizeof(PIX) == 1 && win.on && team_ballot(t, outside) == 0ull;
+      if (use_win) {
+#if !TK_HOST
+#pragma unroll
+#endif
+        for (int u = 0; u < 4; u++)
+          if (c0 + u * P < n) r[u] = win_seg<NB>(win.w32, x[u].dy * win.pitch + x[u].dx + woff);
+      } else {
+#if !TK_HOST
+#pragma unroll
+#endif
+        for (int u = 0; u < 4; u++)
+          if (c0 + u * P < n) r[u] = seg_load<SP_GLOBAL, NB>(x[u].p + roff);
+      }
 #if !TK_HOST
 #pragma unroll
 #endif
       for (int u = 0; u < 4; u++)
         if (c0 + u * P < n) {
           const int c = c0 + u * P + slot;
-          const int sad = team_group_sum(t, seg_sad<PIX>(o, r[u], 0), G);
-          unsigned long long k = ((unsigned long long)cost(x[u], sad) << 32) | (unsigned)c;
-          if (!(c < n && sub == 0)) k = ~0ull;
-          best = k < best ? k : best;
+          const int sad = team_group_sum(t, seg_sad<PIX, NB>(o, r[u], 0), G);
+          sink(c, x[u], sad, c < n && sub == 0);
         }
     }
   } else {
-    const int ipl = nit / G;  // a multiple of 4 except on teams smaller than a wavefront (host simulation)
+    const int ipl = nit >> lgG;  // a multiple of 4 except on teams smaller than a wavefront (host simulation)
     for (int c = 0; c < n; c++) {
       const auto x = cand(c);
       int sad = 0;
@@ -264,20 +311,38 @@ TK_DEV unsigned long long eval_fullpel(const Team t, int n, const PIX* org, int 
         for (int k = 0; k < 4; k++)
           if (k0 + k < ipl) {
             const int q = sub + (k0 + k) * G, i = q >> lgr, j = (q & ((1 << lgr) - 1)) * lw;
-            o[k] = seg_load<SP>(org + i * ostride + j, nb);
-            r[k] = seg_load<SP_GLOBAL>(x.p + i * rstride + j, nb);
+            o[k] = seg_load<SP, NB>(org + i * ostride + j);
+            r[k] = seg_load<SP_GLOBAL, NB>(x.p + i * rstride + j);
           }
 #if !TK_HOST
 #pragma unroll
 #endif
         for (int k = 0; k < 4; k++)
-          if (k0 + k < ipl) sad = seg_sad<PIX>(o[k], r[k], sad);
+          if (k0 + k < ipl) sad = seg_sad<PIX, NB>(o[k], r[k], sad);
       }
       sad = team_group_sum(t, sad, G);
-      const unsigned long long k = ((unsigned long long)cost(x, sad) << 32) | (unsigned)c;
-      best = k < best ? k : best;
+      sink(c, x, sad, sub == 0);
     }
   }
+}
+template <int SP, typename PIX, class CandF, class SinkF>
+TK_DEV void seg_sads(const Team t, int n, const PIX* org, int ostride, int rstride, int width, int height, const MeWin& win, CandF cand, SinkF sink) {
+  const int nb = (width < 16 / (int)sizeof(PIX) ? width : 16 / (int)sizeof(PIX)) * (int)sizeof(PIX);  // bytes per row segment
+  if (nb == 16) seg_sads_nb<SP, PIX, 16>(t, n, org, ostride, rstride, width, height, win, cand, sink);
+  else if (nb == 8) seg_sads_nb<SP, PIX, 8>(t, n, org, ostride, rstride, width, height, win, cand, sink);
+  else seg_sads_nb<SP, PIX, 4>(t, n, org, ostride, rstride, width, height, win, cand, sink);
+}
+// Full-pel candidate evaluation: min over the n candidates of (cost << 32 | index) - the first candidate in evaluation order
+// among those with the smallest cost, i.e. the winner of the reference's sequential strict-'<' scan.
+template <int SP, typename PIX, class CandF, class CostF>
+TK_DEV unsigned long long eval_fullpel(const Team t, int n, const PIX* org, int ostride, int rstride, int width, int height,
+                                       const MeWin& win, CandF cand, CostF cost) {
+  unsigned long long best = ~0ull;
+  seg_sads<SP>(t, n, org, ostride, rstride, width, height, win, cand, [&](int c, const decltype(cand(0))& x, int sad, int mine) {
+    unsigned long long k = ((unsigned long long)cost(x, sad) << 32) | (unsigned)c;
+    if (!mine) k = ~0ull;
+    best = k < best ? k : best;
+  });
   return TKU64(team_min64(t, best));
 }
 
@@ -423,9 +488,17 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
   auto fp_cost = [&](const FP& x, int sad) -> unsigned {
     return ((unsigned)sad >> sh) + mv_cost(a.lam, x.mv.y - mvp.y, x.mv.x - mvp.x);
   };
-  auto mk_fp = [&](mv_t mv) -> FP {
+  // clip_mv leaves every vector within +-R quarter-pels of `ctr` alone when the block displaced by any of them stays inside
+  // the padded area (one wave-uniform test per pass instead of four clamps per candidate; conservative for the
+  // truncating division of clip_mv)
+  auto clip_free = [&](mv_t ctr, int R) -> int {
+    const int ext = kPadY - 16, cy = s * ctr.y, cx = s * ctr.x;
+    return a.ypos + ((cy - R) >> 2) >= -ext && a.ypos + ((cy + R + 3) >> 2) + a.cb_size <= a.fheight + ext &&
+           a.xpos + ((cx - R) >> 2) >= -ext && a.xpos + ((cx + R + 3) >> 2) + a.cb_size <= a.fwidth + ext;
+  };
+  auto mk_fp = [&](mv_t mv, int noclip) -> FP {
     FP x;
-    x.mv = clip_mv(mv, a.ypos, a.xpos, a.fwidth, a.fheight, a.cb_size, a.cb_size, a.sign);
+    x.mv = noclip ? mv : clip_mv(mv, a.ypos, a.xpos, a.fwidth, a.fheight, a.cb_size, a.cb_size, a.sign);
     x.dx = s * (x.mv.x >> 2);
     x.dy = s * (x.mv.y >> 2);
     x.p = ref + x.dy * a.rstride + x.dx;
@@ -435,6 +508,42 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
   long long pq_ = (long long)__builtin_readcyclecounter();
   if (t.rank == 0) w->prof[11] += 1;
 #endif
+  // --- stage the search window in LDS (see MeWin): Wh rows of Ww bytes around the search centre with 16-byte row loads.  Only
+  // when the whole window lies inside the padded reference plane (otherwise every pass of this search reads the plane).
+  MeWin win;
+  win.on = 0; win.w32 = nullptr; win.ox = win.oy = win.Ww = win.Wh = win.pitch = 0;
+  if constexpr (sizeof(PIX) == 1) {
+    if (w->win && a.width <= kMeWinMaxPu && a.height <= kMeWinMaxPu && a.speed == 0) {
+      win.Ww = a.width + 2 * kMeWinR; win.Wh = a.height + 2 * kMeWinR; win.pitch = win.Ww + 4;
+      win.ox = s * (mv_ref.x >> 2) - kMeWinR; win.oy = s * (mv_ref.y >> 2) - kMeWinR;
+      win.w32 = lds_ld(&w_->win);
+      win.on = TKU(a.pu_x + win.ox >= -kPadY && a.pu_x + win.ox + win.Ww <= a.fwidth + kPadY && a.pu_y + win.oy >= -kPadY &&
+                   a.pu_y + win.oy + win.Wh <= a.fheight + kPadY);
+    }
+    if (win.on) {
+      const int spr = (win.Ww + 15) >> 4, total = spr * win.Wh;   // 16-byte segments per row; the last one may read past the row (inside the plane's allocation)
+      t.sync();
+      for (int k0 = 0; k0 < total; k0 += t.size) {
+        const int k = k0 + t.rank;
+        if (k < total) {
+          const int row = k / spr, sg = k - row * spr;
+          const Seg16 v = seg_load<SP_GLOBAL, 16>(ref + (win.oy + row) * a.rstride + win.ox + 16 * sg);
+          const int d = (row * win.pitch + 16 * sg) >> 2;
+          const int nd = tmin(4, (win.Ww - 16 * sg) >> 2);   // dwords of this segment that belong to the row
+#if TK_HOST
+          for (int q = 0; q < nd; q++) ((uint32_t*)win.w32)[d + q] = v.d[q];
+#else
+          TK_LDS uint32_t* l = (TK_LDS uint32_t*)(uint32_t)(uintptr_t)win.w32 + d;
+          l[0] = v.d[0];
+          if (nd > 1) l[1] = v.d[1];
+          if (nd > 2) l[2] = v.d[2];
+          if (nd > 3) l[3] = v.d[3];
+#endif
+        }
+      }
+      t.sync();
+    }
+  }
   // 5-offset "widesad" evaluation of the clipped candidates w->cmv[0..n) (encode_block.c:430-453): per
   // candidate the offset with the smallest SAD (ties -> leftmost), then the usual cost with the adjusted
   // mv (written back to w->cmv).  Returns the best (cost << 32 | index).
@@ -442,13 +551,21 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
     unsigned long long bestk = ~0ull;
     for (int base = 0; base < n; base += kMeWideChunk) {
       const int m = n - base < kMeWideChunk ? n - base : kMeWideChunk;
-      auto widepel = [&](int c5) -> const PIX* {
-        int c = c5 / 5, o = c5 - c * 5;
+      auto widepel = [&](int c5) -> FP {
+        int c = (c5 * 13) >> 6, o = c5 - c * 5;   // c5 / 5 for c5 < 60
         int off = o == 0 ? -3 : o == 1 ? -1 : o == 2 ? 0 : o == 3 ? 1 : 3;
-        mv_t mm = cmv_get(base + c);
-        return ref + (s * (mm.y >> 2)) * a.rstride + s * (mm.x >> 2) + off;
+        FP x;
+        x.mv = cmv_get(base + c);
+        x.dx = s * (x.mv.x >> 2) + off;
+        x.dy = s * (x.mv.y >> 2);
+        x.p = ref + x.dy * a.rstride + x.dx;
+        return x;
       };
-      sad_many_ptr<SP>(t, w_->sad, m * 5, org, a.ostride, a.width, a.height, a.rstride, widepel);
+      {
+        const auto sadl = ldsc(w_->sad);
+        seg_sads<SP>(t, m * 5, org, a.ostride, a.rstride, a.width, a.height, win, widepel, [&](int c5, const FP&, int sad, int mine) { if (mine) sadl[c5] = sad; });
+      }
+      t.sync();
       unsigned long long k = ~0ull;
       for (int lc = t.rank; lc < m; lc += t.size) {
         const int c = base + lc;
@@ -475,10 +592,11 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
   for (int step = 32; step >= 4; step >>= 1) {
     const int n = step < 32 ? 24 : 25;
     const mv_t centre = mv_ref;
+    const int noclip = TKU(clip_free(centre, 2 * step));
     auto tele = [&](int c) -> FP {
       int idx = (step < 32 && c >= 12) ? c + 1 : c;  // centre skipped after the first step
-      int q = idx / 5;
-      return mk_fp(mk_mv(centre.x + (idx - q * 5 - 2) * step, centre.y + (q - 2) * step));
+      int q = (idx * 13) >> 6;                         // idx / 5 for idx < 25
+      return mk_fp(mk_mv(centre.x + (idx - q * 5 - 2) * step, centre.y + (q - 2) * step), noclip);
     };
     if (step == 32 && a.cb_size == 16 && a.speed == 1) {  // first ring by widesad at encoder_speed 1
       t.sync();
@@ -488,7 +606,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
       if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = cmv_get((int)(unsigned)k); }
       t.sync();
     } else {
-      unsigned long long k = eval_fullpel<SP>(t, n, org, a.ostride, a.rstride, a.width, a.height, tele, fp_cost);
+      unsigned long long k = eval_fullpel<SP>(t, n, org, a.ostride, a.rstride, a.width, a.height, win, tele, fp_cost);
       if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = tele((int)(unsigned)k).mv; }
     }
     mv_ref = mv_opt;
@@ -513,8 +631,8 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
         if ((unsigned)(bestk >> 32) < min_sad) { min_sad = (unsigned)(bestk >> 32); mv_opt = cmv_get((int)(unsigned)bestk); }
         t.sync();
       } else {
-        auto cl = [&](int c) -> FP { return mk_fp(cmv_get(c)); };  // cmv already clipped: clip_mv is idempotent
-        unsigned long long k = eval_fullpel<SP>(t, n, org, a.ostride, a.rstride, a.width, a.height, cl, fp_cost);
+        auto cl = [&](int c) -> FP { return mk_fp(cmv_get(c), 1); };  // cmv already clipped (clip_mv is idempotent)
+        unsigned long long k = eval_fullpel<SP>(t, n, org, a.ostride, a.rstride, a.width, a.height, win, cl, fp_cost);
         if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = cmv_get((int)(unsigned)k); }
         t.sync();
       }
@@ -533,14 +651,15 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
     for (int step = 1; step < maxsteps; step++) {
       const int n = (end - start + 6) % 6 + 1;  // 6 in the first round, 3 afterwards
       const mv_t centre = mv_ref;
+      const int noclip = TKU(clip_free(centre, 8));
       auto hex = [&](int c) -> FP {
         int dir = (start + c) % 6;
         int ox = dir == 0 ? 1 : dir == 1 ? 2 : dir == 2 ? 1 : dir == 3 ? -1 : dir == 4 ? -2 : -1;  // "diy" -> x
         int oy = dir == 0 ? -1 : dir == 1 ? 0 : dir == 2 ? 1 : dir == 3 ? 1 : dir == 4 ? 0 : -1;  // "dix" -> y
-        return mk_fp(mk_mv(centre.x + ox * 4, centre.y + oy * 4));
+        return mk_fp(mk_mv(centre.x + ox * 4, centre.y + oy * 4), noclip);
       };
       int which = -1;
-      unsigned long long k = eval_fullpel<SP>(t, n, org, a.ostride, a.rstride, a.width, a.height, hex, fp_cost);
+      unsigned long long k = eval_fullpel<SP>(t, n, org, a.ostride, a.rstride, a.width, a.height, win, hex, fp_cost);
       if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); which = (int)(unsigned)k; mv_opt = hex(which).mv; }
       int best_dir = which < 0 ? -1 : (start + which) % 6;
       mv_ref = mv_opt;
@@ -611,28 +730,39 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
         udy[c] = tk_uniform(cand[c].sp.ver_int - ctr.ver_int + 1);
         udx[c] = tk_uniform(cand[c].sp.hor_int - ctr.hor_int + 1);
       }
+      const int sub_in_win = TKU(sizeof(PIX) == 1 && win.on && ctr.hor_int - 3 >= win.ox && ctr.hor_int + a.width + 5 <= win.ox + win.Ww &&
+                                 ctr.ver_int - 3 >= win.oy && ctr.ver_int + a.height + 5 <= win.oy + win.Wh);
       for (int r = t.rank; r < a.width * a.height; r += t.size) {
         int i, j;
         split2(dw, r, i, j);
         const PIX* p0 = ref + (i + ctr.ver_int - 3) * a.rstride + (j + ctr.hor_int - 3);
-        WinRow<PIX> win[8];
-        for (int q = 0; q < 8; q++) win_load(p0 + q * a.rstride, win[q]);
+        WinRow<PIX> wr[8];
+        if (sub_in_win) {   // the (PU + 8)^2 samples around the centre are inside the staged window
+          if constexpr (sizeof(PIX) == 1) {
+            const int woff = (i + ctr.ver_int - 3 - win.oy) * win.pitch + (j + ctr.hor_int - 3 - win.ox);
+#if !TK_HOST
+#pragma unroll
+#endif
+            for (int q = 0; q < 8; q++) { const Seg16 sg = win_seg<8>(win.w32, woff + q * win.pitch); wr[q].a = ((unsigned long long)sg.d[1] << 32) | sg.d[0]; }
+          }
+        } else
+          for (int q = 0; q < 8; q++) win_load(p0 + q * a.rstride, wr[q]);
         const int o = (int)orgs[i * a.ostride + j];
         if constexpr (sizeof(PIX) == 1) {
-          for (int q = 0; q < 8; q++) win[q] = win_bias(win[q]);
+          for (int q = 0; q < 8; q++) wr[q] = win_bias(wr[q]);
           for (int c = 0; c < 8; c++) {
             WinRow<PIX> rows[6];
             const int dx8 = 8 * udx[c];
-            if (udy[c] == 0) { for (int m = 0; m < 6; m++) rows[m].a = win[m].a >> dx8; }
-            else if (udy[c] == 1) { for (int m = 0; m < 6; m++) rows[m].a = win[m + 1].a >> dx8; }
-            else { for (int m = 0; m < 6; m++) rows[m].a = win[m + 2].a >> dx8; }
+            if (udy[c] == 0) { for (int m = 0; m < 6; m++) rows[m].a = wr[m].a >> dx8; }
+            else if (udy[c] == 1) { for (int m = 0; m < 6; m++) rows[m].a = wr[m + 1].a >> dx8; }
+            else { for (int m = 0; m < 6; m++) rows[m].a = wr[m + 2].a >> dx8; }
             sad8[c] += iabs(o - luma_sample_win8(rows, usp[c], ptap[c], a.enable_bipred));
           }
         } else {
           for (int c = 0; c < 8; c++) {
             const int dy = cand[c].sp.ver_int - ctr.ver_int + 1, dx = cand[c].sp.hor_int - ctr.hor_int + 1;
             WinRow<PIX> rows[6];
-            for (int m = 0; m < 6; m++) rows[m] = win_pick(win[m], win[m + 1], win[m + 2], dy, dx);
+            for (int m = 0; m < 6; m++) rows[m] = win_pick(wr[m], wr[m + 1], wr[m + 2], dy, dx);
             sad8[c] += iabs(o - luma_sample_win<PIX>(rows, cand[c].sp, a.enable_bipred, a.bitdepth));
           }
         }

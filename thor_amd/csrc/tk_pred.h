@@ -275,7 +275,7 @@ TK_DEV void pred_chroma(const Team t, PIX* dst_, int dstride, const PIX* ref, in
 template <int SP, typename PIX>
 TK_DEVNI void pred_inter_yuv(const Team t, const Plane3<PIX> ref, PIX* py, PIX* pu, PIX* pv, int ypos, int xpos,
                            int size, int bw, int bh, const mv_t* mv_arr, int sign, int pic_w, int pic_h,
-                           int enable_bipred, int split, int bitdepth) {
+                           int enable_bipred, int split, int bitdepth, int luma_only = 0) {
   const int div = split + 1;
   const int bwidth = bw / div, bheight = bh / div;
   const int pstride = size;
@@ -292,6 +292,7 @@ TK_DEVNI void pred_inter_yuv(const Team t, const Plane3<PIX> ref, PIX* py, PIX* 
     mv_t mv = clip_mv(mv_arr[index], ypos, xpos, pic_w, pic_h, bwidth, bheight, sign);
     pred_luma<SP>(t, py + offpY, pstride, ry + offrY, ref.sy, bwidth, bheight, mv, sign, enable_bipred, pic_w, pic_h,
               xpos, ypos, bitdepth);
+    if (luma_only) continue;   // the bi-prediction search only needs 2*org - luma prediction
     pred_chroma<SP>(t, pu + offpC, pstride >> 1, ru + offrC, ref.sc, bwidth >> 1, bheight >> 1, mv, sign, pic_w >> 1,
                 pic_h >> 1, xc, yc, bitdepth);
     pred_chroma<SP>(t, pv + offpC, pstride >> 1, rv + offrC, ref.sc, bwidth >> 1, bheight >> 1, mv, sign, pic_w >> 1,

@@ -95,7 +95,7 @@ int main(int argc, char** argv) {
   if (getenv("THOR_PROF")) {
     static const char* nm[32] = {"sb_total", "early_skip", "me_fullpel", "me_subpel", "pred_inter", "md_worker_all_waves", "code_tu", "bits", "cost", "final", "subpel_loop",
                                  "me_calls(n)", "quant", "me_telescope", "me_cands", "me_hex", "tu4", "tu8", "tu16", "tu32", "tu64+",
-                                 "tu4(n)", "tu8(n)", "tu16(n)", "tu32(n)", "tu64+(n)", "md_intra(serial)", "md_uni_inter(serial)", "md_bipred(serial)", "md_fork_to_join(master)", "tu_fwd", "tu_inv"};
+                                 "tu4(n)", "tu8(n)", "tu16(n)", "tu32(n)", "tu64+(n)", "wg_barrier_wait(all waves)", "bipred_lockstep(all waves, incl. barriers)", "helpers_parked(master alone)", "md_fork_to_join(master)", "tu_fwd", "tu_inv"};
     long long pr[32];
     thor_hip_read_prof(e, pr);
     for (int k = 0; k < 32; k++) fprintf(stdout, "prof %-14s %16lld %6.2f%%\n", nm[k], pr[k], pr[0] ? 100.0 * pr[k] / pr[0] : 0.0);
