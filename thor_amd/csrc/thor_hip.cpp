@@ -106,7 +106,7 @@ template <typename PIX> __global__ __launch_bounds__(kWgThreads, TK_OCC) void k_
   __shared__ TeamWs<PIX> s_view[kWaves];   // per-wave view of the workspaces: in LDS so that the callees read it with ds_read
   lds_st(&s_view[wave], make_ws(&sws[wave], &sh, (BigWs<PIX>*)(A.pool + ((size_t)blockIdx.x * kWaves + wave) * A.slot_bytes)));
   WsP<PIX> ws = ldsc(&s_view[wave]);
-  const Team t{lane, 64, sh.tabs.izz};
+  const Team t = mk_team(lane, 64, sh.tabs.izz);
   xform_tables_fill(&sh.tabs, (int)threadIdx.x, kWgThreads);  // constant: once per workgroup
   for (;;) {
     __syncthreads();
@@ -240,7 +240,7 @@ template <typename PIX> __global__ void k_clpf_copy(const ClpfJob<PIX>* lj) {  /
   }
 }
 template <typename PIX> __global__ __launch_bounds__(1024) void k_cdef_select(const CdefJob<PIX>* cj) {
-  Team t{(int)threadIdx.x, (int)blockDim.x};
+  BlockTeam t{(int)threadIdx.x, (int)blockDim.x};
   cdef_pass_select(t, cj[blockIdx.x]);
 }
 
@@ -274,7 +274,7 @@ template <typename PIX> __global__ __launch_bounds__(64) void k_interp_estimate(
   const idev::Job<PIX>& J = jobs[blockIdx.y];
   if (lvl >= J.levels) return;
   const idev::Level<PIX>& L = J.lv[lvl];
-  const Team t{(int)threadIdx.x, 64};
+  const Team t = mk_team((int)threadIdx.x, 64);
   int row = 0;
   if (threadIdx.x == 0) row = (int)atomicAdd((unsigned*)L.ticket, 1u);
   row = __builtin_amdgcn_readfirstlane(row);
@@ -295,7 +295,7 @@ template <typename PIX> __global__ __launch_bounds__(64) void k_interp_merge(con
   const idev::Job<PIX>& J = jobs[blockIdx.y];
   if (lvl >= J.levels) return;
   const idev::Level<PIX>& L = J.lv[lvl];
-  const Team t{(int)threadIdx.x, 64};
+  const Team t = mk_team((int)threadIdx.x, 64);
   for (int k = blockIdx.x; k < L.bw * L.bh; k += gridDim.x) idev::merge_block(t, L, k / L.bw, k % L.bw);
 }
 template <typename PIX> __global__ void k_interp_upscale(const idev::Job<PIX>* jobs, int lvl) {  // level lvl -> guide of lvl-1
@@ -309,7 +309,7 @@ template <typename PIX> __global__ void k_interp_upscale(const idev::Job<PIX>* j
 template <typename PIX> __global__ __launch_bounds__(64) void k_interp_mc(const idev::Job<PIX>* jobs) {
   const idev::Job<PIX>& J = jobs[blockIdx.y];
   const idev::Level<PIX>& L = J.lv[0];
-  const Team t{(int)threadIdx.x, 64};
+  const Team t = mk_team((int)threadIdx.x, 64);
   for (int k = blockIdx.x; k < L.bw * L.bh; k += gridDim.x) idev::mot_comp_unit(t, J, k / L.bw, k % L.bw);
 }
 template <typename PIX> __global__ void k_interp_pad(const idev::Job<PIX>* jobs) {
@@ -993,7 +993,7 @@ namespace tk {
 __global__ __launch_bounds__(64) void k_kat_sad(const uint8_t* org, int w, int h, const uint8_t* refp, int rstride, int bx,
                                                int by, const int* cand, int n, uint32_t* out) {
   __shared__ int sad[kMeMaxCand];
-  Team t{(int)threadIdx.x, 64};
+  const Team t = mk_team((int)threadIdx.x, 64);
   for (int base = 0; base < n; base += kMeMaxCand) {
     const int m = n - base < kMeMaxCand ? n - base : kMeMaxCand;
     auto ptr = [&](int c) -> const uint8_t* {
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(64) void k_kat_sad(const uint8_t* org, int w, int h
 }
 __global__ __launch_bounds__(64) void k_kat_interp(const uint8_t* ref0, int rstride, int pic_w, int pic_h, int bx, int by, int w,
                                                   int h, const int16_t* mv, int bipred, uint8_t* out) {
-  Team t{(int)threadIdx.x, 64};
+  const Team t = mk_team((int)threadIdx.x, 64);
   const int i = blockIdx.x;
   pred_luma<SP_GLOBAL>(t, out + (size_t)i * w * h, w, ref0 + (size_t)by * rstride + bx, rstride, w, h, mk_mv(mv[2 * i], mv[2 * i + 1]), 0,
             bipred, pic_w, pic_h, bx, by, 8);
@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(64) void k_kat_tu(const uint8_t* org, const uint8_t
   __shared__ XformWs xf;
   __shared__ XformTabs tabs;
   __shared__ int16_t cq[256];
-  Team t{(int)threadIdx.x, 64, tabs.izz};
+  const Team t = mk_team((int)threadIdx.x, 64, tabs.izz);
   xf.prof = nullptr;
   xf.tabs = &tabs;
   xform_tables_fill(&tabs, (int)threadIdx.x, 64);

@@ -1480,7 +1480,7 @@ TK_DEV int early_skip_sub(const Team t, JobR<PIX> J, WsP<PIX> ws, const PIX* org
     int b = (int16_t)((int)org[(2 * i) * ostride + 2 * j + 1] - (int)pred[(2 * i) * pstride + 2 * j + 1]);
     int cc = (int16_t)((int)org[(2 * i + 1) * ostride + 2 * j] - (int)pred[(2 * i + 1) * pstride + 2 * j]);
     int d = (int16_t)((int)org[(2 * i + 1) * ostride + 2 * j + 1] - (int)pred[(2 * i + 1) * pstride + 2 * j + 1]);
-    xin[j * s2 + i] = (int16_t)((a + b + cc + d + 2) >> 2);  // transposed (fwd_core layout)
+    xin[i * s2 + j] = (int16_t)((a + b + cc + d + 2) >> 2);  // row-major (fwd_core layout)
   }
   t.sync();
   fwd_transform_block(t, ws->xfp, s2, bd);

@@ -272,7 +272,7 @@ template <typename PIX> TK_DEV void cdef_pass_mse(const CdefJob<PIX>& J, int gid
 // ---- pass 3: joint luma+chroma strength selection (single team) ------------------------------
 // search_one_dual / joint_strength_search_dual (encode_frame.c:86-192) + the sort / dedupe /
 // per-block assignment tail of cdef_search (:380-470).
-template <typename PIX> TK_DEV void cdef_pass_select(const Team t, const CdefJob<PIX>& J) {
+template <typename PIX, class TeamT> TK_DEV void cdef_pass_select(const TeamT t, const CdefJob<PIX>& J) {
   const int nfb = J.nfb_h * J.nfb_v;
   const int total = cdef_total_strengths(J.speed);
   CdefResult* R = J.res;

@@ -67,7 +67,13 @@ int rank();
 // ---------------------------------------------------------------------------------
 struct Team {
   int rank;
+#if TK_HOST
   int size;
+#else
+  // On the device a team is always one 64-lane wavefront: a compile-time constant, so loop strides, lane-group arithmetic and
+  // the branches on them are immediates / scalar code instead of values that arrive in a vector register with every call.
+  static constexpr int size = 64;
+#endif
   // team-local copy of the scan-order tables (scan index -> position): [0,16) 4x4, [16,80) 8x8, [80,336) 16x16.
   // On the device it points into LDS (XformWs::izz) so the per-coefficient lookups of quantisation and bit
   // counting do not take a global-memory round trip each; unused (nullptr) on the host simulation.
@@ -94,6 +100,27 @@ struct Team {
   __device__ __forceinline__ void block_sync() const { __syncthreads(); }
 #endif
 };
+
+// mk_team(rank, size, izz): `size` must be 64 on the device.
+TK_DEV Team mk_team(int rank, int size, const int16_t* izz = nullptr) {
+  Team t;
+  t.rank = rank;
+#if TK_HOST
+  t.size = size;
+#else
+  (void)size;
+#endif
+  t.izz = izz;
+  return t;
+}
+#if !TK_HOST
+// A whole thread block as one team (CDEF strength selection): block-strided loops separated by block barriers.
+struct BlockTeam {
+  int rank;
+  int size;
+  __device__ __forceinline__ void block_sync() const { __syncthreads(); }
+};
+#endif
 
 // ---------------------------------------------------------------------------------
 // Wg: the wavefronts of one workgroup that cooperate on one superblock.  Wave 0 (the "master") walks the quadtree;

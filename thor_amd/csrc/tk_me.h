@@ -245,59 +245,66 @@ template <int NB> TK_DEV Seg16 win_seg(const uint32_t* w32, int off) {
 // sets are in flight per lane; the group sum is a DPP butterfly.  Larger PUs: the whole team works on one candidate, four
 // segments per lane in flight.  cand(c) -> {clipped mv, displacement (dx, dy), pointer to the displaced reference block}.
 // An iteration whose candidate blocks all lie inside the staged window reads LDS, otherwise the reference plane.
+// One iteration of the small-PU path: U candidate sets (U * P candidates) starting at candidate c0.  Straight-line code: the
+// U reference segments are fetched back to back (window or plane, decided once for all of them) before the first SAD; slots
+// beyond n evaluate candidate 0 and are masked out in the sink.
+template <int SP, typename PIX, int NB, int U, class CandF, class SinkF>
+TK_DEV void seg_sads_iter(const Team t, int n, int c0, int P, int G, int slot, int sub, const Seg16& o, int roff, int woff, int width, int height,
+                          const MeWin& win, CandF cand, SinkF sink) {
+  Seg16 r[U];
+  decltype(cand(0)) x[U];
+  int outside = 0;
+#if !TK_HOST
+#pragma unroll
+#endif
+  for (int u = 0; u < U; u++) {
+    const int c = c0 + u * P + slot;
+    x[u] = cand(c < n ? c : 0);
+    if (sizeof(PIX) == 1)
+      outside |= !(x[u].dx >= win.ox && x[u].dx + width <= win.ox + win.Ww && x[u].dy >= win.oy && x[u].dy + height <= win.oy + win.Wh);
+  }
+  const int use_win = sizeof(PIX) == 1 && win.on && team_ballot(t, outside) == 0ull;
+  if (use_win) {
+#if !TK_HOST
+#pragma unroll
+#endif
+    for (int u = 0; u < U; u++) r[u] = win_seg<NB>(win.w32, x[u].dy * win.pitch + x[u].dx + woff);
+  } else {
+#if !TK_HOST
+#pragma unroll
+#endif
+    for (int u = 0; u < U; u++) r[u] = seg_load<SP_GLOBAL, NB>(x[u].p + roff);
+  }
+#if !TK_HOST
+#pragma unroll
+#endif
+  for (int u = 0; u < U; u++) {
+    const int c = c0 + u * P + slot;
+    const int sad = team_group_sum(t, seg_sad<PIX, NB>(o, r[u], 0), G);
+    sink(c, x[u], sad, c < n && sub == 0);
+  }
+}
 template <int SP, typename PIX, int NB, class CandF, class SinkF>
-TK_DEV void seg_sads_nb(const Team t, int n, const PIX* org, int ostride, int rstride, int width, int height, const MeWin& win,
+TK_DEV void seg_sads_nb(const Team t, int n_, const PIX* org, int ostride, int rstride, int width, int height, const MeWin& win,
                         CandF cand, SinkF sink) {
+  // wave-uniform scalars (function arguments arrive in vector registers: without this every branch below is exec-mask code)
+  const int n = TKU(n_), tsz = TKU(t.size);
   const int lw = NB / (int)sizeof(PIX);              // samples per segment
   const int lgr = TKU(ilog2((unsigned)(width / lw)));   // log2(segments per row)
   const int nit = height << lgr;                       // segments per candidate
-  const int G = nit < t.size ? nit : t.size;           // powers of two, wave-uniform
+  const int G = nit < tsz ? nit : tsz;                 // powers of two
   const int lgG = TKU(ilog2((unsigned)G));
-  const int P = t.size >> lgG;
+  const int P = tsz >> lgG;
   const int slot = t.rank >> lgG, sub = t.rank & (G - 1);
-  if (nit <= t.size) {
+  if (nit <= tsz) {
     const int i = sub >> lgr, j = (sub & ((1 << lgr) - 1)) * lw;
     const Seg16 o = seg_load<SP, NB>(org + i * ostride + j);
     const int roff = i * rstride + j;
     const int woff = (i - win.oy) * win.pitch + (j - win.ox);
-    for (int c0 = 0; c0 < n; c0 += 4 * P) {
-      Seg16 r[4];
-      decltype(cand(0)) x[4];
-      int outside = 0;
-#if !TK_HOST
-#pragma unroll
-#endif
-      for (int u = 0; u < 4; u++)
-        if (c0 + u * P < n) {  // uniform
-          const int c = c0 + u * P + slot;
-          x[u] = cand(c < n ? c : 0);
-          if (sizeof(PIX) == 1)
-            outside |= c < n && !(x[u].dx >= win.ox && x[u].dx + width <= win.ox + win.Ww && x[u].dy >= win.oy && x[u].dy + height <= win.oy + win.Wh);
-        }
-      const int use_win = sizeof(PIX) == 1 && win.on && team_ballot(t, outside) == 0ull;
-      if (use_win) {
-#if !TK_HOST
-#pragma unroll
-#endif
-        for (int u = 0; u < 4; u++)
-          if (c0 + u * P < n) r[u] = win_seg<NB>(win.w32, x[u].dy * win.pitch + x[u].dx + woff);
-      } else {
-#if !TK_HOST
-#pragma unroll
-#endif
-        for (int u = 0; u < 4; u++)
-          if (c0 + u * P < n) r[u] = seg_load<SP_GLOBAL, NB>(x[u].p + roff);
-      }
-#if !TK_HOST
-#pragma unroll
-#endif
-      for (int u = 0; u < 4; u++)
-        if (c0 + u * P < n) {
-          const int c = c0 + u * P + slot;
-          const int sad = team_group_sum(t, seg_sad<PIX, NB>(o, r[u], 0), G);
-          sink(c, x[u], sad, c < n && sub == 0);
-        }
-    }
+    if (n <= P) seg_sads_iter<SP, PIX, NB, 1>(t, n, 0, P, G, slot, sub, o, roff, woff, width, height, win, cand, sink);
+    else if (n <= 2 * P) seg_sads_iter<SP, PIX, NB, 2>(t, n, 0, P, G, slot, sub, o, roff, woff, width, height, win, cand, sink);
+    else
+      for (int c0 = 0; c0 < n; c0 += 4 * P) seg_sads_iter<SP, PIX, NB, 4>(t, n, c0, P, G, slot, sub, o, roff, woff, width, height, win, cand, sink);
   } else {
     const int ipl = nit >> lgG;  // a multiple of 4 except on teams smaller than a wavefront (host simulation)
     for (int c = 0; c < n; c++) {
@@ -718,17 +725,13 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
     TK_PROF_MARK(ps1_);
     if (in_window) {
       int sad8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      // per-candidate parameters are identical in every lane: keep them in scalar registers
-      PackedTaps ptap[8];
-      SubPel usp[8];
-      int udy[8], udx[8];
+      // per-candidate parameters are identical in every lane: scalar registers
+      SubK8 k8[8];
       for (int c = 0; c < 8; c++) {
-        usp[c] = cand[c].sp;
-        usp[c].ver_frac = tk_uniform(usp[c].ver_frac); usp[c].hor_frac = tk_uniform(usp[c].hor_frac);
-        for (int m = 0; m < 6; m++) { usp[c].tv[m] = tk_uniform(usp[c].tv[m]); usp[c].th[m] = tk_uniform(usp[c].th[m]); }
-        ptap[c] = pack_taps(usp[c]);
-        udy[c] = tk_uniform(cand[c].sp.ver_int - ctr.ver_int + 1);
-        udx[c] = tk_uniform(cand[c].sp.hor_int - ctr.hor_int + 1);
+        SubPel usp = cand[c].sp;
+        for (int m = 0; m < 6; m++) { usp.tv[m] = tk_uniform(usp.tv[m]); usp.th[m] = tk_uniform(usp.th[m]); }
+        usp.ver_frac = tk_uniform(usp.ver_frac); usp.hor_frac = tk_uniform(usp.hor_frac);
+        k8[c] = subk8_make(usp, tk_uniform(cand[c].sp.ver_int - ctr.ver_int + 1), tk_uniform(cand[c].sp.hor_int - ctr.hor_int + 1), a.enable_bipred);
       }
       const int sub_in_win = TKU(sizeof(PIX) == 1 && win.on && ctr.hor_int - 3 >= win.ox && ctr.hor_int + a.width + 5 <= win.ox + win.Ww &&
                                  ctr.ver_int - 3 >= win.oy && ctr.ver_int + a.height + 5 <= win.oy + win.Wh);
@@ -749,14 +752,14 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
           for (int q = 0; q < 8; q++) win_load(p0 + q * a.rstride, wr[q]);
         const int o = (int)orgs[i * a.ostride + j];
         if constexpr (sizeof(PIX) == 1) {
-          for (int q = 0; q < 8; q++) wr[q] = win_bias(wr[q]);
+          unsigned long long wb[8];
+          for (int q = 0; q < 8; q++) wb[q] = wr[q].a ^ 0x8080808080808080ull;   // samples - 128 as int8 lanes
+#if !TK_HOST
+#pragma unroll
+#endif
           for (int c = 0; c < 8; c++) {
-            WinRow<PIX> rows[6];
-            const int dx8 = 8 * udx[c];
-            if (udy[c] == 0) { for (int m = 0; m < 6; m++) rows[m].a = wr[m].a >> dx8; }
-            else if (udy[c] == 1) { for (int m = 0; m < 6; m++) rows[m].a = wr[m + 1].a >> dx8; }
-            else { for (int m = 0; m < 6; m++) rows[m].a = wr[m + 2].a >> dx8; }
-            sad8[c] += iabs(o - luma_sample_win8(rows, usp[c], ptap[c], a.enable_bipred));
+            const unsigned pr = (unsigned)subk8_sample(wb, k8[c]), uo = (unsigned)o;
+            sad8[c] += (int)((uo > pr ? uo : pr) - (uo < pr ? uo : pr));
           }
         } else {
           for (int c = 0; c < 8; c++) {

@@ -224,6 +224,60 @@ TK_DEV int luma_sample_win8(const WinRow<uint8_t> w[6], const SubPel& s, const P
   return sat_pix((sum + 2048) >> 12, 8);
 }
 
+// Sub-pel search, 8-bit: one prediction sample straight from the eight biased window rows (row q = reference row
+// centre.ver_int - 3 + q, byte n = column centre.hor_int - 3 + n) for a candidate at integer offset (dy, dx) in 0..2 from
+// centre - 1.  The horizontal taps sit in an 8-byte vector at byte offset dx, so a row sum is two v_dot4 on the row as it was
+// loaded (no 64-bit shifts); every fractional position except the (1/2, 1/2) centre filter is the general separable form
+// (a zero fraction has taps {0,0,64,0,0,0}, which reproduces the reference's 1-D formulas and the full-pel copy exactly).
+struct SubK8 {
+  unsigned long long th8;  // horizontal taps (int8 lanes) at bytes dx .. dx+5
+  int tv[6];
+  int centre, dy, dx;
+};
+TK_DEV SubK8 subk8_make(const SubPel& s, int dy, int dx, int bipred) {
+  SubK8 k;
+  unsigned long long th = 0;
+  for (int n = 0; n < 6; n++) th |= (unsigned long long)(unsigned)(s.th[n] & 0xff) << (8 * n);
+  k.th8 = th << (8 * dx);
+  for (int m = 0; m < 6; m++) k.tv[m] = s.tv[m];
+  k.centre = s.ver_frac == 2 && s.hor_frac == 2 && bipred < 2;
+  k.dy = dy; k.dx = dx;
+  return k;
+}
+TK_DEV int mul24(int a, int b) {
+#if TK_HOST
+  return a * b;
+#else
+  return __mul24(a, b);
+#endif
+}
+template <int DY> TK_DEV int subk8_sample_dy(const unsigned long long* wr, const SubK8& k) {
+  if (k.centre) {  // 12-tap centre filter (inter_prediction.c:146-160) as four rows of byte weights
+    const unsigned long long wA = 0x0000000001010000ull << (8 * k.dx), wB = 0x0000000102020100ull << (8 * k.dx);
+    int sum = 128 * 16;
+    sum = dot4_i8((int)(unsigned)wA, (int)(unsigned)wr[DY + 1], dot4_i8((int)(unsigned)(wA >> 32), (int)(unsigned)(wr[DY + 1] >> 32), sum));
+    sum = dot4_i8((int)(unsigned)wB, (int)(unsigned)wr[DY + 2], dot4_i8((int)(unsigned)(wB >> 32), (int)(unsigned)(wr[DY + 2] >> 32), sum));
+    sum = dot4_i8((int)(unsigned)wB, (int)(unsigned)wr[DY + 3], dot4_i8((int)(unsigned)(wB >> 32), (int)(unsigned)(wr[DY + 3] >> 32), sum));
+    sum = dot4_i8((int)(unsigned)wA, (int)(unsigned)wr[DY + 4], dot4_i8((int)(unsigned)(wA >> 32), (int)(unsigned)(wr[DY + 4] >> 32), sum));
+    return sat_pix((sum + 8) >> 4, 8);
+  }
+  int sum = 0;
+#if !TK_HOST
+#pragma unroll
+#endif
+  for (int m = 0; m < 6; m++) {
+    const unsigned long long row = wr[DY + m];
+    const int h = dot4_i8((int)(unsigned)k.th8, (int)(unsigned)row, dot4_i8((int)(unsigned)(k.th8 >> 32), (int)(unsigned)(row >> 32), 128 * 64));
+    sum += mul24(k.tv[m], h);
+  }
+  return sat_pix((sum + 2048) >> 12, 8);
+}
+TK_DEV int subk8_sample(const unsigned long long* wr, const SubK8& k) {
+  if (k.dy == 0) return subk8_sample_dy<0>(wr, k);
+  if (k.dy == 1) return subk8_sample_dy<1>(wr, k);
+  return subk8_sample_dy<2>(wr, k);
+}
+
 // get_inter_prediction_luma for a whole PU (team-parallel over samples).
 template <int SP, typename PIX>
 TK_DEV void pred_luma(const Team t, PIX* dst_, int dstride, const PIX* ref, int rstride, int width, int height, mv_t mv,

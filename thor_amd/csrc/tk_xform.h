@@ -34,24 +34,31 @@ namespace tk {
 // N-point basis is its rows 0, 32/N, 2*32/N, ... restricted to the first N columns - HEVC nesting property) and the
 // scan tables 4x4 | 8x8 | 16x16 (Team::izz points at `izz`).
 struct XformTabs {
-  int16_t dct32[1024];
+  alignas(16) int16_t dct32[1024];
   int16_t izz[336];
+  // transposed N-point bases for the inverse transform, MT_N[j][k] = M_N[k][j]: 32 | 16 | 8 | 4 -point at offsets 0, 1024, 1280, 1344
+  alignas(16) int16_t dctT[1360];
 };
 // The transform stages take the basis from Team::izz (which points at XformTabs::izz of the workgroup's tables): no pointer
 // load from the workspace per stage.  Host simulation: Team::izz is unused, the tables come from ws->tabs.
 static_assert(offsetof(XformTabs, izz) == 1024 * sizeof(int16_t), "dct32 must directly precede izz");
+static_assert(offsetof(XformTabs, dctT) == (1024 + 336) * sizeof(int16_t), "dctT must directly follow izz");
 #if TK_HOST
 #define TK_DCT32(t, ws) ((ws)->tabs->dct32)
+#define TK_DCTT(t, ws) ((ws)->tabs->dctT)
 #else
 #define TK_DCT32(t, ws) (TK_LDS_PTR((t).izz) - 1024)
+#define TK_DCTT(t, ws) (TK_LDS_PTR((t).izz) + 336)
 #endif
+TK_DEV int dctT_off(int n) { return n == 32 ? 0 : n == 16 ? 1024 : n == 8 ? 1280 : 1344; }
 struct XformWs {
-  // `in`: (down-scaled) residual fed to the core transform, TRANSPOSED: in[col*size1 + row].  It is dead
-  // after forward stage 1, so the inverse transform's stage-1 buffer (itmp, [coef col i][sample j],
-  // 16*32 entries) lives in the same storage.
-  int16_t in[32 * 32];
-  int16_t tmp[16 * 32];   // stage-1 output, [row j][coef i] (stride qsize)
-  int16_t coef[16 * 16];  // forward coefficients, compact; reused for the de-quantised ones (rcoef)
+  // `in`: (down-scaled) residual fed to the core transform, row-major in[row*size1 + col].  It is dead after forward
+  // stage 1, so the inverse transform's stage-1 buffer (itmp, TRANSPOSED [sample j][coef col i], 32*16 entries) lives in
+  // the same storage.  Every stage is a set of dot products of two CONTIGUOUS int16 vectors (a basis row and a data row),
+  // read with 16-byte ds_read and multiplied two terms at a time (v_dot2_i32_i16).
+  alignas(16) int16_t in[32 * 32];
+  alignas(16) int16_t tmp[16 * 32];   // forward stage-1 output, TRANSPOSED: tmp[coef i][row j] (stride size1)
+  alignas(16) int16_t coef[16 * 16];  // forward coefficients, compact; reused for the de-quantised ones (rcoef, TRANSPOSED)
   int flag;               // team-shared scalar result
   long long* prof;        // cycle counters (THOR_PROF builds)
   const XformTabs* tabs;  // workgroup-shared constant tables
@@ -64,6 +71,43 @@ TK_DEV int dct_at(const XformWs* ws, int rs, int i, int q) { return ws->tabs->dc
 TK_DEV void xform_tables_fill(XformTabs* tb, int rank, int size) {
   for (int k = rank; k < 1024; k += size) tb->dct32[k] = TK_TAB.dct32[k];
   for (int k = rank; k < 336; k += size) tb->izz[k] = k < 16 ? TK_TAB.izz4[k] : (k < 80 ? TK_TAB.izz8[k - 16] : TK_TAB.izz16[k - 80]);
+  for (int k = rank; k < 1360; k += size) {
+    const int n = k < 1024 ? 32 : k < 1280 ? 16 : k < 1344 ? 8 : 4, rs = 5 - ilog2((unsigned)n);
+    const int e = k - dctT_off(n), j = e / n, q = e - j * n;
+    tb->dctT[k] = TK_TAB.dct32[((q << rs) << 5) + j];   // M_n[q][j]
+  }
+}
+
+// sum_{q<n} a[q] * b[q] of two contiguous int16 vectors in the team's transform workspace / tables (n = 4, 8, 16 or 32; both
+// 2n-byte aligned up to 16).  rot: chunk the lane starts with (spreads the lanes of a wave over the LDS banks).
+typedef short __attribute__((ext_vector_type(2))) tk_s16x2;
+TK_DEV int dot_i16(const lds_i16* a, const lds_i16* b, int n, int rot) {
+#if TK_HOST
+  (void)rot;
+  int s = 0;
+  for (int q = 0; q < n; q++) s += (int)a[q] * (int)b[q];
+  return s;
+#else
+  typedef uint32_t __attribute__((ext_vector_type(4))) v4;
+  typedef uint32_t __attribute__((ext_vector_type(2))) v2;
+  auto d2 = [](uint32_t x, uint32_t y, int c) -> int {
+    tk_s16x2 xv, yv;
+    __builtin_memcpy(&xv, &x, 4); __builtin_memcpy(&yv, &y, 4);
+    return __builtin_amdgcn_sdot2(xv, yv, c, false);
+  };
+  if (n == 4) {
+    const v2 x = *(const TK_LDS v2*)a, y = *(const TK_LDS v2*)b;
+    return d2(x.y, y.y, d2(x.x, y.x, 0));
+  }
+  const int nch = n >> 3;
+  int s = 0;
+  for (int c = 0; c < nch; c++) {
+    const int cc = ((c + rot) & (nch - 1)) << 3;
+    const v4 x = *(const TK_LDS v4*)(a + cc), y = *(const TK_LDS v4*)(b + cc);
+    s = d2(x.w, y.w, d2(x.z, y.z, d2(x.y, y.y, d2(x.x, y.x, s))));
+  }
+  return s;
+#endif
 }
 
 TK_DEV void fwd_core(const Team t, XformWs* ws, int size1, int qsize, int shift_1);
@@ -96,16 +140,15 @@ TK_DEV void fwd_transform(const Team t, XformWs* ws, const PIX* org_, int ostrid
           sum = clampi((int16_t)sum + r, -16384, 16383);
         }
     }
-    in_l[j * size1 + i] = (int16_t)sum;  // transposed store: conflict-free column reads in stage 1
+    in_l[i * size1 + j] = (int16_t)sum;
   }
   t.sync();
   fwd_core(t, ws, size1, qsize, ilog2(size) + ilog2(scale) + bitdepth - 8);
 }
 
-// Core 2-D transform of the (transposed) size1 x size1 block in ws->in -> ws->coef (qsize x qsize).
-// Stage 1 (rows):   tmp[j][i] = (sum_q M[i][q] * in[j][q] + add1) >> shift1   -> stored [row j][coef i]
-// Stage 2 (cols):   coef[i][j] = (sum_q M[i][q] * tmp[q][j] + add2) >> shift2
-// Lane mappings are chosen so that every LDS access is either consecutive across lanes or a broadcast.
+// Core 2-D transform of the size1 x size1 block in ws->in (row-major) -> ws->coef (qsize x qsize).
+// Stage 1 (rows):   T[j][i] = (sum_q M[i][q] * in[j][q] + add1) >> shift1   -> stored transposed tmp[i][j] (stride size1)
+// Stage 2 (cols):   coef[i][j] = (sum_q M[i][q] * T[q][j] + add2) >> shift2 = dot(M row i, tmp row j)
 TK_DEV void fwd_core(const Team t, XformWs* ws, int size1, int qsize, int shift_1) {
   const int rs = 5 - ilog2((unsigned)size1);
   const int add_1 = 1 << (shift_1 - 1);
@@ -118,35 +161,21 @@ TK_DEV void fwd_core(const Team t, XformWs* ws, int size1, int qsize, int shift_
   const Pow2 d1 = mk_pow2(size1), dq = mk_pow2(qsize);
   for (int k = t.rank; k < qsize * size1; k += t.size) {
     int i, j;
-    split2(d1, k, i, j);  // row j fastest: M[i][q] is a broadcast, in[q][j] consecutive
-    const lds_i16* M = dct + ((i << rs) << 5);
-    const lds_i16* col = in + j;
-    int sum = 0;
-    for (int q = 0; q < size1; q += 4) {  // size1 is 4, 8, 16 or 32; all eight loads issue before the first use
-      const int m0 = M[q], m1 = M[q + 1], m2 = M[q + 2], m3 = M[q + 3];
-      const int a0 = col[q * size1], a1 = col[(q + 1) * size1], a2 = col[(q + 2) * size1], a3 = col[(q + 3) * size1];
-      sum += m0 * a0 + m1 * a1 + m2 * a2 + m3 * a3;
-    }
-    tmp[j * qsize + i] = (int16_t)((sum + add_1) >> shift_1);
+    split2(d1, k, i, j);  // row j fastest
+    const int sum = dot_i16(dct + ((i << rs) << 5), in + j * size1, size1, j);
+    tmp[i * size1 + j] = (int16_t)((sum + add_1) >> shift_1);
   }
   t.sync();
   for (int k = t.rank; k < qsize * qsize; k += t.size) {
     int i, j;
     split2(dq, k, i, j);
-    const lds_i16* M = dct + ((i << rs) << 5);
-    const lds_i16* col = tmp + j;
-    int sum = 0;
-    for (int q = 0; q < size1; q += 4) {
-      const int m0 = M[q], m1 = M[q + 1], m2 = M[q + 2], m3 = M[q + 3];
-      const int a0 = col[q * qsize], a1 = col[(q + 1) * qsize], a2 = col[(q + 2) * qsize], a3 = col[(q + 3) * qsize];
-      sum += m0 * a0 + m1 * a1 + m2 * a2 + m3 * a3;
-    }
+    const int sum = dot_i16(dct + ((i << rs) << 5), tmp + j * size1, size1, j);
     coef[i * qsize + j] = (int16_t)((sum + add_2) >> shift_2);
   }
   t.sync();
 }
 
-// Same core transform on an explicit int16 block already stored TRANSPOSED in ws->in (early skip).
+// Same core transform on an explicit int16 block already stored (row-major) in ws->in (early skip).
 TK_DEV void fwd_transform_block(const Team t, XformWs* ws, int size, int bitdepth) {
   fwd_core(t, ws, size, size, ilog2(size) + bitdepth - 8);
 }
@@ -216,12 +245,14 @@ TK_DEV void dequantize(const Team t, XformWs* ws, const int16_t* coefq_, int qp,
   const int lshift = qp / 6, rshift = ilog2(size) - 1;
   const int64_t scale = dequant_scale(qp % 6);
   lds_i16* const rcoef = TK_LDS_PTR(ws->coef);
+  const int lgq = ilog2((unsigned)qsize);
   for (int k = t.rank; k < qsize * qsize; k += t.size) {
     int64_t c = coefq[k];
     int16_t r;
     if (lshift >= rshift) r = (int16_t)((c * scale) << (lshift - rshift));
     else r = (int16_t)((c * scale + ((int64_t)1 << (rshift - lshift - 1))) >> (rshift - lshift));
-    rcoef[k] = r;  // rcoef aliases coef (the forward coefficients are dead after quantisation)
+    rcoef[((k & (qsize - 1)) << lgq) + (k >> lgq)] = r;  // TRANSPOSED (rcoef[col][row]); aliases coef: every lane has read its coefq[k] from the
+                                                          // caller's buffer, not from here
   }
   t.sync();
 }
@@ -237,37 +268,23 @@ TK_DEV void inv_transform_recon(const Team t, XformWs* ws, const PIX* pred_, int
   const int qsize = n < kMaxQuant ? n : kMaxQuant;
   const int rs = 5 - ilog2((unsigned)n);
   lds_i16* const itmp = TK_LDS_PTR(ws->in);  // aliases `in`
-  const lds_i16* const dct = TK_DCT32(t, ws);
-  const lds_i16* const rcoef = TK_LDS_PTR(ws->coef);
+  const lds_i16* const mt = TK_DCTT(t, ws) + dctT_off(n);   // MT[j][k] = M[k][j], row pitch n
+  const lds_i16* const rcoef = TK_LDS_PTR(ws->coef);        // transposed by dequantize: rcoef[col i][row k]
   const int shift_2 = 20 - bitdepth, add_2 = 1 << (shift_2 - 1);
-  const int mstride = (1 << rs) << 5;  // basis row pitch in the 32-point table
   const Pow2 dn = mk_pow2(n);
-  // stage 1: itmp[i*n + j] = clip((sum_k M[k][j]*rcoef[k][i] + 64) >> 7)   i < qsize, j < n
+  (void)rs;
+  // stage 1: itmp[j][i] = clip((sum_k M[k][j]*rcoef[k][i] + 64) >> 7)   i < qsize, j < n   (stored [sample j][coef col i])
   for (int k = t.rank; k < qsize * n; k += t.size) {
     int i, j;
     split2(dn, k, i, j);
-    const lds_i16* M = dct + j;
-    const lds_i16* col = rcoef + i;
-    int sum = 0;
-    for (int q = 0; q < qsize; q += 4) {  // qsize is 4, 8 or 16
-      const int m0 = M[q * mstride], m1 = M[(q + 1) * mstride], m2 = M[(q + 2) * mstride], m3 = M[(q + 3) * mstride];
-      const int a0 = col[q * qsize], a1 = col[(q + 1) * qsize], a2 = col[(q + 2) * qsize], a3 = col[(q + 3) * qsize];
-      sum += m0 * a0 + m1 * a1 + m2 * a2 + m3 * a3;
-    }
-    itmp[i * n + j] = (int16_t)clampi((sum + 64) >> 7, -32768, 32767);
+    const int sum = dot_i16(mt + j * n, rcoef + i * qsize, qsize, j);
+    itmp[j * qsize + i] = (int16_t)clampi((sum + 64) >> 7, -32768, 32767);
   }
   t.sync();
   for (int k = t.rank; k < n * n; k += t.size) {
     int i, j;
     split2(dn, k, i, j);
-    const lds_i16* M = dct + j;
-    const lds_i16* col = itmp + i;
-    int sum = 0;
-    for (int q = 0; q < qsize; q += 4) {
-      const int m0 = M[q * mstride], m1 = M[(q + 1) * mstride], m2 = M[(q + 2) * mstride], m3 = M[(q + 3) * mstride];
-      const int a0 = col[q * n], a1 = col[(q + 1) * n], a2 = col[(q + 2) * n], a3 = col[(q + 3) * n];
-      sum += m0 * a0 + m1 * a1 + m2 * a2 + m3 * a3;
-    }
+    const int sum = dot_i16(mt + j * n, itmp + i * qsize, qsize, j);
     int r = clampi((sum + add_2) >> shift_2, -32768, 32767);
     for (int m = 0; m < scale; m++)
       for (int x = 0; x < scale; x++) {
