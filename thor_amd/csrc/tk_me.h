@@ -466,6 +466,9 @@ template <typename PIX, int SP>
 TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const PIX* ref, const MeArgs& a_in, mv_t mvc,
                                 mv_t mvp, int ref_idx, mv_t* mv_out) {
   TK_PROF_T0();
+#if defined(THOR_PROF_ME) && defined(THOR_PROF) && !TK_HOST
+  const long long pme0_ = (long long)__builtin_readcyclecounter();
+#endif
   const auto w = ldsc(w_);
   const auto lists = ldsc(lds_ld(&w_->lists));
   const auto orgs = spc<SP>(org);
@@ -801,6 +804,14 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
     mv_opt = mk_mv(mv_opt.x + xd_qp, mv_opt.y + yd_qp);
   }
   TK_PROF_ADD(w, 3);
+#if defined(THOR_PROF_ME) && defined(THOR_PROF) && !TK_HOST
+  // whole-call cycles and call counts by coding-block size (this build's code_tu does not use slots 16..25)
+  if (t.rank == 0) {
+    const int cls = a.cb_size <= 8 ? 0 : a.cb_size == 16 ? 1 : a.cb_size == 32 ? 2 : a.cb_size == 64 ? 3 : 4;
+    w->prof[16 + cls] += (long long)__builtin_readcyclecounter() - pme0_;
+    w->prof[21 + cls] += 1;
+  }
+#endif
   *mv_out = mv_opt;
   return cmin < min_sad ? cmin : min_sad;
 }
