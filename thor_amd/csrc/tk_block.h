@@ -66,6 +66,7 @@ struct WgShared {
   unsigned long long bestkey;    // min over finished trials of (cost << 32 | evaluation order), atomic
   unsigned long long wkey[kWaves];
   BlkParam wbest[kWaves];
+  void* wsnap[kWaves];           // BigWs of wave w (its best-trial snapshot)
   MdItem items[kMdMaxItems];
   // original samples (Y, U, V; stride = block size) of the coding block being decided when it is at most kLdsBlk wide:
   // loaded once by the master, read by every trial of every wave instead of the frame in global memory
@@ -96,6 +97,10 @@ template <typename PIX> struct BigWs {
   PIX rec_y[kMaxSb * kMaxSb], rec_u[kMaxSb * kMaxSb / 4], rec_v[kMaxSb * kMaxSb / 4];
   PIX org8[kMaxSb * kMaxSb];
   int16_t coef_u_big[4 * 256], coef_v_big[4 * 256];
+  // snapshot of this wave's best trial of the current block decision (reconstruction + quantised coefficients): the final
+  // encode of the winning trial copies it instead of predicting / transforming the block again (mode_decision_par)
+  PIX best_y[kMaxSb * kMaxSb], best_u[kMaxSb * kMaxSb / 4], best_v[kMaxSb * kMaxSb / 4];
+  int16_t best_cy[4 * 256], best_cu[4 * 256], best_cv[4 * 256];
 };
 template <typename PIX> struct TeamWs {  // view (lives in registers)
   XformWs* xfp;
@@ -1119,6 +1124,31 @@ TK_DEV BlkParam blank_param() {
   return p;
 }
 
+// Keep the trial that is in ws->rec_* / ws->coef_* (reconstruction and quantised coefficients of a square block of `size`)
+// in the wave's snapshot buffers.
+template <typename PIX, int SP>
+TK_DEV void snapshot_trial(const Team t, WsP<PIX> ws, int size, const BlkParam& p) {
+  BigWs<PIX>* g = ws->big;
+  const int sc = size >> 1;
+  copy_block<SP_GLOBAL, SP>(t, g->best_y, size, ws->rec_y, size, size, size);
+  copy_block<SP_GLOBAL, SP>(t, g->best_u, sc, ws->rec_u, sc, sc, sc);
+  copy_block<SP_GLOBAL, SP>(t, g->best_v, sc, ws->rec_v, sc, sc, sc);
+  if (TKU(p.cbp_y) | TKU(p.cbp_u) | TKU(p.cbp_v)) {
+    const int tbs = TKU(p.tb_split);
+    const int qy = tbs ? tmin(size >> 1, (int)kMaxQuant) : tmin(size, (int)kMaxQuant);
+    const int ny = (tbs ? 4 : 1) * qy * qy;
+    const int csplit = tbs && sc > 4;
+    const int qc = csplit ? tmin(sc >> 1, (int)kMaxQuant) : tmin(sc, (int)kMaxQuant);
+    const int nc = (csplit ? 4 : 1) * qc * qc;
+    const int16_t *cy = ws->coef_y, *cu = ws->coef_u, *cv = ws->coef_v;
+    TK_GLOBAL int16_t* dy = gptr(g->best_cy);
+    TK_GLOBAL int16_t* du = gptr(g->best_cu);
+    TK_GLOBAL int16_t* dv = gptr(g->best_cv);
+    for (int k = t.rank; k < ny; k += t.size) dy[k] = cy[k];
+    for (int k = t.rank; k < nc; k += t.size) { du[k] = cu[k]; dv[k] = cv[k]; }
+  }
+}
+
 template <typename PIX> struct MdCtx {
   Wg wg;
   WgShared* sh;
@@ -1138,6 +1168,7 @@ TK_DEV void par_trial(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& M, Blk
       *ldsc(&M.sh->wkey[M.wg.wave]) = key;
       wg_min64(&M.sh->bestkey, key);
     }
+    snapshot_trial<PIX, SP>(t, ws, tk_uniform(ldsc(M.nd)->size), p);
     t.sync();
   }
 }
@@ -1328,6 +1359,7 @@ TK_DEVNI void md_worker_sp(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws) 
   const auto sh = ldsc(sh_);
   MdCtx<PIX> M;
   M.wg = wg; M.sh = sh_; M.nd = &sh_->stack[sh->node]; M.mykey = ~0ull;
+  if (t.rank == 0) sh->wsnap[wg.wave] = (void*)ws->big;
   const auto ndl = ldsc(M.nd);
   ws_select(ws, tk_uniform(ndl->size));
   org_select(t, J, ws, tk_uniform(ndl->size), ndl->ypos, ndl->xpos, ndl->bw, ndl->bh, 0);
@@ -1405,7 +1437,7 @@ TK_DEV void wg_helper_loop(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws) 
 
 // Master side.  Result in nd.best; returns min cost.
 template <typename PIX>
-TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int node) {
+TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int node, int* win_wave) {
   const auto& c = J.cfg;
   WgShared* sh_ = ws->sh;
   const auto sh = ldsc(sh_);
@@ -1456,6 +1488,7 @@ TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, JobR<PIX> J, WsP<
   if (best == ~0ull) return kCostInit;
   if (t.rank == 0) lds_st(&sh_->stack[node].best, lds_ld(&sh_->wbest[bw]));
   t.sync();
+  *win_wave = bw;
   return (unsigned)(best >> 32);
 }
 
@@ -1578,26 +1611,44 @@ TK_DEVNI int check_early_skip(const Team t, JobR<PIX> J, WsP<PIX> ws, const Node
 // Final encode of a CB: recompute (encode_block final), write recon + cell state, emit bits.
 // ---------------------------------------------------------------------------------
 template <typename PIX, int SP>
-TK_DEVNI int final_encode(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd, BitSink& out) {
+TK_DEVNI int final_encode(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd, BitSink& out, const BigWs<PIX>* snap = nullptr) {
   TK_PROF_T0();
   BlkParam p = lds_ld(&nd.best);
-  BitSink cnt;
-  cnt.buf = nullptr; cnt.pos = 0; cnt.cap = 0; cnt.emit = 0; cnt.ovf = 0;
-  int nbits = encode_block<PIX, SP>(t, J, ws, nd, p, cnt);
-  // bits (one lane), then recon copy and cells (all lanes)
-  if (t.rank == 0) {
-    BitSink w = out;
-    bs_open(w);
-    bs_block_t<true>(w, lds_ld(&nd.syn), p, ws->coef_y, ws->coef_u, ws->coef_v, nullptr, nullptr);
-    bs_close(w);
-    out.ovf |= w.ovf;
-  }
-  out.pos += nbits;
   const int size = nd.size, sc = size >> 1;
   const int yc = nd.ypos >> 1, xc = nd.xpos >> 1;
-  copy_block<SP_GLOBAL, SP>(t, J.rec.y + nd.ypos * J.rec.sy + nd.xpos, J.rec.sy, ws->rec_y, size, nd.bw, nd.bh);
-  copy_block<SP_GLOBAL, SP>(t, J.rec.u + yc * J.rec.sc + xc, J.rec.sc, ws->rec_u, sc, nd.bw >> 1, nd.bh >> 1);
-  copy_block<SP_GLOBAL, SP>(t, J.rec.v + yc * J.rec.sc + xc, J.rec.sc, ws->rec_v, sc, nd.bw >> 1, nd.bh >> 1);
+  int nbits = 0;
+  if (snap) {
+    // the winning trial of the parallel decision left its reconstruction and coefficients in its wave's snapshot: emit + copy
+    if (t.rank == 0) {
+      BitSink w = out;
+      bs_open(w);
+      bs_block_t<true>(w, lds_ld(&nd.syn), p, snap->best_cy, snap->best_cu, snap->best_cv, nullptr, nullptr);
+      bs_close(w);
+      out.ovf |= w.ovf;
+      nbits = w.pos - out.pos;
+    }
+    nbits = team_bcast0(t, nbits);
+    out.pos += nbits;
+    copy_block<SP_GLOBAL, SP_GLOBAL>(t, J.rec.y + nd.ypos * J.rec.sy + nd.xpos, J.rec.sy, snap->best_y, size, nd.bw, nd.bh);
+    copy_block<SP_GLOBAL, SP_GLOBAL>(t, J.rec.u + yc * J.rec.sc + xc, J.rec.sc, snap->best_u, sc, nd.bw >> 1, nd.bh >> 1);
+    copy_block<SP_GLOBAL, SP_GLOBAL>(t, J.rec.v + yc * J.rec.sc + xc, J.rec.sc, snap->best_v, sc, nd.bw >> 1, nd.bh >> 1);
+  } else {
+    BitSink cnt;
+    cnt.buf = nullptr; cnt.pos = 0; cnt.cap = 0; cnt.emit = 0; cnt.ovf = 0;
+    nbits = encode_block<PIX, SP>(t, J, ws, nd, p, cnt);
+    // bits (one lane), then recon copy and cells (all lanes)
+    if (t.rank == 0) {
+      BitSink w = out;
+      bs_open(w);
+      bs_block_t<true>(w, lds_ld(&nd.syn), p, ws->coef_y, ws->coef_u, ws->coef_v, nullptr, nullptr);
+      bs_close(w);
+      out.ovf |= w.ovf;
+    }
+    out.pos += nbits;
+    copy_block<SP_GLOBAL, SP>(t, J.rec.y + nd.ypos * J.rec.sy + nd.xpos, J.rec.sy, ws->rec_y, size, nd.bw, nd.bh);
+    copy_block<SP_GLOBAL, SP>(t, J.rec.u + yc * J.rec.sc + xc, J.rec.sc, ws->rec_u, sc, nd.bw >> 1, nd.bh >> 1);
+    copy_block<SP_GLOBAL, SP>(t, J.rec.v + yc * J.rec.sc + xc, J.rec.sc, ws->rec_v, sc, nd.bw >> 1, nd.bh >> 1);
+  }
   // copy_deblock_data (encode_block.c:1568-1613)
   const int tbs = p.tb_param > 0 ? 1 : 0;
   const int pb = p.mode == M_INTER ? p.pb_part : P_NONE;
@@ -1773,10 +1824,11 @@ TK_DEV void process_sb(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int 
       ws_select(ws, tk_uniform(nd.size));
       org_select(t, J, ws, tk_uniform(nd.size), nd.ypos, nd.xpos, tk_uniform(nd.bw), tk_uniform(nd.bh), 1);  // the children replaced the LDS copy
       unsigned cost = 1u << 28;
+      int snap_wave = -1;
       if (nd.encode_this_size || nd.encode_rect) {
         if (!nd.md_done) {
           const int rect = nd.bw != nd.size || nd.bh != nd.size;
-          if (c.encoder_speed == 0 && c.intra_rdo && !rect) cost = mode_decision_par(wg, t, J, ws, sp);
+          if (c.encoder_speed == 0 && c.intra_rdo && !rect) cost = mode_decision_par(wg, t, J, ws, sp, &snap_wave);
           else cost = nd.size <= kLdsBlk ? mode_decision<PIX, SP_LDS>(t, J, ws, nd) : mode_decision<PIX, SP_GLOBAL>(t, J, ws, nd);
           t.sync();
 #if TK_HOST
@@ -1811,8 +1863,10 @@ TK_DEV void process_sb(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int 
         } else cost = nd.cost_this;
         if (cost <= nd.cost_small) {
           out.pos = nd.bitpos0;
-          if (nd.size <= kLdsBlk) final_encode<PIX, SP_LDS>(t, J, ws, nd, out);
-          else final_encode<PIX, SP_GLOBAL>(t, J, ws, nd, out);
+          // decided just now by the parallel decision: the winner's wave still holds its trial (snapshot_trial)
+          const BigWs<PIX>* snap = snap_wave >= 0 ? (const BigWs<PIX>*)ldsc(ws->sh)->wsnap[snap_wave] : nullptr;
+          if (nd.size <= kLdsBlk) final_encode<PIX, SP_LDS>(t, J, ws, nd, out, snap);
+          else final_encode<PIX, SP_GLOBAL>(t, J, ws, nd, out, snap);
         }
       }
       ret = cost < nd.cost_small ? cost : nd.cost_small;

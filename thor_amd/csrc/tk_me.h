@@ -164,10 +164,12 @@ template <> __device__ __forceinline__ int sad4v<uint8_t>(const Px4<uint8_t>& a,
 
 // Row segment of a block: up to 16 bytes (16 8-bit / 8 16-bit samples) held in four dwords, unused dwords zero.
 struct Seg16 { uint32_t d[4]; };
+#if !TK_HOST
 typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
 typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
 typedef u32x4 __attribute__((aligned(1), may_alias)) u32x4_unaligned;
 typedef u32x2 __attribute__((aligned(1), may_alias)) u32x2_unaligned;
+#endif
 // NB (4, 8 or 16) bytes at p.  SP: address space of p; LDS / scratch blocks are aligned to the segment size, frame planes
 // (global) may be read at any byte offset.
 template <int SP, int NB> TK_DEV Seg16 seg_load(const void* p) {
@@ -738,6 +740,31 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
       }
       const int sub_in_win = TKU(sizeof(PIX) == 1 && win.on && ctr.hor_int - 3 >= win.ox && ctr.hor_int + a.width + 5 <= win.ox + win.Ww &&
                                  ctr.ver_int - 3 >= win.oy && ctr.ver_int + a.height + 5 <= win.oy + win.Wh);
+      if (sizeof(PIX) == 1 && a.width * a.height >= 512) {
+        // large PUs: a lane takes a vertical strip of eight samples of one column (tk_pred.h:subk8_strip)
+        if constexpr (sizeof(PIX) == 1) {
+          for (int r = t.rank; r < a.width * (a.height >> 3); r += t.size) {
+            int st, j;
+            split2(dw, r, st, j);
+            const int i0 = st << 3;
+            const PIX* p0 = ref + (i0 + ctr.ver_int - 3) * a.rstride + (j + ctr.hor_int - 3);
+            unsigned long long wb[15];
+#if !TK_HOST
+#pragma unroll
+#endif
+            for (int q = 0; q < 15; q++) wb[q] = gload64(p0 + q * a.rstride) ^ 0x8080808080808080ull;
+            int o8[8];
+#if !TK_HOST
+#pragma unroll
+#endif
+            for (int q = 0; q < 8; q++) o8[q] = (int)orgs[(i0 + q) * a.ostride + j];
+#if !TK_HOST
+#pragma unroll
+#endif
+            for (int c = 0; c < 8; c++) sad8[c] = subk8_strip(wb, k8[c], o8, sad8[c]);
+          }
+        }
+      } else
       for (int r = t.rank; r < a.width * a.height; r += t.size) {
         int i, j;
         split2(dw, r, i, j);

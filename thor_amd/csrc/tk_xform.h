@@ -80,7 +80,9 @@ TK_DEV void xform_tables_fill(XformTabs* tb, int rank, int size) {
 
 // sum_{q<n} a[q] * b[q] of two contiguous int16 vectors in the team's transform workspace / tables (n = 4, 8, 16 or 32; both
 // 2n-byte aligned up to 16).  rot: chunk the lane starts with (spreads the lanes of a wave over the LDS banks).
+#if !TK_HOST
 typedef short __attribute__((ext_vector_type(2))) tk_s16x2;
+#endif
 TK_DEV int dot_i16(const lds_i16* a, const lds_i16* b, int n, int rot) {
 #if TK_HOST
   (void)rot;
