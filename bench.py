@@ -4,6 +4,9 @@
 
 Workload ("step"): one lock-step frame of S independent closed streams (sequence chunks - the only partition of this
 path that is bit-exact, SURVEY.md 8e: stream s is exactly what the reference produces with -skip/-n for its chunk).
+128 streams per GPU: a stream's superblocks form a 62-step dependency chain at 3840x2160, so a frame takes at least 62
+superblock times whatever the number of streams; 128 streams keep ~85 % of the 768 resident workgroups busy through the
+ramp-up / ramp-down of the dependency wavefront (96: 74 %, 144: 86 %, profiles/r03_sbtimes_4k_*.log).
 Warm-up steps include each stream's I frame; the timed K steps are the following frames in coding order.  Defaults:
 warm-up 1 (the I frame) + 4 timed P frames, the last of which searches all 4 reference frames of the operating point; the
 driver's `--steps 20 --warmup 5` times P frames 5..24, all with 4 references + bi-prediction.  Inputs are resident in HBM
@@ -199,7 +202,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=4)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--streams', type=int, default=int(os.environ.get('THOR_BENCH_STREAMS', '96')), help='streams PER GPU')
+    ap.add_argument('--streams', type=int, default=int(os.environ.get('THOR_BENCH_STREAMS', '128')), help='streams PER GPU')
     ap.add_argument('--width', type=int, default=3840)
     ap.add_argument('--height', type=int, default=2160)
     ap.add_argument('--config', choices=sorted(CONFIGS), default='ldb')

@@ -992,17 +992,18 @@ extern "C" void encode_frame_hbd(struct thor_encoder_info* ei) { encode_frame_im
 namespace tk {
 __global__ __launch_bounds__(64) void k_kat_sad(const uint8_t* org, int w, int h, const uint8_t* refp, int rstride, int bx,
                                                int by, const int* cand, int n, uint32_t* out) {
-  __shared__ int sad[kMeMaxCand];
+  // the product's full-pel evaluator (tk_me.h:seg_sads, row segment per lane), plane reads only (no search window)
   const Team t = mk_team((int)threadIdx.x, 64);
-  for (int base = 0; base < n; base += kMeMaxCand) {
-    const int m = n - base < kMeMaxCand ? n - base : kMeMaxCand;
-    auto ptr = [&](int c) -> const uint8_t* {
-      return refp + (size_t)(by + cand[2 * (base + c) + 1]) * rstride + bx + cand[2 * (base + c)];
-    };
-    sad_many_ptr<SP_GLOBAL>(t, sad, m, org, w, w, h, rstride, ptr);
-    for (int c = threadIdx.x; c < m; c += 64) out[base + c] = (uint32_t)sad[c];
-    __syncthreads();
-  }
+  struct KC { const uint8_t* p; int dx, dy; };
+  MeWin win;
+  win.on = 0; win.w32 = nullptr; win.ox = win.oy = win.Ww = win.Wh = win.pitch = 0;
+  auto cnd = [&](int c) -> KC {
+    KC x;
+    x.dx = cand[2 * c]; x.dy = cand[2 * c + 1];
+    x.p = refp + (size_t)(by + x.dy) * rstride + bx + x.dx;
+    return x;
+  };
+  seg_sads<SP_GLOBAL>(t, n, org, w, rstride, w, h, win, cnd, [&](int c, const KC&, int sad, int mine) { if (mine) out[c] = (uint32_t)sad; });
 }
 __global__ __launch_bounds__(64) void k_kat_interp(const uint8_t* ref0, int rstride, int pic_w, int pic_h, int bx, int by, int w,
                                                   int h, const int16_t* mv, int bipred, uint8_t* out) {

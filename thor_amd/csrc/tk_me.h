@@ -55,51 +55,6 @@ TK_DEV void add_mvcand(MeWs* w_, int r, mv_t mv) {
   w->mvcand_mask[r] |= m;
 }
 
-// |a-b| summed over 4 horizontally adjacent samples (a: 4-sample aligned, b: any alignment).
-// a: original block in address space SP (4-sample aligned), b: reference plane (global)
-template <int SP, typename PIX> TK_DEV int sad4(const PIX* a, const PIX* b) {
-#if !TK_HOST
-  if constexpr (sizeof(PIX) == 1) {
-    const uint32_t va = *(const typename SpT<SP, const uint32_t>::ptr)spc<SP>(a);
-    return (int)__builtin_amdgcn_sad_u8(va, gload32(b), 0u);  // v_sad_u8: 4 byte-SADs per lane-op
-  }
-#endif
-  const auto as = spc<SP>(a);
-  return iabs((int)as[0] - (int)b[0]) + iabs((int)as[1] - (int)b[1]) + iabs((int)as[2] - (int)b[2]) + iabs((int)as[3] - (int)b[3]);
-}
-
-// sad[c] = SAD(org block, block at base(c)) for c < ncand; full-pel candidates given as pointers.
-// Work item = (candidate, row, group of 4 samples).
-template <int SP, typename PIX, class F>
-TK_DEV void sad_many_ptr(const Team t, int* sad_, int ncand, const PIX* org, int ostride, int w, int h, int rstride, F base) {
-  const auto sad = ldsc(sad_);
-  // G lanes cooperate on one candidate (G = min(team, items per candidate), a power of two), P = team/G
-  // candidates are evaluated per pass; partial sums are combined with xor-shuffles (no atomics).
-  const int gpr = w >> 2, nit = h * gpr;
-  const int lg = ilog2((unsigned)gpr);
-  const int G = nit < t.size ? nit : t.size;
-  const int P = t.size / G;
-  const int slot = t.rank / G, sub = t.rank - slot * G;
-  for (int c0 = 0; c0 < ncand; c0 += 2 * P) {
-    const int ca = c0 + slot, cb = c0 + P + slot;
-    int la = 0, lb = 0;
-    if (ca < ncand) {
-      const PIX* b = base(ca);
-      for (int r = sub; r < nit; r += G) { int i = r >> lg, g = r & (gpr - 1); la += sad4<SP>(org + i * ostride + 4 * g, b + i * rstride + 4 * g); }
-    }
-    if (cb < ncand) {
-      const PIX* b = base(cb);
-      for (int r = sub; r < nit; r += G) { int i = r >> lg, g = r & (gpr - 1); lb += sad4<SP>(org + i * ostride + 4 * g, b + i * rstride + 4 * g); }
-    }
-    la = team_group_sum(t, la, G); lb = team_group_sum(t, lb, G);
-    if (sub == 0) {
-      if (ca < ncand) sad[ca] = la;
-      if (cb < ncand) sad[cb] = lb;
-    }
-  }
-  t.sync();
-}
-
 // Evaluate n candidates and return min over (cost << 32 | index): the first candidate in evaluation
 // order among those with the smallest cost - exactly the winner of the reference's sequential
 // "if (cost < min) ..." scan.  prep(c) -> per-candidate context, item(ctx, r) -> partial SAD of work
@@ -127,40 +82,6 @@ TK_DEV unsigned long long eval_min(const Team t, int n, int nit, PrepF prep, Ite
   }
   return TKU64(team_min64(t, best));
 }
-
-// 4-sample load helpers for the packed SAD
-template <typename PIX> struct Px4 { PIX v[4]; };
-template <int SP, typename PIX> TK_DEV Px4<PIX> ld4(const PIX* p) {  // p: original block in address space SP, 4-sample aligned
-  Px4<PIX> r;
-#if TK_HOST
-  __builtin_memcpy(&r, p, sizeof(r));
-#else
-  if constexpr (sizeof(PIX) == 1) { const uint32_t v = *(const typename SpT<SP, const uint32_t>::ptr)spc<SP>(p); __builtin_memcpy(&r, &v, 4); }
-  else { const unsigned long long v = *(const typename SpT<SP, const unsigned long long>::ptr)spc<SP>(p); __builtin_memcpy(&r, &v, 8); }
-#endif
-  return r;
-}
-template <typename PIX> TK_DEV Px4<PIX> ld4g(const PIX* p) {  // p: global memory (reference plane)
-  Px4<PIX> r;
-#if TK_HOST
-  __builtin_memcpy(&r, p, sizeof(r));
-#else
-  if constexpr (sizeof(PIX) == 1) { const uint32_t v = gload32(p); __builtin_memcpy(&r, &v, 4); }
-  else { const unsigned long long v = gload64(p); __builtin_memcpy(&r, &v, 8); }
-#endif
-  return r;
-}
-template <typename PIX> TK_DEV int sad4v(const Px4<PIX>& a, const Px4<PIX>& b) {
-  return iabs((int)a.v[0] - (int)b.v[0]) + iabs((int)a.v[1] - (int)b.v[1]) + iabs((int)a.v[2] - (int)b.v[2]) + iabs((int)a.v[3] - (int)b.v[3]);
-}
-#if !TK_HOST
-template <> __device__ __forceinline__ int sad4v<uint8_t>(const Px4<uint8_t>& a, const Px4<uint8_t>& b) {
-  uint32_t va, vb;
-  __builtin_memcpy(&va, &a, 4);
-  __builtin_memcpy(&vb, &b, 4);
-  return (int)__builtin_amdgcn_sad_u8(va, vb, 0u);
-}
-#endif
 
 // Row segment of a block: up to 16 bytes (16 8-bit / 8 16-bit samples) held in four dwords, unused dwords zero.
 struct Seg16 { uint32_t d[4]; };

@@ -188,42 +188,6 @@ TK_DEV int dot4_i8(int a, int b, int c) {
   return __builtin_amdgcn_sdot4(a, b, c, false);
 #endif
 }
-struct PackedTaps {
-  int h_lo, h_hi;  // th[0..3], th[4..5] as int8 lanes
-};
-TK_DEV PackedTaps pack_taps(const SubPel& s) {
-  PackedTaps p;
-  p.h_lo = (s.th[0] & 0xff) | ((s.th[1] & 0xff) << 8) | ((s.th[2] & 0xff) << 16) | ((s.th[3] & 0xff) << 24);
-  p.h_hi = (s.th[4] & 0xff) | ((s.th[5] & 0xff) << 8);
-  return p;
-}
-TK_DEV WinRow<uint8_t> win_bias(const WinRow<uint8_t>& r) {
-  WinRow<uint8_t> o;
-  o.a = r.a ^ 0x8080808080808080ull;
-  return o;
-}
-TK_DEV int win_raw8(const WinRow<uint8_t>& biased, int n) { return (int)(((biased.a >> (8 * n)) & 0xffu) ^ 0x80u); }
-TK_DEV int win_hsum8(const WinRow<uint8_t>& biased, const PackedTaps& pt) {
-  return dot4_i8(pt.h_lo, (int)(unsigned)biased.a, dot4_i8(pt.h_hi, (int)(unsigned)(biased.a >> 32), 128 * 64));
-}
-TK_DEV int luma_sample_win8(const WinRow<uint8_t> w[6], const SubPel& s, const PackedTaps& pt, int bipred) {  // w: biased rows
-  if (s.ver_frac == 0 && s.hor_frac == 0) return win_raw8(w[2], 2);
-  if (s.ver_frac == 2 && s.hor_frac == 2 && bipred < 2) {
-    int sum = win_raw8(w[1], 2) + win_raw8(w[1], 3) + win_raw8(w[2], 1) + 2 * win_raw8(w[2], 2) + 2 * win_raw8(w[2], 3) + win_raw8(w[2], 4) +
-              win_raw8(w[3], 1) + 2 * win_raw8(w[3], 2) + 2 * win_raw8(w[3], 3) + win_raw8(w[3], 4) + win_raw8(w[4], 2) + win_raw8(w[4], 3);
-    return sat_pix((sum + 8) >> 4, 8);
-  }
-  if (s.hor_frac == 0) {
-    int sum = 0;
-    for (int m = 0; m < 6; m++) sum += s.tv[m] * win_raw8(w[m], 2);
-    return sat_pix((sum * 64 + 2048) >> 12, 8);
-  }
-  if (s.ver_frac == 0) return sat_pix((win_hsum8(w[2], pt) * 64 + 2048) >> 12, 8);
-  int sum = 0;
-  for (int m = 0; m < 6; m++) sum += s.tv[m] * win_hsum8(w[m], pt);  // = sum_n th[n] * sum_m tv[m] * p[m][n]
-  return sat_pix((sum + 2048) >> 12, 8);
-}
-
 // Sub-pel search, 8-bit: one prediction sample straight from the eight biased window rows (row q = reference row
 // centre.ver_int - 3 + q, byte n = column centre.hor_int - 3 + n) for a candidate at integer offset (dy, dx) in 0..2 from
 // centre - 1.  The horizontal taps sit in an 8-byte vector at byte offset dx, so a row sum is two v_dot4 on the row as it was
