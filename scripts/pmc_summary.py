@@ -23,7 +23,7 @@ g = lambda k: agg.get(k, float('nan'))
 fetch_b = g('FETCH_SIZE') * 1024 * 2
 write_b = g('WRITE_SIZE') * 1024
 tsum = sum(times.get('sq1', [0]))
-res = {'workload': desc, 'luma_pixels': px, 'kernel_seconds_total': tsum, 'launches': len(times.get('sq1', [])),
+res = {'workload': desc, 'width': w, 'height': h, 'streams': S, 'frames': n, 'config': 'ldb', 'luma_pixels': px, 'kernel_seconds_total': tsum, 'launches': len(times.get('sq1', [])),
        'fetch_bytes_per_px': fetch_b / px, 'write_bytes_per_px': write_b / px,
        'valu_insts_per_px': g('SQ_INSTS_VALU') / px, 'salu_insts_per_px': g('SQ_INSTS_SALU') / px, 'lds_insts_per_px': g('SQ_INSTS_LDS') / px,
        'vmem_rd_insts_per_px': g('SQ_INSTS_VMEM_RD') / px, 'vmem_wr_insts_per_px': g('SQ_INSTS_VMEM_WR') / px, 'flat_insts_per_px': g('SQ_INSTS_FLAT') / px,
