@@ -190,9 +190,7 @@ struct BlkParam {  // block_param_t without the coefficient arrays (common/types
 // SC: address space of the coefficient block (SP_LDS for every buffer except the chroma buffers of tb-split 64/128 blocks)
 template <int SC>
 TK_DEVNI int coeff_bits_team(const Team t, const int16_t* coeff_, int size, int type) {
-#ifdef THOR_EXP_UNIFORM
   coeff_ = tk_uniform_ptr(coeff_); size = tk_uniform(size); type = tk_uniform(type);
-#endif
   const auto coeff = spc<SC>(coeff_);
   const int qsize = size < kMaxQuant ? size : kMaxQuant;
   const int N = qsize * qsize;
@@ -334,7 +332,6 @@ template <bool E, int SC> TK_DEV void bs_coeff_any(BitSink& b, const Team* t, co
 
 // ybits (optional, counting mode only): bit lengths of the luma TU coefficient strings already counted by the
 // caller (partial-cost pruning), [0] for an unsplit block, [t] for TU t of a tb-split one.
-#ifdef THOR_EXP_UNIFORM
 TK_DEV mv_t uniform_mv(mv_t m) { return mk_mv(tk_uniform(m.x), tk_uniform(m.y)); }
 TK_DEV SynCtx uniform_syn(const SynCtx& a) {
   SynCtx u;
@@ -354,7 +351,6 @@ TK_DEV BlkParam uniform_blk(const BlkParam& a) {
   for (int i = 0; i < 4; i++) { u.mv0[i] = uniform_mv(a.mv0[i]); u.mv1[i] = uniform_mv(a.mv1[i]); }
   return u;
 }
-#endif
 
 // E = false: cooperative counting (every lane of the team calls, b.emit == 0, tm != nullptr) - the instance all RDO trials
 // use; E = true: emission by ONE lane (or serial counting when tm == nullptr).
@@ -362,15 +358,10 @@ TK_DEV BlkParam uniform_blk(const BlkParam& a) {
 template <bool E, int SCC = SP_LDS>
 TK_DEVNI int bs_block_t(BitSink& b, const SynCtx& s_in, const BlkParam& p_in, const int16_t* cy, const int16_t* cu,
                     const int16_t* cv, const Team* tm, const int* ybits) {
-#ifdef THOR_EXP_UNIFORM
   // only in cooperative counting mode: the emitting call is made by one lane alone
   const bool coop = !E;
   const SynCtx s = coop ? uniform_syn(s_in) : s_in;
   const BlkParam p = coop ? uniform_blk(p_in) : p_in;
-#else
-  const SynCtx& s = s_in;
-  const BlkParam& p = p_in;
-#endif
   const int start = b.pos;
   const int size = s.size, size_uv = size >> 1;
   const int mode = p.mode;

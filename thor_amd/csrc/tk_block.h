@@ -36,10 +36,7 @@ struct Node {
 // up to 128x128 in a global scratch arena that stays L1/L2 resident).
 enum { kProfSlots = 32 };
 enum { kMdMaxItems = 32 };
-#ifndef TK_LDS_BLK
-#define TK_LDS_BLK 16
-#endif
-enum { kLdsBlk = TK_LDS_BLK };
+enum { kLdsBlk = 16 };   // coding blocks up to this size keep their sample buffers in LDS
 enum { MD_SKIP = 0, MD_MERGE, MD_REF, MD_INTRA, MD_BIPRED };
 enum { WG_CMD_EXIT = 0, WG_CMD_MD = 1 };
 struct MdItem { int8_t kind, a, b, pad; };
@@ -312,9 +309,7 @@ TK_DEV void find_contexts(const DbCell* cells, int cs, int ypos, int xpos, int f
 // SP: address space of both sample blocks; acc lives in LDS
 template <int SP, typename PIX>
 TK_DEV void ssd_acc(const Team t, unsigned long long* acc, const PIX* a_, int as, const PIX* b_, int bs, int w, int h) {
-#ifdef THOR_EXP_UNIFORM
   acc = tk_uniform_ptr(acc); a_ = tk_uniform_ptr(a_); b_ = tk_uniform_ptr(b_); as = tk_uniform(as); bs = tk_uniform(bs); w = tk_uniform(w); h = tk_uniform(h);
-#endif
   const auto a = spc<SP>(a_);
   const auto b = spc<SP>(b_);
   unsigned long long local = 0;

@@ -14,16 +14,9 @@
 #include <stdint.h>
 #include <stddef.h>
 // Wave-uniform values (arguments of the hot callees, running minima, syntax parameters) are moved to scalar registers
-// with readfirstlane: +8 % on the MI355X (profiles/r02_ab_variants.md), bit-exact on the GPU parity suite.  The host
-// simulation checks the uniformity assumption (tk_uniform aborts when lanes disagree).  -DTHOR_NO_UNIFORM turns it off.
-#if !defined(THOR_NO_UNIFORM) && !defined(THOR_EXP_UNIFORM)
-#define THOR_EXP_UNIFORM 1
-#endif
-
-// Wave reductions through DPP + v_readlane instead of ds_bpermute shuffles: +5 % on the MI355X (profiles/r03_call2_findings.md)
-#ifndef TK_DPP
-#define TK_DPP 1
-#endif
+// with readfirstlane (TKU / tk_uniform*): function arguments arrive in vector registers, and a branch on a vector register is
+// exec-mask code.  The host simulation checks the uniformity assumption (tk_uniform aborts when lanes disagree).
+// Wave reductions use DPP row operations + v_readlane instead of ds_bpermute shuffles (profiles/r03_call2_findings.md).
 #if defined(THOR_HOSTSIM)
 #include <string.h>
 #include <stdlib.h>
@@ -128,18 +121,13 @@ struct BlockTeam {
 // (tk_block.h:mode_decision_par).  The host simulation runs one OS thread per wave (-DTHOR_HOSTSIM_WAVES=N, 1-lane
 // teams) or a single wave (everything else).
 // ---------------------------------------------------------------------------------
-#ifndef TK_WAVES
-#if TK_HOST
-#ifdef THOR_HOSTSIM_WAVES
-#define TK_WAVES THOR_HOSTSIM_WAVES
+#if !TK_HOST
+enum { kWaves = 4 };
+#elif defined(THOR_HOSTSIM_WAVES)
+enum { kWaves = THOR_HOSTSIM_WAVES };
 #else
-#define TK_WAVES 1
+enum { kWaves = 1 };
 #endif
-#else
-#define TK_WAVES 4
-#endif
-#endif
-enum { kWaves = TK_WAVES };
 #if TK_HOST && defined(THOR_HOSTSIM_WAVES)
 namespace hostwaves { void barrier(); }
 #endif
@@ -288,12 +276,7 @@ TK_DEV int team_sum(const Team t, int v) {
   return v;
 #else
   (void)t;
-#if TK_DPP
   return wave_sum_dpp(v);
-#else
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-  return v;
-#endif
 #endif
 }
 TK_DEV int team_max(const Team t, int v) {
@@ -308,12 +291,7 @@ TK_DEV int team_max(const Team t, int v) {
   return v;
 #else
   (void)t;
-#if TK_DPP
   return wave_max_i32_dpp(v);
-#else
-  for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(v, d); v = o > v ? o : v; }
-  return v;
-#endif
 #endif
 }
 TK_DEV int team_shfl_xor(const Team t, int v, int d) {
@@ -333,7 +311,7 @@ TK_DEV int team_shfl_xor(const Team t, int v, int d) {
 }
 // sum over aligned groups of G lanes (G a power of two <= team size), result in every lane of the group
 TK_DEV int team_group_sum(const Team t, int v, int G) {
-#if !TK_HOST && TK_DPP
+#if !TK_HOST
   (void)t;
   if (G >= 2) v += dpp_mov<DPP_XOR1>(v);
   if (G >= 4) v += dpp_mov<DPP_XOR2>(v);
@@ -359,15 +337,7 @@ TK_DEV unsigned long long team_min64(const Team t, unsigned long long v) {
   return v;
 #else
   (void)t;
-#if TK_DPP
   return wave_min64_dpp(v);
-#else
-  for (int d = 32; d >= 1; d >>= 1) {
-    unsigned long long o = __shfl_xor(v, d);
-    v = o < v ? o : v;
-  }
-  return v;
-#endif
 #endif
 }
 // Value known to be identical in every lane of the team: on the device it is moved to a scalar register so that
@@ -402,8 +372,6 @@ TK_DEV int team_bcast0(const Team t, int v) {
   return __builtin_amdgcn_readfirstlane(v);
 #endif
 }
-// THOR_EXP_UNIFORM (default on, see the top of this file): scalarise more wave-uniform values.  TKU*/tk_uniform* are
-// identities when it is off.
 TK_DEV unsigned long long tk_uniform64(unsigned long long v) {
 #if TK_LANES
   const unsigned long long* g = hostlanes::exchange_begin(v);
@@ -427,13 +395,8 @@ TK_DEV double tk_uniform_f64(double d) {
   return d;
 }
 template <class T> TK_DEV T* tk_uniform_ptr(T* p) { return (T*)(uintptr_t)tk_uniform64((unsigned long long)(uintptr_t)p); }
-#ifdef THOR_EXP_UNIFORM
 #define TKU(x) tk_uniform(x)
 #define TKU64(x) tk_uniform64(x)
-#else
-#define TKU(x) (x)
-#define TKU64(x) (x)
-#endif
 // sum over the team, result in every lane (xor-shuffle butterfly; identity for a 1-lane team)
 TK_DEV unsigned long long team_sum64(const Team t, unsigned long long v) {
 #if TK_LANES
@@ -447,12 +410,7 @@ TK_DEV unsigned long long team_sum64(const Team t, unsigned long long v) {
   return v;
 #else
   (void)t;
-#if TK_DPP
   return wave_sum64_dpp(v);
-#else
-  for (int d = 32; d >= 1; d >>= 1) v += (unsigned long long)__shfl_xor(v, d);
-  return v;
-#endif
 #endif
 }
 // index of the highest set bit of m strictly below `rank`, or -1

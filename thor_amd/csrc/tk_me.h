@@ -397,7 +397,6 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
   const auto orgs = spc<SP>(org);
   auto cmv_get = [&](int c) -> mv_t { return mk_mv(w->cmv[c].x, w->cmv[c].y); };
   auto cmv_set = [&](int c, mv_t m) { w->cmv[c].x = m.x; w->cmv[c].y = m.y; };
-#ifdef THOR_EXP_UNIFORM
   MeArgs a_u;
   a_u.cb_size = tk_uniform(a_in.cb_size); a_u.ostride = tk_uniform(a_in.ostride); a_u.width = tk_uniform(a_in.width);
   a_u.height = tk_uniform(a_in.height); a_u.rstride = tk_uniform(a_in.rstride); a_u.sign = tk_uniform(a_in.sign);
@@ -409,9 +408,6 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
   mvc = mk_mv(tk_uniform(mvc.x), tk_uniform(mvc.y));
   mvp = mk_mv(tk_uniform(mvp.x), tk_uniform(mvp.y));
   ref_idx = tk_uniform(ref_idx);
-#else
-  const MeArgs& a = a_in;
-#endif
   const int s = a.sign ? -1 : 1;
   const int sh = a.bitdepth - 8;
   unsigned min_sad = kCostInit;

@@ -407,11 +407,9 @@ template <int SP, typename PIX>
 TK_DEV void make_edges(const Team t, IntraEdge<PIX>* e, const PIX* rec_frame, int fstride, const PIX* rblock,
                        int rbstride, int i, int j, int ypos, int xpos, int size, int cb_upright, int cb_downleft,
                        int tb_split, int bitdepth) {
-#ifdef THOR_EXP_UNIFORM
   e = tk_uniform_ptr(e); rec_frame = tk_uniform_ptr(rec_frame); rblock = tk_uniform_ptr(rblock); fstride = tk_uniform(fstride);
   rbstride = tk_uniform(rbstride); i = tk_uniform(i); j = tk_uniform(j); ypos = tk_uniform(ypos); xpos = tk_uniform(xpos); size = tk_uniform(size);
   cb_upright = tk_uniform(cb_upright); cb_downleft = tk_uniform(cb_downleft); tb_split = tk_uniform(tb_split); bitdepth = tk_uniform(bitdepth);
-#endif
   const int len = 2 * size;
   const PIX dflt = (PIX)(128 << (bitdepth - 8));
   int downleft, upright;
@@ -478,10 +476,8 @@ template <int SP, typename PIX>
 TK_DEV void pred_intra(const Team t, const IntraEdge<PIX>* e, int ypos, int xpos, int size, PIX* dst_, int dstride,
                        int mode, int bitdepth) {
   PIX* dst = dst_;
-#ifdef THOR_EXP_UNIFORM
   e = tk_uniform_ptr(e); dst = tk_uniform_ptr(dst); ypos = tk_uniform(ypos); xpos = tk_uniform(xpos); size = tk_uniform(size);
   dstride = tk_uniform(dstride); mode = tk_uniform(mode); bitdepth = tk_uniform(bitdepth);
-#endif
   typedef TK_LDS PIX lpix;  // the edge arrays live in LDS on the device (see tk_common.h)
   const lpix* left = (const lpix*)ldsc(e->left);
   const lpix* top = (const lpix*)ldsc(e->top);

@@ -299,9 +299,7 @@ TK_DEV void inv_transform_recon(const Team t, XformWs* ws, const PIX* pred_, int
 
 template <int SD, int SS, typename PIX>
 TK_DEV void copy_block(const Team t, PIX* dst_, int dstride, const PIX* src_, int sstride, int w, int h) {
-#ifdef THOR_EXP_UNIFORM
   dst_ = tk_uniform_ptr(dst_); src_ = tk_uniform_ptr(src_); dstride = tk_uniform(dstride); sstride = tk_uniform(sstride); w = tk_uniform(w); h = tk_uniform(h);
-#endif
   const auto dst = spc<SD>(dst_);
   const auto src = spc<SS>(src_);
   if ((w & (w - 1)) == 0) {
@@ -325,11 +323,9 @@ TK_DEV void copy_block(const Team t, PIX* dst_, int dstride, const PIX* src_, in
 template <typename PIX, int SP, int SC>
 TK_DEVNI int code_tu_sp(const Team t, XformWs* ws, const PIX* org, int ostride, const PIX* pred, int pstride, PIX* rec,
                    int rstride, int size, int qp, int coeff_type, int fast, int16_t* coefq, int bitdepth) {
-#ifdef THOR_EXP_UNIFORM
   org = tk_uniform_ptr(org); pred = tk_uniform_ptr(pred); rec = tk_uniform_ptr(rec); coefq = tk_uniform_ptr(coefq); ws = tk_uniform_ptr(ws);
   ostride = tk_uniform(ostride); pstride = tk_uniform(pstride); rstride = tk_uniform(rstride); size = tk_uniform(size);
   qp = tk_uniform(qp); coeff_type = tk_uniform(coeff_type); fast = tk_uniform(fast); bitdepth = tk_uniform(bitdepth);
-#endif
   TK_PROF_T0();
   fwd_transform<PIX, SP>(t, ws, org, ostride, pred, pstride, size, fast, bitdepth);
   TK_PROF_ADD(ws, 30);
