@@ -306,32 +306,37 @@ TK_DEV void find_contexts(const DbCell* cells, int cs, int ypos, int xpos, int f
 // ---------------------------------------------------------------------------------
 // SSD / cost
 // ---------------------------------------------------------------------------------
-// SP: address space of both sample blocks; acc lives in LDS
+// Sum of squared differences of two sample blocks, kept in registers: ssd_part() is this lane's share (8-bit samples: at most
+// 256 samples x 255^2 per lane and 1.6e9 for the three planes of a 128x128 block - 32-bit arithmetic; 64-bit for 16-bit
+// samples), ssd_total() the wave-wide sum - one DPP reduction per cost instead of an LDS accumulator round trip per plane.
+// SP: address space of both sample blocks.
+template <typename PIX> struct SsdT { typedef unsigned long long type; };
+template <> struct SsdT<uint8_t> { typedef unsigned type; };
 template <int SP, typename PIX>
-TK_DEV void ssd_acc(const Team t, unsigned long long* acc, const PIX* a_, int as, const PIX* b_, int bs, int w, int h) {
-  acc = tk_uniform_ptr(acc); a_ = tk_uniform_ptr(a_); b_ = tk_uniform_ptr(b_); as = tk_uniform(as); bs = tk_uniform(bs); w = tk_uniform(w); h = tk_uniform(h);
+TK_DEV typename SsdT<PIX>::type ssd_part(const Team t, const PIX* a_, int as, const PIX* b_, int bs, int w, int h) {
+  a_ = tk_uniform_ptr(a_); b_ = tk_uniform_ptr(b_); as = tk_uniform(as); bs = tk_uniform(bs); w = tk_uniform(w); h = tk_uniform(h);
   const auto a = spc<SP>(a_);
   const auto b = spc<SP>(b_);
-  unsigned long long local = 0;
+  typename SsdT<PIX>::type local = 0;
   if ((w & (w - 1)) == 0) {  // every width except the frame-edge rectangles
     const Pow2 pw = mk_pow2(w);
     for (int k = t.rank; k < w * h; k += t.size) {
       int i, j;
       split2(pw, k, i, j);
       int d = (int)a[i * as + j] - (int)b[i * bs + j];
-      local += (unsigned long long)(d * d);
+      local += (typename SsdT<PIX>::type)(d * d);
     }
   } else {
     for (int k = t.rank; k < w * h; k += t.size) {
       int i = k / w, j = k - i * w;
       int d = (int)a[i * as + j] - (int)b[i * bs + j];
-      local += (unsigned long long)(d * d);
+      local += (typename SsdT<PIX>::type)(d * d);
     }
   }
-  // butterfly reduction + one writer instead of 64 same-address LDS atomics (the callers sync before reading)
-  local = team_sum64(t, local);
-  if (t.rank == 0) *ldsc(acc) += local;
+  return local;
 }
+TK_DEV unsigned long long ssd_total(const Team t, unsigned v) { return (unsigned long long)(unsigned)team_sum(t, (int)v); }
+TK_DEV unsigned long long ssd_total(const Team t, unsigned long long v) { return team_sum64(t, v); }
 
 // cost_calc (encode_block.c:916-926) on the trial recon in ws->rec_* vs. the original frame.
 template <typename PIX, int SP>
@@ -339,17 +344,13 @@ TK_DEVNI unsigned rd_cost(const Team t, JobR<PIX> J, WsP<PIX> ws, const Node& nd
                          long long ssd_y = -1) {
   TK_PROF_T0();
   const auto nd = ldsc(&nd_);
-  const auto acc = ldsc(ws->acc);
   const int size = TKU(nd->size), bw = TKU(nd->bw), bh = TKU(nd->bh);
-  if (t.rank == 0) acc[0] = ssd_y >= 0 ? (unsigned long long)ssd_y : 0ull;
-  t.sync();
   const int sc = size >> 1;
-  if (ssd_y < 0) ssd_acc<SP>(t, &ws->acc[0], ws->org_y, ws->org_sy, ws->rec_y, size, bw, bh);
-  ssd_acc<SP>(t, &ws->acc[0], ws->org_u, ws->org_sc, ws->rec_u, sc, bw >> 1, bh >> 1);
-  ssd_acc<SP>(t, &ws->acc[0], ws->org_v, ws->org_sc, ws->rec_v, sc, bw >> 1, bh >> 1);
-  t.sync();
-  unsigned long long ssd = acc[0];
-  t.sync();
+  typename SsdT<PIX>::type part = 0;
+  if (ssd_y < 0) part += ssd_part<SP>(t, ws->org_y, ws->org_sy, ws->rec_y, size, bw, bh);
+  part += ssd_part<SP>(t, ws->org_u, ws->org_sc, ws->rec_u, sc, bw >> 1, bh >> 1);
+  part += ssd_part<SP>(t, ws->org_v, ws->org_sc, ws->rec_v, sc, bw >> 1, bh >> 1);
+  const unsigned long long ssd = ssd_total(t, part) + (ssd_y >= 0 ? (unsigned long long)ssd_y : 0ull);
   unsigned long long cost = (ssd >> (J.cfg.bitdepth * 2 - 16)) + (unsigned long long)(long long)mul_add_nofma(lambda, (double)nbits, 0.5);
   if (cost > (1ull << 30)) cost = 1ull << 30;
   TK_PROF_ADD(ws, PF_COST);
@@ -364,26 +365,24 @@ template <typename PIX, int SP>
 TK_DEVNI void improve_uv(const Team t, WsP<PIX> ws, const PIX* y_, PIX* u_, PIX* v_, const PIX* ry_, int n, int cstride,
                        int stride, int bitdepth) {
   const auto y = spc<SP>(y_); const auto u = spc<SP>(u_); const auto v = spc<SP>(v_); const auto ry = spc<SP>(ry_);
-  const auto acc = ldsc(ws->acc);
+  (void)ws;
   const int nc = n >> 1, lognc = ilog2(nc), cs = cstride >> 1;
-  for (int k = t.rank; k < 9; k += t.size) acc[k] = 0;
-  t.sync();
+  long long tot8[8];
+  typedef typename SsdT<PIX>::type sum_t;   // 32-bit sums for 8-bit samples (at most 4096 x 255^2 per sum), 64-bit otherwise
+  long long sq;
   {
-    unsigned long long local = 0;
+    sum_t local = 0;
     for (int k = t.rank; k < n * n; k += t.size) {
       int i, j;
       split2(mk_pow2(n), k, i, j);
       int d = (int)ry[i * stride + j] - (int)y[i * n + j];
-      local += (unsigned long long)(d * d);
+      local += (sum_t)(d * d);
     }
-    local = team_sum64(t, local);
-    if (t.rank == 0) acc[0] += local;
+    sq = (long long)ssd_total(t, local);
   }
-  t.sync();
-  long long sq = (long long)acc[0];
   if ((sq >> (2 * ilog2(n))) <= (64ll << (2 * (bitdepth - 8)))) { t.sync(); return; }
   {
-    unsigned long long ls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    sum_t ls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = t.rank; k < nc * nc; k += t.size) {
       int i, j;
       split2(mk_pow2(nc), k, i, j);
@@ -393,15 +392,12 @@ TK_DEVNI void improve_uv(const Team t, WsP<PIX> ws, const PIX* y_, PIX* u_, PIX*
       ls[3] += (unsigned)(ys * ys); ls[4] += (unsigned)(ys * us); ls[5] += (unsigned)(ys * vs);
       ls[6] += (unsigned)(us * us); ls[7] += (unsigned)(vs * vs);
     }
-    for (int q = 0; q < 8; q++) {
-      const unsigned long long tot = team_sum64(t, ls[q]);
-      if (t.rank == 0) acc[1 + q] += tot;
-    }
+    for (int q = 0; q < 8; q++) ls[q] = (sum_t)ssd_total(t, ls[q]);
+    tot8[0] = (long long)ls[0]; tot8[1] = (long long)ls[1]; tot8[2] = (long long)ls[2]; tot8[3] = (long long)ls[3];
+    tot8[4] = (long long)ls[4]; tot8[5] = (long long)ls[5]; tot8[6] = (long long)ls[6]; tot8[7] = (long long)ls[7];
   }
-  t.sync();
-  const long long ysum = acc[1], usum = acc[2], vsum = acc[3], yysum = acc[4], yusum = acc[5],
-                  yvsum = acc[6], uusum = acc[7], vvsum = acc[8];
-  t.sync();
+  const long long ysum = tot8[0], usum = tot8[1], vsum = tot8[2], yysum = tot8[3], yusum = tot8[4],
+                  yvsum = tot8[5], uusum = tot8[6], vvsum = tot8[7];
   const long long ssyy = yysum - ((ysum * ysum) >> (lognc * 2));
   const long long ssuu = uusum - ((usum * usum) >> (lognc * 2));
   const long long ssvv = vvsum - ((vsum * vsum) >> (lognc * 2));
@@ -498,14 +494,8 @@ template <typename PIX, int SP>
 TK_DEV int prune_after_quadrant(const Team t, JobR<PIX> J, WsP<PIX> ws, int nd_size, int intra, int tu, int i, int j,
                                 int s2, int bit, const int16_t* coef, PruneCtx* pc) {
   if (!prune_active(pc)) return 0;
-  const auto acc = ldsc(ws->acc);
   t.sync();
-  if (t.rank == 0) acc[1] = 0;
-  t.sync();
-  ssd_acc<SP>(t, &ws->acc[1], ws->org_y + i * ws->org_sy + j, ws->org_sy, ws->rec_y + i * nd_size + j, nd_size, s2, s2);
-  t.sync();
-  pc->ssd_part += (long long)acc[1];
-  t.sync();
+  pc->ssd_part += (long long)ssd_total(t, ssd_part<SP>(t, ws->org_y + i * ws->org_sy + j, ws->org_sy, ws->rec_y + i * nd_size + j, nd_size, s2, s2));
   pc->ybits[tu] = bit ? coeff_bits_team<SP_LDS>(t, coef, s2, intra << 1) : 0;  // luma coefficients: always SmallWs (LDS)
   pc->bits_part += pc->ybits[tu];
   if (tu == 3) { pc->ssd_y = pc->ssd_part; pc->have_ybits = 1; }
@@ -524,14 +514,8 @@ TK_DEV int prune_after_luma(const Team t, JobR<PIX> J, WsP<PIX> ws, int size, in
   if (!prune_active(pc)) return 0;
   if (pc->pruned) return 1;
   if (pc->have_ybits) return 0;  // tb-split luma: bound already evaluated quadrant by quadrant
-  const auto acc = ldsc(ws->acc);
   t.sync();
-  if (t.rank == 0) acc[1] = 0;
-  t.sync();
-  ssd_acc<SP>(t, &ws->acc[1], ws->org_y, ws->org_sy, ws->rec_y, size, bw, bh);
-  t.sync();
-  const unsigned long long ssd = acc[1];
-  t.sync();
+  const unsigned long long ssd = ssd_total(t, ssd_part<SP>(t, ws->org_y, ws->org_sy, ws->rec_y, size, bw, bh));
   pc->ssd_y = (long long)ssd;
   const int coeff_type = (p.mode == M_INTRA) << 1;
   int bits = 0;
@@ -1497,7 +1481,6 @@ TK_DEV int early_skip_sub(const Team t, JobR<PIX> J, WsP<PIX> ws, const PIX* org
   const auto pred = spc<SP>(pred_);
   const auto xin = ldsc(ws->xfp->in);
   const auto xcoef = ldsc(ws->xfp->coef);
-  const auto xflag = ldsc(&ws->xfp->flag);
   // luma: 2x2 average + (N/2) transform (size > 4 always here), threshold 0.5*thr
   const int bd = J.cfg.bitdepth;
   const int s2 = size / 2;
@@ -1516,16 +1499,12 @@ TK_DEV int early_skip_sub(const Team t, JobR<PIX> J, WsP<PIX> ws, const PIX* org
   const double fql = (double)(1 << shift2) / (double)quant_scale(qp % 6);
   const double rel = 0.5 * thr;  // float -> double promotion as in the reference
   const int threshold = (int)(rel * fql);
-  if (t.rank == 0) *xflag = 0;
-  t.sync();
   int f = 0;
   for (int k = t.rank; k < s2 * s2; k += t.size)
     if (iabs((int)xcoef[k]) > threshold) f = 1;
-  if (f) team_or((unsigned*)&ws->xfp->flag, 1u);
+  const int r = team_ballot(t, f) != 0ull;   // any lane: no LDS flag round trip
   t.sync();
-  int r = *xflag;
-  t.sync();
-  return r != 0;
+  return r;
 }
 
 template <typename PIX, int SP>
@@ -1533,12 +1512,9 @@ TK_DEV int early_skip_subC(const Team t, JobR<PIX> J, WsP<PIX> ws, const PIX* or
                            const PIX* pred_, int pstride, int size, int qp, float thr) {
   const auto org = spc<SP>(org_);
   const auto pred = spc<SP>(pred_);
-  const auto xflag = ldsc(&ws->xfp->flag);
   const int shift2 = 21 - 5 + qp / 6;
   const double fql = (double)(1 << shift2) / (double)quant_scale(qp % 6);
   const int threshold = ((int)(thr * fql)) << (J.cfg.bitdepth - 8);
-  if (t.rank == 0) *xflag = 0;
-  t.sync();
   // calc_cbp as the reference EXECUTES it, i.e. calc_cbp_simd (enc/enc_kernels.c:827-907, selected at
   // encode_block.c:2225 because use_simd = 1): int16 column sums of the residual; for 16/8 wide
   // blocks |sum| > thr per column; for 4x4 the SIMD code tests (col[2k+1] + |col[2k]|) > thr, which
@@ -1559,11 +1535,9 @@ TK_DEV int early_skip_subC(const Team t, JobR<PIX> J, WsP<PIX> ws, const PIX* or
       if ((int16_t)iabs(sum) > (int16_t)threshold) f = 1;
     }
   }
-  if (f) team_or((unsigned*)&ws->xfp->flag, 1u);
+  const int r = team_ballot(t, f) != 0ull;
   t.sync();
-  int r = *xflag;
-  t.sync();
-  return r != 0;
+  return r;
 }
 
 template <typename PIX, int SP>
