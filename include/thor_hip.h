@@ -125,7 +125,7 @@ void thor_hip_read_prof(thor_hip_encoder* e, long long out[32]);
 /* ---- (3) kernel-level batch entry points (known-answer tests) ------------------------------- */
 /* SAD of `n` candidate positions: org is a compact w x h block (stride w); ref points at the
  * frame sample co-located with the block, stride rstride; cand[2*i],cand[2*i+1] = full-pel (dx,dy).
- * Follows sad_calc (enc/encode_block.c:417-428). out[i] = SAD. */
+ * w, h: powers of two >= 4 (PU sizes).  Follows sad_calc (enc/encode_block.c:417-428). out[i] = SAD. */
 int thor_hip_sad_batch(const uint8_t* org, int w, int h, const uint8_t* ref_plane, int plane_w, int plane_h,
                        int rstride, int bx, int by, const int* cand, int n, uint32_t* out);
 /* Quarter-pel luma prediction (get_inter_prediction_luma, common/inter_prediction.c:117-181) of a
@@ -148,6 +148,17 @@ typedef struct thor_hip_cell {
   uint8_t pad;
 } thor_hip_cell;
 int thor_hip_deblock_frame(uint8_t* yuv, int width, int height, int qp, const thor_hip_cell* cells);
+
+/* The same four entry points on 16-bit samples = the reference's _hbd instances (SAMPLE = uint16_t: enc/enc_kernels_hbd.c,
+ * common/inter_prediction_hbd.c, common/common_block_hbd.c, common/common_frame_hbd.c); bitdepth 9..12, strides and sizes in
+ * samples.  Known answers recorded from those reference functions: tests/golden/kat4.npz (bitdepth 10). */
+int thor_hip_sad_batch_hbd(const uint16_t* org, int w, int h, const uint16_t* ref_plane, int plane_w, int plane_h,
+                           int rstride, int bx, int by, const int* cand, int n, uint32_t* out);
+int thor_hip_interp_luma_hbd(const uint16_t* ref_plane, int plane_w, int plane_h, int rstride, int pad, int bx, int by,
+                             int w, int h, const int16_t* mv, int n, int bipred, int bitdepth, uint16_t* out);
+int thor_hip_code_tu_batch_hbd(const uint16_t* org, const uint16_t* pred, int size, int qp, int coeff_type, int fast, int n,
+                               int bitdepth, int16_t* coefq, uint16_t* rec, int* cbp);
+int thor_hip_deblock_frame_hbd(uint16_t* yuv, int width, int height, int qp, int bitdepth, const thor_hip_cell* cells);
 
 #ifdef __cplusplus
 }

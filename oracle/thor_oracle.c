@@ -9,7 +9,7 @@
  * by the generators and must agree), and, when /root/reference is present, against the live reference.
  * The frame-level oracle is the reference encoder itself (oracle/_ref/Thorenc).
  *
- * 8-bit samples, 4:2:0.  Build: gcc -O2 -std=c99 -fPIC -shared -ffp-contract=off
+ * 8-bit samples (and the 16-bit twins of the SAD / interpolation / transform-unit functions), 4:2:0.  Build: gcc -O2 -std=c99 -fPIC -shared -ffp-contract=off
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -210,6 +210,66 @@ int orc_code_tu(const uint8_t* org, const uint8_t* pred, int size, int qp, int c
     for (int i = 0; i < n2; i++) rec[i] = (uint8_t)clampi(rb[i] + pred[i], 0, 255);
   } else
     memcpy(rec, pred, n2);
+  free(res);
+  free(rb);
+  return cbp;
+}
+
+/* ---- 16-bit samples (the reference's _hbd instances: SAMPLE = uint16_t, the same source compiled a second time,
+ *      enc/encode_block_hbd.c / common/inter_prediction_hbd.c ...).  Pinned by tests/golden/kat4.npz (bitdepth 10). ---- */
+unsigned orc_sad16(const uint16_t* a, int astride, const uint16_t* b, int bstride, int w, int h) {
+  unsigned s = 0;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) s += (unsigned)abs((int)a[y * astride + x] - (int)b[y * bstride + x]);
+  return s;
+}
+void orc_interp_luma16(uint16_t* dst, int dstride, const uint16_t* ref, int rstride, int w, int h, int mvx, int mvy, int sign,
+                       int bipred, int pic_w, int pic_h, int xpos, int ypos, int bitdepth) {
+  const int maxv = (1 << bitdepth) - 1;
+  if (sign) { mvx = -mvx; mvy = -mvy; }
+  int fy = mvy & 3, fx = mvx & 3, iy = mvy >> 2, ix = mvx >> 2;
+  if (iy > pic_h - ypos) iy = pic_h - ypos;
+  if (iy < -xpos - h) iy = -xpos - h; /* sic: xpos, inter_prediction.c:129 */
+  if (ix > pic_w - xpos) ix = pic_w - xpos;
+  if (ix < -xpos - w) ix = -xpos - w;
+  const int(*T)[6] = bipred ? TAPS_BI : TAPS_STD;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      const uint16_t* p = ref + (y + iy) * rstride + x + ix;
+      int v;
+      if (!fx && !fy) v = p[0];
+      else if (fx == 2 && fy == 2 && bipred < 2) {
+        int s = p[-rstride] + p[-rstride + 1] + p[-1] + 2 * p[0] + 2 * p[1] + p[2] + p[rstride - 1] + 2 * p[rstride] +
+                2 * p[rstride + 1] + p[rstride + 2] + p[2 * rstride] + p[2 * rstride + 1];
+        v = clampi((s + 8) >> 4, 0, maxv);
+      } else {
+        int acc = 0;
+        for (int n = 0; n < 6; n++) {
+          int col = 0;
+          for (int m = 0; m < 6; m++) col += T[fy][m] * p[(m - 2) * rstride + n - 2];
+          acc += T[fx][n] * col;
+        }
+        v = clampi((acc + 2048) >> 12, 0, maxv);
+      }
+      dst[y * dstride + x] = (uint16_t)v;
+    }
+}
+int orc_code_tu16(const uint16_t* org, const uint16_t* pred, int size, int qp, int coeff_type, int fast, int16_t* coefq, uint16_t* rec,
+                  int bitdepth) {
+  int n2 = size * size;
+  const int maxv = (1 << bitdepth) - 1;
+  int16_t* res = (int16_t*)malloc(sizeof(int16_t) * n2);
+  int16_t* rb = (int16_t*)malloc(sizeof(int16_t) * n2);
+  int16_t co[256], rc[256];
+  for (int i = 0; i < n2; i++) res[i] = (int16_t)((int)org[i] - (int)pred[i]);
+  orc_fwd_transform(res, co, size, fast, bitdepth);
+  int cbp = orc_quantize(co, coefq, qp, size, (coeff_type >> 1) & 1);
+  if (cbp) {
+    orc_dequantize(coefq, rc, qp, size);
+    orc_inv_transform(rc, rb, size, bitdepth);
+    for (int i = 0; i < n2; i++) rec[i] = (uint16_t)clampi(rb[i] + pred[i], 0, maxv);
+  } else
+    memcpy(rec, pred, sizeof(uint16_t) * n2);
   free(res);
   free(rb);
   return cbp;

@@ -95,3 +95,47 @@ def test_clpf_sample_and_block_statistics():
         s = (C.c_int * 4)(0, 0, 0, 0)
         O.orc_detect_multi_clpf(vp(rec), vp(org), int(x0), int(y0), W, H, W, W, s, 0, 8, int(dmp))
         assert list(s) == [int(v) for v in want], (int(x0), int(y0), int(dmp))
+
+
+# ---- 16-bit samples: the same restatement against vectors recorded from the reference's _hbd functions (kat4.npz) ----
+K4 = np.load(os.path.join(GOLD, 'kat4.npz'))
+
+
+def test_sad_16bit():
+    plane = np.ascontiguousarray(K4['sad_plane'])
+    for i in range(6):
+        org, cand, want = np.ascontiguousarray(K4[f'sad_org{i}']), K4[f'sad_cand{i}'], K4[f'sad_out{i}']
+        h, w = org.shape
+        got = [O.orc_sad16(vp(org), w, C.c_void_p(int(plane.ctypes.data) + 2 * ((12 + int(dy)) * 96 + 12 + int(dx))), 96, w, h) for dx, dy in cand]
+        assert (np.array(got, dtype=np.uint32) == want).all()
+
+
+def test_interp_luma_16bit():
+    ref = np.ascontiguousarray(K4['ip_ref'])
+    pad, pw, ph = 16, 64, 48
+    k = 0
+    while f'ip_geo{k}' in K4:
+        w, h, bx, by, bip = [int(v) for v in K4[f'ip_geo{k}']]
+        for i, (mx, my) in enumerate(K4[f'ip_mv{k}']):
+            out = np.zeros((h, w), dtype=np.uint16)
+            base = int(ref.ctypes.data) + 2 * ((pad + by) * ref.shape[1] + pad + bx)
+            O.orc_interp_luma16(vp(out), w, C.c_void_p(base), ref.shape[1], w, h, int(mx), int(my), 0, bip, pw, ph, bx, by, 10)
+            assert (out == K4[f'ip_out{k}'][i]).all(), (k, i)
+        k += 1
+    assert k == 8
+
+
+def test_tu_pipeline_16bit():
+    k = 0
+    while f'tu_par{k}' in K4:
+        size, qp, ctype, fast = [int(v) for v in K4[f'tu_par{k}']]
+        org, pred = K4[f'tu_org{k}'], K4[f'tu_pred{k}']
+        q = min(size, 16)
+        for i in range(org.shape[0]):
+            cq = np.zeros((q, q), dtype=np.int16); rec = np.zeros((size, size), dtype=np.uint16)
+            cbp = O.orc_code_tu16(vp(np.ascontiguousarray(org[i])), vp(np.ascontiguousarray(pred[i])), size, qp, ctype, fast, vp(cq), vp(rec), 10)
+            assert cbp == K4[f'tu_cbp{k}'][i]
+            assert (cq == K4[f'tu_coefq{k}'][i]).all(), ('coefq', k, i)
+            assert (rec == K4[f'tu_rec{k}'][i]).all(), ('rec', k, i)
+        k += 1
+    assert k == 24

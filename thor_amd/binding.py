@@ -73,6 +73,7 @@ def lib():
         L.thor_hip_kernel_time_reset.argtypes = [C.c_void_p]
         L.thor_hip_read_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
         L.thor_hip_deblock_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.thor_hip_deblock_frame_hbd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.thor_hip_params_from_config.argtypes = [C.POINTER(ThorParams), C.c_char_p]
         L.thor_hip_params_set.argtypes = [C.POINTER(ThorParams), C.c_char_p, C.c_char_p]
         _LIB = L
@@ -199,44 +200,63 @@ def _vp(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def sad_batch(org, ref_plane, bx, by, cand):
-    org = np.ascontiguousarray(org, dtype=np.uint8); ref_plane = np.ascontiguousarray(ref_plane, dtype=np.uint8)
+def _pix(bitdepth):
+    return np.uint16 if bitdepth > 8 else np.uint8
+
+
+def sad_batch(org, ref_plane, bx, by, cand, bitdepth=8):
+    """SADs of the candidates (thor_hip_sad_batch; bitdepth > 8: thor_hip_sad_batch_hbd on uint16 samples)."""
+    T = _pix(bitdepth)
+    org = np.ascontiguousarray(org, dtype=T); ref_plane = np.ascontiguousarray(ref_plane, dtype=T)
     cand = np.ascontiguousarray(cand, dtype=np.int32)
     out = np.zeros(len(cand), dtype=np.uint32)
-    rc = lib().thor_hip_sad_batch(_vp(org), org.shape[1], org.shape[0], _vp(ref_plane), ref_plane.shape[1], ref_plane.shape[0],
-                                  ref_plane.shape[1], bx, by, _vp(cand), len(cand), _vp(out))
+    fn = lib().thor_hip_sad_batch_hbd if bitdepth > 8 else lib().thor_hip_sad_batch
+    rc = fn(_vp(org), org.shape[1], org.shape[0], _vp(ref_plane), ref_plane.shape[1], ref_plane.shape[0], ref_plane.shape[1], bx, by,
+            _vp(cand), len(cand), _vp(out))
     if rc:
         raise RuntimeError(f'thor_hip_sad_batch rc={rc}')
     return out
 
 
-def interp_luma(ref_padded, pad, pic_w, pic_h, bx, by, w, h, mvs, bipred):
-    ref_padded = np.ascontiguousarray(ref_padded, dtype=np.uint8); mvs = np.ascontiguousarray(mvs, dtype=np.int16)
-    out = np.zeros((len(mvs), h, w), dtype=np.uint8)
-    rc = lib().thor_hip_interp_luma(_vp(ref_padded), pic_w, pic_h, ref_padded.shape[1], pad, bx, by, w, h, _vp(mvs), len(mvs),
-                                    bipred, _vp(out))
+def interp_luma(ref_padded, pad, pic_w, pic_h, bx, by, w, h, mvs, bipred, bitdepth=8):
+    T = _pix(bitdepth)
+    ref_padded = np.ascontiguousarray(ref_padded, dtype=T); mvs = np.ascontiguousarray(mvs, dtype=np.int16)
+    out = np.zeros((len(mvs), h, w), dtype=T)
+    if bitdepth > 8:
+        rc = lib().thor_hip_interp_luma_hbd(_vp(ref_padded), pic_w, pic_h, ref_padded.shape[1], pad, bx, by, w, h, _vp(mvs), len(mvs),
+                                            bipred, bitdepth, _vp(out))
+    else:
+        rc = lib().thor_hip_interp_luma(_vp(ref_padded), pic_w, pic_h, ref_padded.shape[1], pad, bx, by, w, h, _vp(mvs), len(mvs),
+                                        bipred, _vp(out))
     if rc:
         raise RuntimeError(f'thor_hip_interp_luma rc={rc}')
     return out
 
 
-def code_tu_batch(org, pred, qp, coeff_type, fast):
-    org = np.ascontiguousarray(org, dtype=np.uint8); pred = np.ascontiguousarray(pred, dtype=np.uint8)
+def code_tu_batch(org, pred, qp, coeff_type, fast, bitdepth=8):
+    T = _pix(bitdepth)
+    org = np.ascontiguousarray(org, dtype=T); pred = np.ascontiguousarray(pred, dtype=T)
     n, size = org.shape[0], org.shape[1]
     q = min(size, 16)
     coefq = np.zeros((n, q, q), dtype=np.int16); rec = np.zeros_like(org); cbp = np.zeros(n, dtype=np.int32)
-    rc = lib().thor_hip_code_tu_batch(_vp(org), _vp(pred), size, qp, coeff_type, fast, n, _vp(coefq), _vp(rec), _vp(cbp))
+    if bitdepth > 8:
+        rc = lib().thor_hip_code_tu_batch_hbd(_vp(org), _vp(pred), size, qp, coeff_type, fast, n, bitdepth, _vp(coefq), _vp(rec), _vp(cbp))
+    else:
+        rc = lib().thor_hip_code_tu_batch(_vp(org), _vp(pred), size, qp, coeff_type, fast, n, _vp(coefq), _vp(rec), _vp(cbp))
     if rc:
         raise RuntimeError(f'thor_hip_code_tu_batch rc={rc}')
     return coefq, rec, cbp
 
 
-def deblock_frame(yuv, width, height, qp, cells):
-    """In-loop deblocking of one 8-bit planar frame (thor_hip_deblock_frame); cells: (h/4, w/4, 16) uint8 records."""
-    yuv = np.ascontiguousarray(yuv, dtype=np.uint8).copy()
+def deblock_frame(yuv, width, height, qp, cells, bitdepth=8):
+    """In-loop deblocking of one planar 4:2:0 frame (thor_hip_deblock_frame / _hbd); cells: (h/4, w/4, 16) uint8 records."""
+    yuv = np.ascontiguousarray(yuv, dtype=_pix(bitdepth)).copy()
     cells = np.ascontiguousarray(cells, dtype=np.uint8)
     assert yuv.size == width * height * 3 // 2 and cells.size == (width // 4) * (height // 4) * 16
-    rc = lib().thor_hip_deblock_frame(_vp(yuv), width, height, qp, _vp(cells))
+    if bitdepth > 8:
+        rc = lib().thor_hip_deblock_frame_hbd(_vp(yuv), width, height, qp, bitdepth, _vp(cells))
+    else:
+        rc = lib().thor_hip_deblock_frame(_vp(yuv), width, height, qp, _vp(cells))
     if rc:
         raise RuntimeError(f'thor_hip_deblock_frame rc={rc}')
     return yuv

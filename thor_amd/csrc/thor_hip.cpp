@@ -988,11 +988,14 @@ extern "C" void encode_frame_hbd(struct thor_encoder_info* ei) { encode_frame_im
 // C ABI - kernel-level batch entry points (known-answer tests)
 // ---------------------------------------------------------------------------------------------
 namespace tk {
-__global__ __launch_bounds__(64) void k_kat_sad(const uint8_t* org, int w, int h, const uint8_t* refp, int rstride, int bx,
-                                               int by, const int* cand, int n, uint32_t* out) {
+// The kernels behind the known-answer entry points run the product's device code on one block / transform unit per workgroup of
+// one wavefront; PIX = uint8_t (the reference's _lbd functions) or uint16_t (_hbd, bitdepth 9..12).
+template <typename PIX>
+__global__ __launch_bounds__(64) void k_kat_sad(const PIX* org, int w, int h, const PIX* refp, int rstride, int bx, int by, const int* cand, int n,
+                                               uint32_t* out) {
   // the product's full-pel evaluator (tk_me.h:seg_sads, row segment per lane), plane reads only (no search window)
   const Team t = mk_team((int)threadIdx.x, 64);
-  struct KC { const uint8_t* p; int dx, dy; };
+  struct KC { const PIX* p; int dx, dy; };
   MeWin win;
   win.on = 0; win.w32 = nullptr; win.ox = win.oy = win.Ww = win.Wh = win.pitch = 0;
   auto cnd = [&](int c) -> KC {
@@ -1003,15 +1006,17 @@ __global__ __launch_bounds__(64) void k_kat_sad(const uint8_t* org, int w, int h
   };
   seg_sads<SP_GLOBAL>(t, n, org, w, rstride, w, h, win, cnd, [&](int c, const KC&, int sad, int mine) { if (mine) out[c] = (uint32_t)sad; });
 }
-__global__ __launch_bounds__(64) void k_kat_interp(const uint8_t* ref0, int rstride, int pic_w, int pic_h, int bx, int by, int w,
-                                                  int h, const int16_t* mv, int bipred, uint8_t* out) {
+template <typename PIX>
+__global__ __launch_bounds__(64) void k_kat_interp(const PIX* ref0, int rstride, int pic_w, int pic_h, int bx, int by, int w, int h,
+                                                  const int16_t* mv, int bipred, int bitdepth, PIX* out) {
   const Team t = mk_team((int)threadIdx.x, 64);
   const int i = blockIdx.x;
   pred_luma<SP_GLOBAL>(t, out + (size_t)i * w * h, w, ref0 + (size_t)by * rstride + bx, rstride, w, h, mk_mv(mv[2 * i], mv[2 * i + 1]), 0,
-            bipred, pic_w, pic_h, bx, by, 8);
+            bipred, pic_w, pic_h, bx, by, bitdepth);
 }
-__global__ __launch_bounds__(64) void k_kat_tu(const uint8_t* org, const uint8_t* pred, int size, int qp, int coeff_type, int fast,
-                                              int16_t* coefq, uint8_t* rec, int* cbp) {
+template <typename PIX>
+__global__ __launch_bounds__(64) void k_kat_tu(const PIX* org, const PIX* pred, int size, int qp, int coeff_type, int fast, int bitdepth,
+                                              int16_t* coefq, PIX* rec, int* cbp) {
   __shared__ XformWs xf;
   __shared__ XformTabs tabs;
   __shared__ int16_t cq[256];
@@ -1022,7 +1027,7 @@ __global__ __launch_bounds__(64) void k_kat_tu(const uint8_t* org, const uint8_t
   t.sync();
   const int i = blockIdx.x, qs = size < 16 ? size : 16;
   const size_t o = (size_t)i * size * size;
-  int c = code_tu(t, &xf, org + o, size, pred + o, size, rec + o, size, size, qp, coeff_type, fast, cq, 8);
+  int c = code_tu(t, &xf, org + o, size, pred + o, size, rec + o, size, size, qp, coeff_type, fast, cq, bitdepth);
   for (int k = threadIdx.x; k < qs * qs; k += 64) coefq[(size_t)i * qs * qs + k] = cq[k];
   if (threadIdx.x == 0) cbp[i] = c;
 }
@@ -1034,86 +1039,123 @@ template <typename T> static T* to_dev(const T* h, size_t n) {
   return d;
 }
 
-extern "C" int thor_hip_sad_batch(const uint8_t* org, int w, int h, const uint8_t* ref_plane, int plane_w, int plane_h, int rstride,
-                                  int bx, int by, const int* cand, int n, uint32_t* out) {
-  if (!org || !ref_plane || !cand || !out || n <= 0 || (w & 3)) return 1;
+template <typename PIX>
+static int kat_sad_batch(const PIX* org, int w, int h, const PIX* ref_plane, int plane_w, int plane_h, int rstride, int bx, int by, const int* cand,
+                         int n, uint32_t* out) {
+  if (!org || !ref_plane || !cand || !out || n <= 0 || w < 4 || h < 4 || (w & (w - 1)) || (h & (h - 1))) return 1;
   for (int i = 0; i < n; i++) {
     int x = bx + cand[2 * i], y = by + cand[2 * i + 1];
     if (x < 0 || y < 0 || x + w > plane_w || y + h > plane_h) return 2;
   }
   if (!ensure_init(g_inited ? g_device : 0)) return 3;
-  uint8_t* d_org = to_dev(org, (size_t)w * h);
-  uint8_t* d_ref = to_dev(ref_plane, (size_t)rstride * plane_h);
+  PIX* d_org = to_dev(org, (size_t)w * h);
+  PIX* d_ref = to_dev(ref_plane, (size_t)rstride * plane_h + 16);   // the evaluator reads whole 16-byte row segments
   int* d_c = to_dev(cand, (size_t)2 * n);
   uint32_t* d_o = to_dev<uint32_t>(nullptr, n);
-  hipLaunchKernelGGL(k_kat_sad, dim3(1), dim3(64), 0, g_stream, d_org, w, h, d_ref, rstride, bx, by, d_c, n, d_o);
+  hipLaunchKernelGGL(k_kat_sad<PIX>, dim3(1), dim3(64), 0, g_stream, d_org, w, h, d_ref, rstride, bx, by, d_c, n, d_o);
   HIPCHECK(hipGetLastError());
   backend::d2h(out, d_o, (size_t)n * 4);
   backend::dev_free(d_org); backend::dev_free(d_ref); backend::dev_free(d_c); backend::dev_free(d_o);
   return 0;
 }
+extern "C" int thor_hip_sad_batch(const uint8_t* org, int w, int h, const uint8_t* ref_plane, int plane_w, int plane_h, int rstride,
+                                  int bx, int by, const int* cand, int n, uint32_t* out) {
+  return kat_sad_batch<uint8_t>(org, w, h, ref_plane, plane_w, plane_h, rstride, bx, by, cand, n, out);
+}
+extern "C" int thor_hip_sad_batch_hbd(const uint16_t* org, int w, int h, const uint16_t* ref_plane, int plane_w, int plane_h, int rstride,
+                                      int bx, int by, const int* cand, int n, uint32_t* out) {
+  return kat_sad_batch<uint16_t>(org, w, h, ref_plane, plane_w, plane_h, rstride, bx, by, cand, n, out);
+}
 
-extern "C" int thor_hip_interp_luma(const uint8_t* ref_plane, int plane_w, int plane_h, int rstride, int pad, int bx, int by, int w,
-                                    int h, const int16_t* mv, int n, int bipred, uint8_t* out) {
+template <typename PIX>
+static int kat_interp_luma(const PIX* ref_plane, int plane_w, int plane_h, int rstride, int pad, int bx, int by, int w, int h, const int16_t* mv,
+                           int n, int bipred, int bitdepth, PIX* out) {
   if (!ref_plane || !mv || !out || n <= 0) return 1;
   if (!ensure_init(g_inited ? g_device : 0)) return 3;
   const size_t total = (size_t)rstride * (plane_h + 2 * pad);
-  uint8_t* d_ref = to_dev(ref_plane, total);
+  PIX* d_ref = to_dev(ref_plane, total);
   int16_t* d_mv = to_dev(mv, (size_t)2 * n);
-  uint8_t* d_o = to_dev<uint8_t>(nullptr, (size_t)n * w * h);
-  hipLaunchKernelGGL(k_kat_interp, dim3(n), dim3(64), 0, g_stream, d_ref + (size_t)pad * rstride + pad, rstride, plane_w, plane_h, bx,
-                     by, w, h, d_mv, bipred, d_o);
+  PIX* d_o = to_dev<PIX>(nullptr, (size_t)n * w * h);
+  hipLaunchKernelGGL(k_kat_interp<PIX>, dim3(n), dim3(64), 0, g_stream, d_ref + (size_t)pad * rstride + pad, rstride, plane_w, plane_h, bx,
+                     by, w, h, d_mv, bipred, bitdepth, d_o);
   HIPCHECK(hipGetLastError());
-  backend::d2h(out, d_o, (size_t)n * w * h);
+  backend::d2h(out, d_o, (size_t)n * w * h * sizeof(PIX));
   backend::dev_free(d_ref); backend::dev_free(d_mv); backend::dev_free(d_o);
   return 0;
 }
+extern "C" int thor_hip_interp_luma(const uint8_t* ref_plane, int plane_w, int plane_h, int rstride, int pad, int bx, int by, int w,
+                                    int h, const int16_t* mv, int n, int bipred, uint8_t* out) {
+  return kat_interp_luma<uint8_t>(ref_plane, plane_w, plane_h, rstride, pad, bx, by, w, h, mv, n, bipred, 8, out);
+}
+extern "C" int thor_hip_interp_luma_hbd(const uint16_t* ref_plane, int plane_w, int plane_h, int rstride, int pad, int bx, int by, int w,
+                                        int h, const int16_t* mv, int n, int bipred, int bitdepth, uint16_t* out) {
+  if (bitdepth < 9 || bitdepth > 12) return 1;
+  return kat_interp_luma<uint16_t>(ref_plane, plane_w, plane_h, rstride, pad, bx, by, w, h, mv, n, bipred, bitdepth, out);
+}
 
-extern "C" int thor_hip_code_tu_batch(const uint8_t* org, const uint8_t* pred, int size, int qp, int coeff_type, int fast, int n,
-                                      int16_t* coefq, uint8_t* rec, int* cbp) {
+template <typename PIX>
+static int kat_code_tu_batch(const PIX* org, const PIX* pred, int size, int qp, int coeff_type, int fast, int n, int bitdepth, int16_t* coefq,
+                             PIX* rec, int* cbp) {
   if (!org || !pred || !coefq || !rec || !cbp || n <= 0) return 1;
   if (size != 4 && size != 8 && size != 16 && size != 32 && size != 64 && size != 128) return 2;
   if (!ensure_init(g_inited ? g_device : 0)) return 3;
   const size_t px = (size_t)n * size * size;
   const int qs = size < 16 ? size : 16;
-  uint8_t* d_org = to_dev(org, px);
-  uint8_t* d_pred = to_dev(pred, px);
-  uint8_t* d_rec = to_dev<uint8_t>(nullptr, px);
+  PIX* d_org = to_dev(org, px);
+  PIX* d_pred = to_dev(pred, px);
+  PIX* d_rec = to_dev<PIX>(nullptr, px);
   int16_t* d_cq = to_dev<int16_t>(nullptr, (size_t)n * qs * qs);
   int* d_cbp = to_dev<int>(nullptr, n);
-  hipLaunchKernelGGL(k_kat_tu, dim3(n), dim3(64), 0, g_stream, d_org, d_pred, size, qp, coeff_type, fast, d_cq, d_rec, d_cbp);
+  hipLaunchKernelGGL(k_kat_tu<PIX>, dim3(n), dim3(64), 0, g_stream, d_org, d_pred, size, qp, coeff_type, fast, bitdepth, d_cq, d_rec, d_cbp);
   HIPCHECK(hipGetLastError());
   backend::d2h(coefq, d_cq, (size_t)n * qs * qs * 2);
-  backend::d2h(rec, d_rec, px);
+  backend::d2h(rec, d_rec, px * sizeof(PIX));
   backend::d2h(cbp, d_cbp, (size_t)n * 4);
   backend::dev_free(d_org); backend::dev_free(d_pred); backend::dev_free(d_rec); backend::dev_free(d_cq); backend::dev_free(d_cbp);
   return 0;
 }
+extern "C" int thor_hip_code_tu_batch(const uint8_t* org, const uint8_t* pred, int size, int qp, int coeff_type, int fast, int n,
+                                      int16_t* coefq, uint8_t* rec, int* cbp) {
+  return kat_code_tu_batch<uint8_t>(org, pred, size, qp, coeff_type, fast, n, 8, coefq, rec, cbp);
+}
+extern "C" int thor_hip_code_tu_batch_hbd(const uint16_t* org, const uint16_t* pred, int size, int qp, int coeff_type, int fast, int n,
+                                          int bitdepth, int16_t* coefq, uint16_t* rec, int* cbp) {
+  if (bitdepth < 9 || bitdepth > 12) return 1;
+  return kat_code_tu_batch<uint16_t>(org, pred, size, qp, coeff_type, fast, n, bitdepth, coefq, rec, cbp);
+}
 
-extern "C" int thor_hip_deblock_frame(uint8_t* yuv, int width, int height, int qp, const thor_hip_cell* cells) {
+template <typename PIX> static int kat_deblock_frame(PIX* yuv, int width, int height, int qp, int bitdepth, const thor_hip_cell* cells) {
   static_assert(sizeof(thor_hip_cell) == sizeof(DbCell), "thor_hip_cell must mirror tk::DbCell");
   if (!yuv || !cells || width % 8 || height % 8 || width < 16 || height < 16 || qp < 0 || qp > 51) return 1;
   if (!ensure_init(g_inited ? g_device : 0)) return 3;
-  DevFrame<uint8_t> f;
+  DevFrame<PIX> f;
   f.alloc(width, height, 0);
   const size_t ncell = (size_t)(width / 4) * (height / 4);
   DbCell* d_cells = to_dev((const DbCell*)cells, ncell);
-  HIPCHECK(hipMemcpy2D(f.p.y, f.p.sy, yuv, width, width, height, hipMemcpyHostToDevice));
-  const uint8_t* hu = yuv + (size_t)width * height;
-  const uint8_t* hv = hu + (size_t)(width / 2) * (height / 2);
-  HIPCHECK(hipMemcpy2D(f.p.u, f.p.sc, hu, width / 2, width / 2, height / 2, hipMemcpyHostToDevice));
-  HIPCHECK(hipMemcpy2D(f.p.v, f.p.sc, hv, width / 2, width / 2, height / 2, hipMemcpyHostToDevice));
-  FrameJob<uint8_t> J;
+  const size_t B = sizeof(PIX);
+  HIPCHECK(hipMemcpy2D(f.p.y, f.p.sy * B, yuv, width * B, width * B, height, hipMemcpyHostToDevice));
+  PIX* hu = yuv + (size_t)width * height;
+  PIX* hv = hu + (size_t)(width / 2) * (height / 2);
+  HIPCHECK(hipMemcpy2D(f.p.u, f.p.sc * B, hu, width / 2 * B, width / 2 * B, height / 2, hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy2D(f.p.v, f.p.sc * B, hv, width / 2 * B, width / 2 * B, height / 2, hipMemcpyHostToDevice));
+  FrameJob<PIX> J;
   memset(&J, 0, sizeof(J));
-  J.cfg.width = width; J.cfg.height = height; J.cfg.bitdepth = 8;
+  J.cfg.width = width; J.cfg.height = height; J.cfg.bitdepth = bitdepth;
   J.qp = qp; J.rec = f.p; J.cells = d_cells; J.cell_stride = width / 4;
-  FrameJob<uint8_t>* d_job = to_dev(&J, 1);
-  backend::run_deblock<uint8_t>(d_job, &J, 1);
+  FrameJob<PIX>* d_job = to_dev(&J, 1);
+  backend::run_deblock<PIX>(d_job, &J, 1);
   backend::dev_sync();
-  HIPCHECK(hipMemcpy2D(yuv, width, f.p.y, f.p.sy, width, height, hipMemcpyDeviceToHost));
-  HIPCHECK(hipMemcpy2D((uint8_t*)hu, width / 2, f.p.u, f.p.sc, width / 2, height / 2, hipMemcpyDeviceToHost));
-  HIPCHECK(hipMemcpy2D((uint8_t*)hv, width / 2, f.p.v, f.p.sc, width / 2, height / 2, hipMemcpyDeviceToHost));
+  HIPCHECK(hipMemcpy2D(yuv, width * B, f.p.y, f.p.sy * B, width * B, height, hipMemcpyDeviceToHost));
+  HIPCHECK(hipMemcpy2D(hu, width / 2 * B, f.p.u, f.p.sc * B, width / 2 * B, height / 2, hipMemcpyDeviceToHost));
+  HIPCHECK(hipMemcpy2D(hv, width / 2 * B, f.p.v, f.p.sc * B, width / 2 * B, height / 2, hipMemcpyDeviceToHost));
   backend::dev_free(d_job); backend::dev_free(d_cells);
   f.release();
   return 0;
+}
+extern "C" int thor_hip_deblock_frame(uint8_t* yuv, int width, int height, int qp, const thor_hip_cell* cells) {
+  return kat_deblock_frame<uint8_t>(yuv, width, height, qp, 8, cells);
+}
+extern "C" int thor_hip_deblock_frame_hbd(uint16_t* yuv, int width, int height, int qp, int bitdepth, const thor_hip_cell* cells) {
+  if (bitdepth < 9 || bitdepth > 12) return 1;
+  return kat_deblock_frame<uint16_t>(yuv, width, height, qp, bitdepth, cells);
 }
