@@ -87,6 +87,9 @@ template <typename PIX> struct SmallWs {
   long long prof[1];
 #endif
 };
+// the row-segment loads of the motion search read the LDS sample blocks with 16-byte ds_read
+static_assert(offsetof(SmallWs<uint8_t>, lbuf) % 16 == 0 && offsetof(SmallWs<uint16_t>, lbuf) % 16 == 0 && sizeof(SmallWs<uint8_t>) % 16 == 0 &&
+              sizeof(SmallWs<uint16_t>) % 16 == 0 && offsetof(WgShared, org_raw) % 16 == 0, "LDS sample blocks must be 16-byte aligned");
 template <typename PIX> struct BigWs {
   PIX pred_y[kMaxSb * kMaxSb], pred_u[kMaxSb * kMaxSb / 4], pred_v[kMaxSb * kMaxSb / 4];
   PIX p0_y[kMaxSb * kMaxSb], p0_u[kMaxSb * kMaxSb / 4], p0_v[kMaxSb * kMaxSb / 4];
