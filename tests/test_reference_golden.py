@@ -60,6 +60,18 @@ def test_engine_multi_wave_host_simulation_matches_golden(name):
 
 
 @needs_ref
+def test_sixteen_lane_teams_search_window_and_row_segments_vs_live_reference():
+    """16-lane teams on a 64x64 clip (I + 2 P): with 16 lanes the PUs up to 16x16 take the side-by-side row-segment path of the
+    full-pel evaluator and the LDS search window (candidate sets per lane group, in-window test by ballot, window reads of the
+    sub-pel search), larger PUs the whole-team path - the lane mappings the 8-lane test above does not reach."""
+    from thor_amd import synth
+    clip = b''.join(p.tobytes() for fr in synth.make_clip(64, 64, 3, 11, 4.0) for p in fr)
+    rb, rr = run_encoder(REF_ENC, clip, 64, 64, 3, 32)
+    bits, rec = run_encoder(build_hostsim(lanes=16), clip, 64, 64, 3, 32)
+    assert bits == rb and rec == rr
+
+
+@needs_ref
 def test_multi_wave_host_simulation_416x240_four_references_vs_live_reference():
     """416x240 LDB_high_efficiency, I + 5 P (the last two P frames search 4 references): the regime bench.py times - lock-step
     bi-prediction search over 4 references with skipped repeat steps, duplicate-partition skipping, key-based pruning - in the
