@@ -8,6 +8,7 @@
  *     enc_params       enc/mainenc.h:35-112      ->  thor_enc_params
  *     frame_info_t     enc/mainenc.h:140-156     ->  thor_frame_info     (9040 bytes)
  *     encoder_info_t   enc/mainenc.h:158-184     ->  thor_encoder_info   (16456 bytes)
+ *     deblock_data_t   common/types.h:178-187    ->  thor_deblock_data   (364 bytes; mv_t :132-136, inter_pred_t :138-145, cbp_t :147-152)
  * Only the members this path reads or writes are named individually; the rest are kept as opaque
  * storage of the right size.  tests/test_abi.py compiles a probe against the reference headers
  * (when /root/reference is present) and checks every named offset and every sizeof.
@@ -90,6 +91,21 @@ typedef struct thor_frame_info {
   int max_clpf_strength;
 } thor_frame_info;
 
+/* one entry per 4x4 block of the frame, row-major, (height/4) x (width/4) entries (enc/mainenc.c:208) */
+typedef struct thor_inter_pred {
+  thor_mv mv0, mv1;
+  uint32_t ref_idx0, ref_idx1, bipred_flag;
+} thor_inter_pred;
+typedef struct thor_deblock_data {
+  int mode;                /* block_mode_t: 0 skip, 1 intra, 2 inter, 3 bipred, 4 merge */
+  int cbp_y, cbp_u, cbp_v; /* cbp_t */
+  uint8_t size;
+  uint8_t tb_split;
+  int pb_part;             /* part_t */
+  thor_inter_pred inter_pred;
+  thor_inter_pred inter_pred_arr[16]; /* interp_ref 2 only (not supported by this path): never touched */
+} thor_deblock_data;
+
 typedef struct thor_encoder_info {
   void* block_info;
   thor_frame_info frame_info;
@@ -100,7 +116,7 @@ typedef struct thor_encoder_info {
   thor_yuv_frame* ref[THOR_MAX_REF_FRAMES];
   thor_yuv_frame* interp_frames[THOR_MAX_SKIP_FRAMES];
   thor_stream* stream;
-  void* deblock_data;
+  thor_deblock_data* deblock_data;
   void* rc;
   int width, height, depth;
   void* wmatrix[12][3][2][6];
@@ -117,5 +133,6 @@ typedef struct thor_encoder_info {
 _Static_assert(sizeof(thor_yuv_frame) == 96, "yuv_frame_t layout");
 _Static_assert(sizeof(thor_frame_info) == 9040, "frame_info_t layout");
 _Static_assert(sizeof(thor_encoder_info) == 16456, "encoder_info_t layout");
+_Static_assert(sizeof(thor_deblock_data) == 364, "deblock_data_t layout");
 #endif
 #endif

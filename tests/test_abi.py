@@ -42,7 +42,7 @@ def test_abi_layout_matches_reference_headers():
 #define SZ(rt, mt) if (sizeof(rt) != sizeof(mt)) { printf("size %%s\n", #rt); bad++; }
 int main(void) { int bad = 0;
   SZ(yuv_frame_t, thor_yuv_frame) SZ(stream_t, thor_stream) SZ(enc_params, thor_enc_params) SZ(frame_info_t, thor_frame_info)
-  SZ(encoder_info_t, thor_encoder_info) SZ(stream_pos_t, thor_stream_pos)
+  SZ(encoder_info_t, thor_encoder_info) SZ(stream_pos_t, thor_stream_pos) SZ(deblock_data_t, thor_deblock_data) SZ(inter_pred_t, thor_inter_pred)
   CHK(yuv_frame_t, stride_c, thor_yuv_frame) CHK(yuv_frame_t, frame_num, thor_yuv_frame) CHK(yuv_frame_t, pad_ver_c, thor_yuv_frame)
   CHK(enc_params, early_skip_thr, thor_enc_params) CHK(enc_params, mqpP, thor_enc_params) CHK(enc_params, cdef, thor_enc_params)
   CHK(enc_params, enable_bipred, thor_enc_params) CHK(enc_params, cfl_inter, thor_enc_params) CHK(enc_params, input_bitdepth, thor_enc_params)
@@ -50,6 +50,10 @@ int main(void) { int bad = 0;
   CHK(frame_info_t, num_intra_modes, thor_frame_info) CHK(frame_info_t, frame_num, thor_frame_info) CHK(frame_info_t, prev_qp, thor_frame_info)
   CHK(encoder_info_t, params, thor_encoder_info) CHK(encoder_info_t, orig, thor_encoder_info) CHK(encoder_info_t, ref, thor_encoder_info)
   CHK(encoder_info_t, stream, thor_encoder_info) CHK(encoder_info_t, width, thor_encoder_info) CHK(encoder_info_t, cdef_bits, thor_encoder_info)
+  CHK(encoder_info_t, deblock_data, thor_encoder_info) CHK(deblock_data_t, mode, thor_deblock_data) CHK(deblock_data_t, size, thor_deblock_data)
+  CHK(deblock_data_t, tb_split, thor_deblock_data) CHK(deblock_data_t, pb_part, thor_deblock_data) CHK(deblock_data_t, inter_pred, thor_deblock_data)
+  CHK(deblock_data_t, inter_pred_arr, thor_deblock_data) CHK(inter_pred_t, ref_idx0, thor_inter_pred) CHK(inter_pred_t, bipred_flag, thor_inter_pred)
+  if (offsetof(deblock_data_t, cbp) != offsetof(thor_deblock_data, cbp_y) || offsetof(deblock_data_t, cbp) + offsetof(cbp_t, v) != offsetof(thor_deblock_data, cbp_v)) { printf("offset deblock_data_t.cbp\n"); bad++; }
   return bad; }''' % ROOT
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, 'p.c'), 'w').write(probe)

@@ -959,6 +959,20 @@ template <typename PIX> static void encode_frame_impl(struct thor_encoder_info* 
       memcpy((PIX*)r.v + (size_t)i * r.stride_c, cv + (size_t)i * (w / 2), (w / 2) * sizeof(PIX));
     }
   }
+  // deblock_data[] as copy_deblock_data leaves it (enc/encode_block.c:1568-1613): the device keeps it as 16-byte DbCells
+  if (ei->deblock_data) {
+    std::vector<DbCell> cells(eng.num_cells());
+    eng.download_cells(0, cells.data());
+    for (size_t i = 0; i < cells.size(); i++) {
+      const DdFields c = dd_fields(cells[i]);
+      thor_deblock_data& d = ei->deblock_data[i];
+      d.mode = c.mode; d.cbp_y = c.cbp_y; d.cbp_u = c.cbp_u; d.cbp_v = c.cbp_v;
+      d.size = (uint8_t)c.size; d.tb_split = (uint8_t)c.tb_split; d.pb_part = c.pb_part;
+      d.inter_pred.mv0.x = (int16_t)c.mv0x; d.inter_pred.mv0.y = (int16_t)c.mv0y;
+      d.inter_pred.mv1.x = (int16_t)c.mv1x; d.inter_pred.mv1.y = (int16_t)c.mv1y;
+      d.inter_pred.ref_idx0 = (uint32_t)c.ref_idx0; d.inter_pred.ref_idx1 = (uint32_t)c.ref_idx1; d.inter_pred.bipred_flag = (uint32_t)c.bipred_flag;
+    }
+  }
   // sliding window of the caller's reference pointers + padded copy (enc/encode_frame.c:826-835)
   {
     thor_yuv_frame* last = ei->ref[THOR_MAX_REF_FRAMES - 1];

@@ -169,6 +169,20 @@ template <typename PIX> int cli_run(const CliArgs& a) {
     if (!active) break;
     if (active != a.streams) { fprintf(stderr, "streams out of step\n"); return 4; }
     eng.encode_frames(fp);
+    if (const char* ddp = getenv("THOR_DD_DUMP")) {   // tests: stream 0's block data in the record format of oracle/dd_shim.c
+      std::vector<DbCell> cells(eng.num_cells());
+      eng.download_cells(0, cells.data());
+      FILE* fd = fopen(ddp, "ab");
+      if (!fd) { fprintf(stderr, "cannot open %s\n", ddp); return 5; }
+      const int32_t hdr[3] = {0x44444444, fp[0].frame_num, (int32_t)cells.size()};
+      fwrite(hdr, sizeof hdr, 1, fd);
+      for (const DbCell& c : cells) {
+        const DdFields d = dd_fields(c);
+        const int32_t r[14] = {d.mode, d.cbp_y, d.cbp_u, d.cbp_v, d.size, d.tb_split, d.pb_part, d.mv0x, d.mv0y, d.mv1x, d.mv1y, d.ref_idx0, d.ref_idx1, d.bipred_flag};
+        fwrite(r, sizeof r, 1, fd);
+      }
+      fclose(fd);
+    }
     for (int s = 0; s < a.streams; s++)
       if (fr[s]) {
         eng.download_rec(s, rec.data());

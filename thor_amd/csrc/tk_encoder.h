@@ -346,6 +346,18 @@ template <typename PIX> struct Stream {
   std::vector<uint8_t> out;  // finished stream bytes (4-byte big-endian length + payload per frame)
 };
 
+// The caller-visible fields of the reference's deblock_data_t (common/types.h:178-187) in declaration order, from one DbCell:
+// cbp.y/u/v are 0/1 in the reference too (quantize() returns a flag; transform-split blocks store 1/1/1, encode_block.c:1495-1498).
+struct DdFields { int mode, cbp_y, cbp_u, cbp_v, size, tb_split, pb_part, mv0x, mv0y, mv1x, mv1y, ref_idx0, ref_idx1, bipred_flag; };
+static inline DdFields dd_fields(const DbCell& c) {
+  DdFields d;
+  d.mode = c.mode; d.cbp_y = c.cbp & 1; d.cbp_u = (c.cbp >> 1) & 1; d.cbp_v = (c.cbp >> 2) & 1;
+  d.size = c.size; d.tb_split = c.tbpb & 1; d.pb_part = c.tbpb >> 1;
+  d.mv0x = c.mv0.x; d.mv0y = c.mv0.y; d.mv1x = c.mv1.x; d.mv1y = c.mv1.y;
+  d.ref_idx0 = c.ref0; d.ref_idx1 = c.ref1; d.bipred_flag = c.dir;
+  return d;
+}
+
 template <typename PIX> class Engine {
  public:
   SeqParams sp;
@@ -514,6 +526,11 @@ template <typename PIX> class Engine {
     backend::d2h(tmp.data(), f.p.v, tmp.size() * sizeof(PIX));
     for (int i = 0; i < h / 2; i++) memcpy(cv + (size_t)i * (w / 2), &tmp[(size_t)i * f.p.sc], (w / 2) * sizeof(PIX));
   }
+
+  // The frame's per-4x4 block data (DbCell, tk_common.h) as the block decisions and the in-loop filters left it: what the
+  // reference keeps in encoder_info->deblock_data[] (written by copy_deblock_data, enc/encode_block.c:1568-1613).
+  size_t num_cells() const { return (size_t)(sp.width / 4) * (sp.height / 4); }
+  void download_cells(int s, DbCell* out) { backend::d2h(out, st[s].cells, num_cells() * sizeof(DbCell)); }
 
   // Coding-order schedule.  begin_sequence fixes the chunk [skip, skip+num_frames) of an input holding
   // file_frames frames (needed for the reference's end-of-sequence behaviour with reordered GOPs).
