@@ -569,6 +569,7 @@ TK_DEV int code_inter_plane(const Team t, JobR<PIX> J, WsP<PIX> ws, const PIX* o
 
 // reuse_pred: the inter prediction of this (mode, refs, MVs) is already in ws->pred_* (previous trial
 // of the same candidate with another tb_param) - exact, the prediction does not depend on tb_param.
+// reuse_pred == 2: the caller vouches that ws->pred_* holds the prediction untouched (no CfL pass has refined its chroma).
 // SP: address space of the coding block's sample buffers and original samples (SP_LDS for blocks up to kLdsBlk).
 template <typename PIX, int SP>
 TK_DEVNI int encode_block(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd_, BlkParam& p, BitSink& bs,
@@ -670,7 +671,7 @@ TK_DEVNI int encode_block(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd_, Blk
     }
   } else {
     const int split = (TKU(p.mode) == M_INTER || TKU(p.mode) == M_BIPRED) ? c.enable_pb_split : 0;
-    if (!(reuse_pred && !c.cfl_inter)) predict_inter<PIX, SP>(t, J, ws, nd_, p, split);
+    if (!(reuse_pred == 2 || (reuse_pred && !c.cfl_inter))) predict_inter<PIX, SP>(t, J, ws, nd_, p, split);
     if (TKU(p.mode) == M_SKIP || zero_block) {
       copy_block<SP, SP>(t, ws->rec_y, size, ws->pred_y, size, nd.bw, nd.bh);
       copy_block<SP, SP>(t, ws->rec_u, sizeC, ws->pred_u, sizeC, nd.bw >> 1, nd.bh >> 1);
@@ -706,12 +707,13 @@ TK_DEVNI int encode_block(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd_, Blk
 template <typename PIX, int SP>
 TK_DEV unsigned rdo_trial(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd, BlkParam& p, double lambda,
                           int reuse_pred = 0, unsigned prune_thr = 0xffffffffu, const unsigned long long* bestkey = nullptr,
-                          unsigned order = 0) {
+                          unsigned order = 0, int* nbits_out = nullptr) {
   BitSink cnt;
   cnt.buf = nullptr; cnt.pos = 0; cnt.cap = 0; cnt.emit = 0; cnt.ovf = 0;
   PruneCtx pc;
   pc.thr = prune_thr; pc.bestkey = bestkey; pc.order = order; pc.lambda = lambda; pc.ssd_y = -1; pc.have_ybits = 0; pc.pruned = 0; pc.ssd_part = 0; pc.bits_part = 0;
   int nbits = encode_block<PIX, SP>(t, J, ws, nd, p, cnt, reuse_pred, &pc);
+  if (nbits_out) *nbits_out = nbits;
   if (pc.pruned) return kCostInit;  // lower bound >= threshold: cannot be selected
   return rd_cost<PIX, SP>(t, J, ws, nd, nbits, lambda, pc.ssd_y);
 }
@@ -1583,7 +1585,8 @@ TK_DEVNI int check_early_skip(const Team t, JobR<PIX> J, WsP<PIX> ws, const Node
 // Final encode of a CB: recompute (encode_block final), write recon + cell state, emit bits.
 // ---------------------------------------------------------------------------------
 template <typename PIX, int SP>
-TK_DEVNI int final_encode(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd, BitSink& out, const BigWs<PIX>* snap = nullptr) {
+TK_DEVNI int final_encode(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd, BitSink& out, const BigWs<PIX>* snap = nullptr,
+                          int trial_bits = -1) {
   TK_PROF_T0();
   BlkParam p = lds_ld(&nd.best);
   const int size = nd.size, sc = size >> 1;
@@ -1605,9 +1608,15 @@ TK_DEVNI int final_encode(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd, BitS
     copy_block<SP_GLOBAL, SP_GLOBAL>(t, J.rec.u + yc * J.rec.sc + xc, J.rec.sc, snap->best_u, sc, nd.bw >> 1, nd.bh >> 1);
     copy_block<SP_GLOBAL, SP_GLOBAL>(t, J.rec.v + yc * J.rec.sc + xc, J.rec.sc, snap->best_v, sc, nd.bw >> 1, nd.bh >> 1);
   } else {
-    BitSink cnt;
-    cnt.buf = nullptr; cnt.pos = 0; cnt.cap = 0; cnt.emit = 0; cnt.ovf = 0;
-    nbits = encode_block<PIX, SP>(t, J, ws, nd, p, cnt);
+    if (trial_bits >= 0) {
+      // skip candidate whose trial was the block's last encode_block: its reconstruction is still in ws->rec_*, nd.best carries
+      // the fields the trial set, a skip block has no coefficients - the second encode_block would rebuild the same state
+      nbits = trial_bits;
+    } else {
+      BitSink cnt;
+      cnt.buf = nullptr; cnt.pos = 0; cnt.cap = 0; cnt.emit = 0; cnt.ovf = 0;
+      nbits = encode_block<PIX, SP>(t, J, ws, nd, p, cnt);
+    }
     // bits (one lane), then recon copy and cells (all lanes)
     if (t.rank == 0) {
       BitSink w = out;
@@ -1710,6 +1719,7 @@ TK_DEV void process_sb(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int 
       if (nd.encode_this_size && J.frame_type != F_I && c.early_skip_thr > 0.0f) {
         unsigned min_cost = kCostInit;
         int any = 0;
+        int best_bits = -1;   // >= 0: the best candidate's trial was the last encode_block (its reconstruction is in ws->rec_*)
         BlkParam p;
         p.intra_mode = 0; p.pb_part = P_NONE; p.tb_param = 0; p.tb_split = 0; p.cbp_y = p.cbp_u = p.cbp_v = 0;
         for (int k = 0; k < nd.syn.num_skip; k++) {
@@ -1719,8 +1729,14 @@ TK_DEV void process_sb(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int 
           TK_PROF_ADD(ws, PF_ESKIP);
           if (es_) {
             any = 1;
-            unsigned cost = lds_blk ? rdo_trial<PIX, SP_LDS>(t, J, ws, nd, p, J.lambda) : rdo_trial<PIX, SP_GLOBAL>(t, J, ws, nd, p, J.lambda);
-            if (cost < min_cost) { min_cost = cost; if (t.rank == 0) keep_best(nd, p); t.sync(); }
+            // The check of a block of up to 32x32 predicts the whole block in one piece with the arguments predict_inter uses for
+            // a uni-directional skip candidate, into the same buffers, and only reads them afterwards: the trial takes it over.
+            const int reuse = tk_uniform(size <= 32 && p.dir != 2) ? 2 : 0;
+            int nb = 0;
+            unsigned cost = lds_blk ? rdo_trial<PIX, SP_LDS>(t, J, ws, nd, p, J.lambda, reuse, 0xffffffffu, nullptr, 0, &nb)
+                                    : rdo_trial<PIX, SP_GLOBAL>(t, J, ws, nd, p, J.lambda, reuse, 0xffffffffu, nullptr, 0, &nb);
+            if (cost < min_cost) { min_cost = cost; best_bits = nb; if (t.rank == 0) keep_best(nd, p); t.sync(); }
+            else best_bits = -1;
           }
         }
         if (any) {
@@ -1728,9 +1744,12 @@ TK_DEV void process_sb(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int 
             team_add64(&J.stats[0], (unsigned long long)(nd.bw * nd.bh));
             if (nd.size == kMaxSb) team_add64(&J.stats[1], 1ull);
           }
-          int nbits = lds_blk ? final_encode<PIX, SP_LDS>(t, J, ws, nd, out) : final_encode<PIX, SP_GLOBAL>(t, J, ws, nd, out);
-          // reference recomputes cost_calc on the final recon: identical to min_cost of that candidate
-          ret = lds_blk ? rd_cost<PIX, SP_LDS>(t, J, ws, nd, nbits, J.lambda) : rd_cost<PIX, SP_GLOBAL>(t, J, ws, nd, nbits, J.lambda);
+          const int nbits = lds_blk ? final_encode<PIX, SP_LDS>(t, J, ws, nd, out, nullptr, best_bits)
+                                    : final_encode<PIX, SP_GLOBAL>(t, J, ws, nd, out, nullptr, best_bits);
+          (void)nbits;
+          // The reference recomputes cost_calc on the final reconstruction (encode_block.c:2384): the final encode repeats the
+          // winning trial (same prediction, same bits), so that value is the trial's cost.
+          ret = min_cost;
 #if TK_HOST
           if (getenv("THOR_DBG")) fprintf(stderr, "F %d y %d x %d s %d ES mode %d idx %d cost %u bits %d\n", J.frame_num, nd.ypos, nd.xpos, nd.size, nd.best.mode, nd.best.skip_idx, ret, nbits);
 #endif
