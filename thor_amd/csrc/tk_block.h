@@ -35,9 +35,9 @@ struct Node {
 // wavefront: SmallWs (LDS: transform tiles, ME scratch, coefficient buffers, intra edges) and BigWs (sample blocks
 // up to 128x128 in a global scratch arena that stays L1/L2 resident).
 enum { kProfSlots = 32 };
-enum { kMdMaxItems = 32 };
+enum { kMdMaxItems = 48 };
 enum { kLdsBlk = 16 };   // coding blocks up to this size keep their sample buffers in LDS
-enum { MD_SKIP = 0, MD_MERGE, MD_REF, MD_INTRA, MD_BIPRED };
+enum { MD_SKIP = 0, MD_MERGE, MD_REF, MD_INTRA, MD_BIPRED, MD_TRIAL };
 enum { WG_CMD_EXIT = 0, WG_CMD_MD = 1 };
 struct MdItem { int8_t kind, a, b, pad; };
 struct WgShared {
@@ -49,6 +49,10 @@ struct WgShared {
   int next_item, n_items;        // work queue cursor (atomic) / length
   int refs_done, n_ref_items;    // reference searches finished (atomic) / expected; the last one triggers the bipred item
   int do_bipred;                 // 0 none, 1 one item (B frames), 2 lock-step phase after the queue (P frames)
+  // A reference's MD_REF item searches its partitions one after the other and publishes each partition's vectors; the RDO
+  // trials of (reference, partition) are queue items of their own (MD_TRIAL) that any wave takes once the vectors are there.
+  int parts_done[kMaxRefs];      // partitions of reference r searched so far (atomic, released after ref_mv[r][part] is written)
+  mv_t ref_mv[kMaxRefs][4][4];   // [reference][partition][quadrant]
   // bi-prediction search of P frames, run by all waves in lock step (bipred_par)
   const void* bp_org8;           // 2*org - pred of the current step (leader's buffer)
   unsigned bp_sad[kMaxRefs];
@@ -1199,47 +1203,66 @@ TK_DEVNI void md_item_bipred(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>&
   }
 }
 
+// MD_REF: the motion searches of one reference (encode_block.c:2011-2034) - partition after partition, each one seeded by
+// the candidates the earlier ones left in mvcand[r].  The vectors of a partition are published as soon as it is searched.
 template <typename PIX, int SP>
 TK_DEVNI void md_item_ref(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& M, int r) {
   const auto& c = J.cfg;
   const auto ndl = ldsc(M.nd);
   struct { int size, ypos, xpos; } nd = {TKU(ndl->size), TKU(ndl->ypos), TKU(ndl->xpos)};
   const int size = nd.size;
-  const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
   const int max_pb = c.enable_pb_split ? 4 : 1;
   const mv_t mvp = lds_ld(&M.sh->mvp);
   const PIX* oy = ws->org_y;
   if (t.rank == 0) add_mvcand(ws->mep, r, mvp);
   t.sync();
   mv_t mv_center = mvp;
-  mv_t mv_all[4][4];
   for (int part = 0; part < max_pb; part++) {
-    search_inter<PIX, SP>(t, J, ws, nd.ypos, nd.xpos, size, oy, ws->org_sy, r, mv_center, mvp, mv_all[part], part, J.sign[r]);
-    add_cands4(t, ws, r, mv_all[part]);
-    mv_center = mv_all[0][0];
+    mv_t mv_all[4];
+    search_inter<PIX, SP>(t, J, ws, nd.ypos, nd.xpos, size, oy, ws->org_sy, r, mv_center, mvp, mv_all, part, J.sign[r]);
+    add_cands4(t, ws, r, mv_all);
+    if (part == 0) mv_center = mv_all[0];
+    if (t.rank == 0) {
+      for (int i = 0; i < 4; i++) lds_st(&M.sh->ref_mv[r][part][i], mv_all[i]);
+      if (part == max_pb - 1) lds_st(&M.sh->mv_center[r], mv_center);
+      wg_fetch_add(&M.sh->parts_done[r], 1);   // release: the vectors above are visible to the wave that sees the count
+    }
+    t.sync();
   }
-  if (t.rank == 0) lds_st(&M.sh->mv_center[r], mv_center);
+}
+
+// MD_TRIAL: the RDO trials of one (reference, partition): tb_param -1 (no residual), 0 and 1 share one prediction.
+template <typename PIX, int SP>
+TK_DEVNI void md_item_trial(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& M, int r, int part) {
+  const auto& c = J.cfg;
+  const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
+  for (;;) {   // the reference's search item was taken from the queue before this one: it is finished or running on another wave
+    const int d = wg_load_acquire(&M.sh->parts_done[r]);   // every lane acquires (one broadcast LDS read)
+    if (team_bcast0(t, d) > part) break;
+    wg_pause();
+  }
+  mv_t mv_all[4][4];
+  for (int q = 0; q <= part; q++)
+    for (int i = 0; i < 4; i++) mv_all[q][i] = lds_ld(&M.sh->ref_mv[r][q][i]);
+  // With enable_pb_split every inter trial predicts the four quadrants with mv0[0..3] whatever the partition, so a
+  // partition whose quadrant vectors equal those of an EARLIER partition has the same prediction, residual, SSD and
+  // coefficient bits as that one and strictly more header bits (longer partition code, more vector differences): its
+  // cost is not smaller and its evaluation order is later - it can never be selected.  Skipped (exact).
+  int dup = 0;
+  for (int q = 0; q < part && c.enable_pb_split; q++) {
+    int eq = 1;
+    for (int i = 0; i < 4; i++) eq = eq && mv_all[q][i].x == mv_all[part][i].x && mv_all[q][i].y == mv_all[part][i].y;
+    dup = dup || eq;
+  }
+  if (tk_uniform(dup)) return;
   BlkParam p = blank_param();
   p.mode = M_INTER;
   p.ref0 = p.ref1 = (int8_t)r;
-  for (int part = 0; part < max_pb; part++) {
-    // With enable_pb_split every inter trial predicts the four quadrants with mv0[0..3] whatever the partition, so a
-    // partition whose quadrant vectors equal those of an EARLIER partition has the same prediction, residual, SSD and
-    // coefficient bits as that one and strictly more header bits (longer partition code, more vector differences): its
-    // cost is not smaller and its evaluation order is later - it can never be selected.  Skipped (exact).
-    int dup = 0;
-    for (int q = 0; q < part && c.enable_pb_split; q++) {
-      int eq = 1;
-      for (int i = 0; i < 4; i++) eq = eq && mv_all[q][i].x == mv_all[part][i].x && mv_all[q][i].y == mv_all[part][i].y;
-      dup = dup || eq;
-    }
-    if (tk_uniform(dup)) continue;
-    p.pb_part = (int8_t)part;
-    for (int i = 0; i < 4; i++) { p.mv0[i] = mv_all[part][i]; p.mv1[i] = mv_all[part][i]; }
-    for (int tb = -1; tb <= max_tb - 1; tb++) {
-      p.tb_param = (int8_t)tb;
-      par_trial<PIX, SP>(t, J, ws, M, p, 6u + 12u * (unsigned)r + 3u * (unsigned)part + (unsigned)(tb + 1), tb > -1);
-    }
+  p.pb_part = (int8_t)part;
+  for (int i = 0; i < 4; i++) { p.mv0[i] = mv_all[part][i]; p.mv1[i] = mv_all[part][i]; }
+  for (int tb = -1; tb <= max_tb - 1; tb++) {
+    p.tb_param = (int8_t)tb;
+    par_trial<PIX, SP>(t, J, ws, M, p, 6u + 12u * (unsigned)r + 3u * (unsigned)part + (unsigned)(tb + 1), tb > -1);
   }
 }
 
@@ -1380,6 +1403,8 @@ TK_DEVNI void md_worker_sp(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws) 
       if (done == sh->n_ref_items && sh->do_bipred == 1) {
         md_item_bipred<PIX, SP>(t, J, ws, M);
       }
+    } else if (kind == MD_TRIAL) {
+      md_item_trial<PIX, SP>(t, J, ws, M, ia, ib);
     }
   }
   if (sh->do_bipred == 2) {  // uniform over the workgroup: every wave takes part (same number of barriers)
@@ -1434,7 +1459,7 @@ TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, JobR<PIX> J, WsP<
   if (t.rank == 0) {
     int n = 0;
     auto push = [&](int kind, int a, int b) { sh->items[n].kind = (int8_t)kind; sh->items[n].a = (int8_t)a; sh->items[n].b = (int8_t)b; sh->items[n].pad = 0; n++; };
-    static_assert(2 + 2 + kMaxRefs + 2 * kNumIntraModes <= kMdMaxItems, "work queue too small");
+    static_assert(2 + 2 + kMaxRefs + 2 * kNumIntraModes + 4 * kMaxRefs <= kMdMaxItems, "work queue too small");
     static_assert(6 + 12 * kMaxRefs <= 54, "evaluation-order layout: the reference trials must end before the bi-prediction trials");
     if (inter) {
       for (int k = 0; k < nd->syn.num_skip; k++) push(MD_SKIP, k, 0);
@@ -1444,6 +1469,10 @@ TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, JobR<PIX> J, WsP<
     }
     for (int m = 0; m < J.num_intra_modes; m++)
       for (int tb = 0; tb <= max_tb - 1; tb++) push(MD_INTRA, m, tb);
+    // the trials of the searched vectors come last: by the time the queue gets here most searches have published theirs
+    if (inter)
+      for (int part = 0; part < (c.enable_pb_split ? 4 : 1); part++)
+        for (int r = 0; r < J.num_ref; r++) { push(MD_TRIAL, r, part); sh->parts_done[r] = 0; }
     sh->n_items = n; sh->next_item = 0;
     sh->refs_done = 0; sh->n_ref_items = inter ? J.num_ref : 0;
     sh->do_bipred = (inter && J.num_ref > 1 && c.enable_bipred) ? (J.frame_type == F_P ? 2 : 1) : 0;

@@ -21,6 +21,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <stdio.h>
+#include <sched.h>
 #define TK_DEV static inline
 #define TK_HD static inline
 #define TK_CONST static const
@@ -162,6 +163,21 @@ TK_DEV void wg_min64(unsigned long long* p, unsigned long long v) {
   while (v < cur && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED)) {}
 #else
   __hip_atomic_fetch_min((__attribute__((address_space(3))) unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+TK_DEV int wg_load_acquire(const int* p) {
+#if TK_HOST
+  return __atomic_load_n(p, __ATOMIC_ACQUIRE);
+#else
+  return __hip_atomic_load((const __attribute__((address_space(3))) int*)p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+// Back-off inside a wait on another wave of the workgroup.
+TK_DEV void wg_pause() {
+#if TK_HOST
+  sched_yield();
+#else
+  __builtin_amdgcn_s_sleep(8);
 #endif
 }
 TK_DEV unsigned long long wg_load64(const unsigned long long* p) {
