@@ -1236,14 +1236,16 @@ template <typename PIX, int SP>
 TK_DEVNI void md_item_trial(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& M, int r, int part) {
   const auto& c = J.cfg;
   const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
+  r = tk_uniform(r); part = tk_uniform(part);
+  WgShared* const sh_ = tk_uniform_ptr(M.sh);
   for (;;) {   // the reference's search item was taken from the queue before this one: it is finished or running on another wave
-    const int d = wg_load_acquire(&M.sh->parts_done[r]);   // every lane acquires (one broadcast LDS read)
+    const int d = wg_load_acquire(&sh_->parts_done[r]);   // every lane acquires (one broadcast LDS read)
     if (team_bcast0(t, d) > part) break;
     wg_pause();
   }
   mv_t mv_all[4][4];
   for (int q = 0; q <= part; q++)
-    for (int i = 0; i < 4; i++) mv_all[q][i] = lds_ld(&M.sh->ref_mv[r][q][i]);
+    for (int i = 0; i < 4; i++) mv_all[q][i] = lds_ld(&sh_->ref_mv[r][q][i]);
   // With enable_pb_split every inter trial predicts the four quadrants with mv0[0..3] whatever the partition, so a
   // partition whose quadrant vectors equal those of an EARLIER partition has the same prediction, residual, SSD and
   // coefficient bits as that one and strictly more header bits (longer partition code, more vector differences): its
