@@ -1,0 +1,27 @@
+#!/bin/bash
+# round 4, call 1 (prepared at the end of round 3, whose GPU budget was spent before these changes existed): parity and A/B of the
+# three exact work-avoidance / scheduling steps that were verified in the host simulations only -
+#   r3final = 1fc3cf8 (last library measured on the MI355X: 93.2 Mpx/s driver regime), es = + early-skip reuse (29ce444),
+#   split = + search / trial queue items, dd = + no vector evaluated twice (HEAD).
+# Build the variants in the container first (the libraries travel with the snapshot):
+#   scripts/build_at_commit.sh 1fc3cf8 r3final; scripts/build_at_commit.sh 29ce444 es; scripts/build_at_commit.sh <split commit> split
+R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+O=$R/gpurun_out
+timeout 300 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "golden or two_streams" > $O/r4c1_par_small.log 2>&1; echo "parity small rc=$? $(tail -1 $O/r4c1_par_small.log)"
+timeout 700 python -m pytest tests/test_gpu_fullsize.py -q -x -m gpu -k "1080p_ldb_n5 or six_frames or ra" > $O/r4c1_par_big.log 2>&1; echo "parity big rc=$? $(tail -1 $O/r4c1_par_big.log)"
+ab() {
+  tag=$1; lib=$R/thor_amd/libthor_hip_$tag.so; [ "$tag" = head ] && lib=$R/thor_amd/libthor_hip.so
+  [ -f $lib ] || { echo "ab $tag: $lib missing"; return; }
+  THOR_HIP_LIB=$lib timeout 300 python bench.py --width 1920 --height 1080 --streams 128 --warmup 4 --steps 2 --no-verify --no-cpu-baseline > $O/r4c1_ab_$tag.log 2>&1
+  echo "ab $tag: $(grep -o '"value": [0-9.]*' $O/r4c1_ab_$tag.log | head -1) $(grep -o '"ms_per_step": [0-9.]*' $O/r4c1_ab_$tag.log)"
+}
+ab r3final; ab es; ab split; ab head
+abra() {
+  tag=$1; lib=$R/thor_amd/libthor_hip_$tag.so; [ "$tag" = head ] && lib=$R/thor_amd/libthor_hip.so
+  [ -f $lib ] || return
+  THOR_HIP_LIB=$lib timeout 400 python bench.py --config ra --width 1920 --height 1080 --streams 96 --warmup 1 --steps 8 --no-verify --no-cpu-baseline > $O/r4c1_abra_$tag.log 2>&1
+  echo "ab RA $tag: $(grep -o '"value": [0-9.]*' $O/r4c1_abra_$tag.log | head -1) $(grep -o '"ms_per_step": [0-9.]*' $O/r4c1_abra_$tag.log)"
+}
+abra r3final; abra head

@@ -82,6 +82,36 @@ def test_multi_wave_host_simulation_416x240_four_references_vs_live_reference():
     assert bits == rb and rec == rr
 
 
+def _large_pan_clip(w, h, n, seed):
+    """Smoothed random texture panned by 13 / 17 samples per frame in alternating directions: the motion vectors near the frame
+    borders point outside the padded area (clip_mv acts), telescope grids move every step."""
+    import numpy as np
+    from numpy.lib.stride_tricks import sliding_window_view
+    rng = np.random.default_rng(seed)
+    sm = sliding_window_view(rng.integers(0, 256, size=(h + 400, w + 400)).astype(np.float64), (5, 5)).mean(axis=(2, 3))
+    out = b''
+    for f in range(n):
+        dy, dx = 200 + 13 * f * (1 if f % 2 else -1), 200 - 17 * f
+        Y = sm[dy:dy + h, dx:dx + w] + rng.normal(0, 2.0, size=(h, w))
+        U = sm[dy:dy + h:2, dx:dx + w:2] * 0.5 + 64 + rng.normal(0, 1.0, size=(h // 2, w // 2))
+        V = sm[dy + 1:dy + h:2, dx + 1:dx + w:2] * 0.5 + 64
+        out += b''.join(np.clip(np.rint(p), 0, 255).astype(np.uint8).tobytes() for p in (Y, U, V))
+    return out
+
+
+@needs_ref
+def test_large_pan_clipped_vectors_and_moving_search_grids_vs_live_reference():
+    """Fast alternating pan at 192x128 (I + 4 P): vectors get clipped at the frame borders and every telescope step moves its
+    centre - the cases the "no vector is evaluated twice" rule of the motion search (tk_me.h: on_grid) has to get right: grids
+    whose centre sits on the rim of the previous one, clipped candidates, hexagon starts off the last grid's centre.  1-lane and
+    4-wave host simulation against a live run of the reference."""
+    clip = _large_pan_clip(192, 128, 5, 77)
+    rb, rr = run_encoder(REF_ENC, clip, 192, 128, 5, 30)
+    for sim in (build_hostsim(), build_hostsim(waves=4)):
+        bits, rec = run_encoder(sim, clip, 192, 128, 5, 30)
+        assert bits == rb and rec == rr
+
+
 @needs_ref
 def test_host_simulation_two_random_access_streams_equal_reference_chunks():
     """Two closed RA streams (hierarchical B + interpolated references, host-threaded interpolation) in lock step ==

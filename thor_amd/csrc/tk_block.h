@@ -1778,7 +1778,7 @@ TK_DEV void process_sb(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int 
           const int nbits = lds_blk ? final_encode<PIX, SP_LDS>(t, J, ws, nd, out, nullptr, best_bits)
                                     : final_encode<PIX, SP_GLOBAL>(t, J, ws, nd, out, nullptr, best_bits);
           (void)nbits;
-          // The reference recomputes cost_calc on the final reconstruction (encode_block.c:2384): the final encode repeats the
+          // The reference recomputes cost_calc on the final reconstruction (encode_block.c:2483-2488): the final encode repeats the
           // winning trial (same prediction, same bits), so that value is the trial's cost.
           ret = min_cost;
 #if TK_HOST

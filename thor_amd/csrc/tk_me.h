@@ -516,17 +516,52 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
     }
     return bestk;
   };
+  // Vectors this search has already evaluated cannot win a later pass: every pass keeps a candidate only on a strict '<'
+  // against min_sad, the minimum over everything evaluated so far with the same cost function (same block, same mvp; a
+  // vector is clipped the same way whenever it comes up).  The 5x5 grid of a telescope step (spacing `step`) shares its
+  // points with even offsets with the previous step's grid (spacing 2*step) - up to 8 of 24; by induction the previous
+  // grid is the only one that needs checking.  Passes of PUs that need more than one evaluator iteration for 24 candidates
+  // leave those points out (encoder_speed 0; exact: the surviving candidates keep their relative order, so ties resolve the
+  // same way); a hexagon refinement that starts on the centre of the last grid would only revisit it and is skipped.
+  mv_t g_ctr = mk_mv(0, 0);
+  int g_step = 0;   // spacing of the last telescope grid evaluated (0: none)
+  auto on_grid = [&](mv_t m) -> int {
+    const int dx = m.x - g_ctr.x, dy = m.y - g_ctr.y;
+    return g_step && !((dx | dy) & (g_step - 1)) && iabs(dx) <= 2 * g_step && iabs(dy) <= 2 * g_step;
+  };
+  const int lw_ = (a.width < 16 / (int)sizeof(PIX)) ? a.width : 16 / (int)sizeof(PIX);   // samples per row segment (seg_sads)
+  const int dedup = a.speed == 0 && a.height * (a.width / lw_) >= 16;
   // --- telescope (encode_block.c:529-561); encoder_speed > 0 keeps it only for 16x16 CBs with bipred on
   if ((a.cb_size == 16 && a.enable_bipred) || a.speed == 0)
   for (int step = 32; step >= 4; step >>= 1) {
     const int n = step < 32 ? 24 : 25;
     const mv_t centre = mv_ref;
     const int noclip = TKU(clip_free(centre, 2 * step));
-    auto tele = [&](int c) -> FP {
+    auto tele_mv = [&](int c) -> mv_t {
       int idx = (step < 32 && c >= 12) ? c + 1 : c;  // centre skipped after the first step
       int q = (idx * 13) >> 6;                         // idx / 5 for idx < 25
-      return mk_fp(mk_mv(centre.x + (idx - q * 5 - 2) * step, centre.y + (q - 2) * step), noclip);
+      return mk_mv(centre.x + (idx - q * 5 - 2) * step, centre.y + (q - 2) * step);
     };
+    auto tele = [&](int c) -> FP { return mk_fp(tele_mv(c), noclip); };
+    if (dedup && g_step) {
+      // compact list of the grid points not evaluated before (clipped) in w->cmv, in grid order
+      t.sync();
+      int cnt = 0;
+      for (int c0 = 0; c0 < n; c0 += t.size) {
+        const int c = c0 + t.rank;
+        const mv_t m = tele_mv(c < n ? c : 0);
+        const int keep = c < n && !on_grid(m);
+        const unsigned long long mask = team_ballot(t, keep);
+        if (keep) cmv_set(cnt + __builtin_popcountll(mask & ((1ull << t.rank) - 1ull)), mk_fp(m, noclip).mv);
+        cnt += __builtin_popcountll(mask);
+      }
+      t.sync();
+      cnt = TKU(cnt);
+      auto cl = [&](int c) -> FP { return mk_fp(cmv_get(c), 1); };
+      unsigned long long k = eval_fullpel<SP>(t, cnt, org, a.ostride, a.rstride, a.width, a.height, win, cl, fp_cost);
+      if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = cmv_get((int)(unsigned)k); }
+      t.sync();
+    } else
     if (step == 32 && a.cb_size == 16 && a.speed == 1) {  // first ring by widesad at encoder_speed 1
       t.sync();
       for (int c = t.rank; c < n; c += t.size) cmv_set(c, tele(c).mv);
@@ -538,6 +573,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
       unsigned long long k = eval_fullpel<SP>(t, n, org, a.ostride, a.rstride, a.width, a.height, win, tele, fp_cost);
       if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = tele((int)(unsigned)k).mv; }
     }
+    g_ctr = centre; g_step = a.speed == 0 ? step : 0;
     mv_ref = mv_opt;
   }
 
@@ -560,9 +596,14 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
         if ((unsigned)(bestk >> 32) < min_sad) { min_sad = (unsigned)(bestk >> 32); mv_opt = cmv_get((int)(unsigned)bestk); }
         t.sync();
       } else {
-        auto cl = [&](int c) -> FP { return mk_fp(cmv_get(c), 1); };  // cmv already clipped (clip_mv is idempotent)
-        unsigned long long k = eval_fullpel<SP>(t, n, org, a.ostride, a.rstride, a.width, a.height, win, cl, fp_cost);
-        if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = cmv_get((int)(unsigned)k); }
+        // candidates that lie on the last telescope grid have been evaluated (see on_grid): a list of nothing else is skipped
+        int fresh = 0;
+        for (int c = t.rank; c < n; c += t.size) fresh |= !on_grid(cmv_get(c));
+        if (team_ballot(t, fresh) != 0ull) {
+          auto cl = [&](int c) -> FP { return mk_fp(cmv_get(c), 1); };  // cmv already clipped (clip_mv is idempotent)
+          unsigned long long k = eval_fullpel<SP>(t, n, org, a.ostride, a.rstride, a.width, a.height, win, cl, fp_cost);
+          if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = cmv_get((int)(unsigned)k); }
+        }
         t.sync();
       }
     }
@@ -576,7 +617,9 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
   // --- hexagon refinement (encode_block.c:583-616): up to 5 rounds; skipped for CBs > 16 at encoder_speed > 0
   {
     int start = 0, end = 5;
-    const int maxsteps = (a.cb_size <= 16 || a.speed == 0) ? 6 : 0;
+    // all six points around the centre of the last telescope grid (spacing one sample) belong to that grid: nothing to find
+    const int revisit = TKU(g_step == 4 && mv_ref.x == g_ctr.x && mv_ref.y == g_ctr.y);
+    const int maxsteps = revisit ? 0 : (a.cb_size <= 16 || a.speed == 0) ? 6 : 0;
     for (int step = 1; step < maxsteps; step++) {
       const int n = (end - start + 6) % 6 + 1;  // 6 in the first round, 3 afterwards
       const mv_t centre = mv_ref;
