@@ -466,7 +466,8 @@ def main():
                                    f'{S} independent closed streams per GPU in lock step, timed frames = coded frames {a.warmup}..{nframes - 1} of each stream '
                                    f'({R:.2f} references on average), synthetic content sigma {a.sigma:g}',
                        'streams_per_gpu': S, 'frames_timed_per_stream': a.steps, 'parallelism': f'stream-sharded x{world}',
-                       'per_stream_fps': round(a.steps / dt, 4), 'per_stream_mpx_s': round(w * h * a.steps / dt / 1e6, 4)},
+                       'per_stream_fps': round(a.steps / dt, 4), 'per_stream_mpx_s': round(w * h * a.steps / dt / 1e6, 4),
+                       'superblock_queue': os.environ.get('THOR_SCHED', 'fifo')},   # thor_amd/csrc/tk_sched.h: fifo | lag
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 4), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 8), 'traffic': traffic, 'traffic_unit': 'bytes per launch', 'traffic_source': traffic_src,
                          'alg_bytes_per_launch': round(alg_bytes_per_launch),

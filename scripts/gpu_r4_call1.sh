@@ -25,3 +25,9 @@ abra() {
   echo "ab RA $tag: $(grep -o '"value": [0-9.]*' $O/r4c1_abra_$tag.log | head -1) $(grep -o '"ms_per_step": [0-9.]*' $O/r4c1_abra_$tag.log)"
 }
 abra r3final; abra head
+# queue discipline of the superblock scheduler (tk_sched.h): parity with laggards first, then the A/B where it matters (4K, 128 streams)
+THOR_SCHED=lag timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -q -x -m gpu -k "golden or two_streams or six_frames" > $O/r4c1_par_lag.log 2>&1; echo "parity lag rc=$? $(tail -1 $O/r4c1_par_lag.log)"
+for q in fifo lag; do
+  THOR_SCHED=$q timeout 500 python bench.py --warmup 5 --steps 2 --no-verify --no-cpu-baseline > $O/r4c1_sched_$q.log 2>&1
+  echo "sched $q: $(grep -o '"value": [0-9.]*' $O/r4c1_sched_$q.log | head -1) $(grep -o '"ms_per_step": [0-9.]*' $O/r4c1_sched_$q.log)"
+done

@@ -1,4 +1,4 @@
-"""Model check of the superblock dependency scheduler (thor_amd/csrc/thor_hip.cpp:k_superblocks).
+"""Model check of the superblock dependency scheduler (thor_amd/csrc/tk_sched.h:df_finish, used by thor_hip.cpp:k_superblocks).
 
 The kernel releases a task when its dependency counter reaches `need`; a finishing task (k,l) bumps the counters
 of  (k,l+1),  (k+1,l-1)  and, in the last column,  (k+1,l).  This test restates that successor rule and checks,
@@ -18,7 +18,7 @@ def deps(k, l, rows, cols):
     return d
 
 
-def successors(k, l, rows, cols):  # the rule coded in k_superblocks
+def successors(k, l, rows, cols):  # the rule coded in tk_sched.h:df_finish
     s = []
     if l + 1 < cols:
         s.append((k, l + 1))

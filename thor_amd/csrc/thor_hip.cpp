@@ -17,6 +17,7 @@
 #include "tk_clpf.h"
 #include "tk_encoder.h"
 #include "tk_cli.h"
+#include "tk_sched.h"
 #include "../../include/thor_hip.h"
 
 #define HIPCHECK(x)                                                                              \
@@ -37,51 +38,7 @@ __device__ Tables g_tab;
 // ---------------------------------------------------------------------------------------------
 // Dependency-driven persistent superblock kernel.  A task is (stream, superblock).  SB(k,l) needs its left
 // neighbour (k,l-1) and its up-right neighbour (k-1,l+1) ((k-1,l) in the last column) - SURVEY.md Appendix A.
-// Ready tasks live in a single-use FIFO in global memory (one slot per task of the frame, so no wrap-around):
-// a finishing task bumps the dependency counters of its successors and pushes those that became ready;
-// idle workgroups take a pop ticket and wait for that slot to be filled.  Every task is pushed exactly once
-// and running tasks never wait, so every pop ticket below the task count is eventually served: no deadlock
-// whatever the dispatch order or residency, and no workgroup ever holds a task that is not ready.
-// Publication uses agent-scope release/acquire, which also orders the data across the 8 XCD L2s.
-struct DfCtl {
-  unsigned head, tail, error, pad;
-};
-struct DfArgs {
-  DfCtl* ctl;
-  unsigned* queue;             // [S*nsb] task ids (stream*nsb + sb), 0xffffffff = not filled yet
-  unsigned* cnt;               // [S*nsb] finished-dependency counters
-  uint8_t* pool;               // one BigWs scratch slot per workgroup
-  size_t slot_bytes;
-  unsigned long long* times;   // optional [S*nsb][3] pop/start/end wall clock (100 MHz)
-  int S, nsb, cols, rows;
-  unsigned long long spin_limit;  // wall-clock ticks a workgroup may wait for a queue slot
-};
-static const unsigned kDfEmpty = 0xffffffffu;
-
-// Poll with RELAXED agent-scope loads: an acquire load in the loop would issue a buffer_inv (a whole-L2
-// invalidate on this XCD) per poll and starve every working wavefront.  The single acquire fence executed
-// after the wait orders the dependent reads.
-__device__ inline unsigned df_pop(const DfArgs& A, unsigned slot) {
-  const unsigned long long t0 = wall_clock64();
-  unsigned n = 0, v;
-  while ((v = __hip_atomic_load(&A.queue[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kDfEmpty) {
-    for (int i = 0; i < 4; i++) __builtin_amdgcn_s_sleep(127);  // ~14 us between polls
-    if ((++n & 63u) == 0) {
-      if (__hip_atomic_load(&A.ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return kDfEmpty;
-      if (wall_clock64() - t0 > A.spin_limit) { atomicExch(&A.ctl->error, 1u); return kDfEmpty; }
-    }
-  }
-  return v;
-}
-__device__ inline void df_done_dep(const DfArgs& A, unsigned base, int k, int l) {  // a dependency of (k,l) finished
-  const unsigned id = base + (unsigned)(k * A.cols + l);
-  const unsigned need = (l > 0 ? 1u : 0u) + (k > 0 ? 1u : 0u);
-  const unsigned old = __hip_atomic_fetch_add(&A.cnt[id], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-  if (old + 1 == need) {
-    const unsigned p = __hip_atomic_fetch_add(&A.ctl->tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&A.queue[p], id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
+// The ready-task queues and their two disciplines (FIFO / laggards first) are in tk_sched.h.
 
 // Workgroup = kWaves wavefronts on one superblock: wave 0 walks the quadtree (process_sb), the others are parked on
 // the workgroup barrier and take work items of the block decisions (tk_block.h:mode_decision_par).  3 workgroups of
@@ -106,13 +63,13 @@ template <typename PIX> __global__ __launch_bounds__(kWgThreads, kOcc) void k_su
   WsP<PIX> ws = ldsc(&s_view[wave]);
   const Team t = mk_team(lane, 64, sh.tabs.izz);
   xform_tables_fill(&sh.tabs, (int)threadIdx.x, kWgThreads);  // constant: once per workgroup
+  unsigned sched_lo = 0;   // thread 0: scheduler state of this workgroup (tk_sched.h:df_next)
   for (;;) {
     __syncthreads();
     unsigned long long tpop = 0;
     if (threadIdx.x == 0) {
-      const unsigned slot = atomicAdd(&A.ctl->head, 1u);
       if (A.times) tpop = wall_clock64();
-      s_task = slot < total ? df_pop(A, slot) : kDfEmpty;
+      s_task = df_next(A, total, sched_lo);
     }
     __syncthreads();
     const unsigned task = (unsigned)__builtin_amdgcn_readfirstlane((int)s_task);
@@ -152,12 +109,7 @@ template <typename PIX> __global__ __launch_bounds__(kWgThreads, kOcc) void k_su
     __syncthreads();
     if (threadIdx.x == 0) {
       if (A.times) A.times[3 * (size_t)task + 2] = wall_clock64();
-      const unsigned base = (unsigned)sidx * (unsigned)A.nsb;
-      if (l + 1 < A.cols) df_done_dep(A, base, k, l + 1);               // right neighbour: its left dependency
-      if (k + 1 < A.rows) {
-        if (l >= 1) df_done_dep(A, base, k + 1, l - 1);                 // down-left: its up-right dependency
-        if (l == A.cols - 1) df_done_dep(A, base, k + 1, l);            // last column: the SB below uses (k,l) as "up-right"
-      }
+      df_finish(A, (unsigned)sidx * (unsigned)A.nsb, k, l);
     }
   }
 }
@@ -396,21 +348,39 @@ struct DfState {  // per engine (keyed by its device job array)
   unsigned* cnt = nullptr;
   uint8_t* pool = nullptr;
   unsigned long long* times = nullptr;
+  unsigned* bq = nullptr;      // laggards-first discipline: per-bucket claim / push counts, bucket offsets (tk_sched.h)
+  unsigned* bbase = nullptr;
+  int nb = 0;
   int S = 0, nsb = 0, wgs = 0;
   size_t slot = 0;
   int frame = 0;
 };
 static std::map<const void*, DfState> g_df;
+static void df_free(DfState& D) {
+  if (!D.ctl) return;
+  HIPCHECK(hipFree(D.ctl)); HIPCHECK(hipFree(D.queue)); HIPCHECK(hipFree(D.cnt)); HIPCHECK(hipFree(D.pool));
+  if (D.times) HIPCHECK(hipFree(D.times));
+  if (D.bq) { HIPCHECK(hipFree(D.bq)); HIPCHECK(hipFree(D.bbase)); }
+}
+// Queue discipline of the superblock scheduler (tk_sched.h): THOR_SCHED=fifo (default) | lag (laggards first).
+static int df_lag_discipline() {
+  const char* e = getenv("THOR_SCHED");
+  if (!e || !strcmp(e, "fifo")) return 0;
+  if (!strcmp(e, "lag")) return 1;
+  fprintf(stderr, "Run-time error...\nthor_hip: THOR_SCHED must be fifo or lag (got %s)\n...now exiting to system...\n", e);
+  abort();
+}
 
 template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S) {
   const int cols = hjobs[0].sb_cols, rows = hjobs[0].sb_rows, nsb = cols * rows;
   const size_t total = (size_t)S * nsb;
   DfState& D = g_df[jobs];
   const size_t slot = (sizeof(BigWs<PIX>) + 255) & ~(size_t)255;
-  if (D.S != S || D.nsb != nsb || D.slot != slot) {
-    if (D.ctl) { HIPCHECK(hipFree(D.ctl)); HIPCHECK(hipFree(D.queue)); HIPCHECK(hipFree(D.cnt)); HIPCHECK(hipFree(D.pool)); if (D.times) HIPCHECK(hipFree(D.times)); }
+  const int nb = df_lag_discipline() ? df_num_buckets(rows, cols) : 0;
+  if (D.S != S || D.nsb != nsb || D.slot != slot || D.nb != nb) {
+    df_free(D);
     D = DfState();
-    D.S = S; D.nsb = nsb; D.slot = slot;
+    D.S = S; D.nsb = nsb; D.slot = slot; D.nb = nb;
     int per_cu = 0;
     HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_superblocks<PIX>, kWgThreads, 0));
     hipDeviceProp_t prop;
@@ -425,6 +395,16 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
     HIPCHECK(hipMalloc(&D.cnt, sizeof(unsigned) * total));
     HIPCHECK(hipMalloc(&D.pool, slot * (size_t)D.wgs * kWaves));  // one BigWs slot per wavefront
     if (getenv("THOR_SBTIMES")) { HIPCHECK(hipMalloc(&D.times, sizeof(unsigned long long) * 3 * total)); }
+    if (nb) {
+      // bucket b = anti-diagonal l + 2k holds S * #{(k,l): l + 2k = b} tasks, back to back in `queue`
+      std::vector<unsigned> base(nb + 1, 0u);
+      for (int k = 0; k < rows; k++)
+        for (int l = 0; l < cols; l++) base[df_bucket(k, l) + 1] += (unsigned)S;
+      for (int b = 0; b < nb; b++) base[b + 1] += base[b];
+      HIPCHECK(hipMalloc(&D.bq, sizeof(unsigned) * 2 * nb));
+      HIPCHECK(hipMalloc(&D.bbase, sizeof(unsigned) * (nb + 1)));
+      HIPCHECK(hipMemcpy(D.bbase, base.data(), sizeof(unsigned) * (nb + 1), hipMemcpyHostToDevice));
+    }
   }
   // frame start: only SB(0,0) of every stream is ready
   {
@@ -433,13 +413,19 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
     DfCtl hc0 = {0u, (unsigned)S, 0u, 0u};
     HIPCHECK(hipMemsetAsync(D.queue, 0xff, sizeof(unsigned) * total, g_stream));
     HIPCHECK(hipMemsetAsync(D.cnt, 0, sizeof(unsigned) * total, g_stream));
-    HIPCHECK(hipMemcpyAsync(D.queue, q0.data(), sizeof(unsigned) * S, hipMemcpyHostToDevice, g_stream));
+    HIPCHECK(hipMemcpyAsync(D.queue, q0.data(), sizeof(unsigned) * S, hipMemcpyHostToDevice, g_stream));   // bucket 0 = SB(0,0) of every stream
     HIPCHECK(hipMemcpyAsync(D.ctl, &hc0, sizeof(hc0), hipMemcpyHostToDevice, g_stream));
+    if (nb) {
+      const unsigned pushed0 = (unsigned)S;
+      HIPCHECK(hipMemsetAsync(D.bq, 0, sizeof(unsigned) * 2 * nb, g_stream));
+      HIPCHECK(hipMemcpyAsync(D.bq + 1, &pushed0, sizeof(unsigned), hipMemcpyHostToDevice, g_stream));
+    }
     HIPCHECK(hipStreamSynchronize(g_stream));
   }
   DfArgs A;
   A.ctl = D.ctl; A.queue = D.queue; A.cnt = D.cnt; A.pool = D.pool; A.slot_bytes = slot; A.times = D.times;
   A.S = S; A.nsb = nsb; A.cols = cols; A.rows = rows;
+  A.nb = nb; A.bq = D.bq; A.bbase = D.bbase;
   double lim_s = 300.0;
   if (const char* e = getenv("THOR_HIP_SPIN_TIMEOUT_S")) lim_s = atof(e);
   A.spin_limit = (unsigned long long)(lim_s * 1e8);
@@ -452,8 +438,9 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
   DfCtl hc;
   HIPCHECK(hipMemcpyAsync(&hc, D.ctl, sizeof(hc), hipMemcpyDeviceToHost, g_stream));
   HIPCHECK(hipStreamSynchronize(g_stream));
-  if (hc.error || hc.tail != (unsigned)total) {
-    fprintf(stderr, "Run-time error...\nthor_hip: superblock scheduler failed (error %u, %u of %zu tasks released)\n...now exiting to system...\n", hc.error, hc.tail, total);
+  const unsigned handed_out = nb ? hc.claimed : hc.tail;
+  if (hc.error || handed_out != (unsigned)total) {
+    fprintf(stderr, "Run-time error...\nthor_hip: superblock scheduler failed (error %u, %u of %zu tasks released)\n...now exiting to system...\n", hc.error, handed_out, total);
     abort();
   }
   if (D.times) {
@@ -470,7 +457,7 @@ void release_superblocks(const void* jobs) {
   auto it = g_df.find(jobs);
   if (it == g_df.end()) return;
   DfState& D = it->second;
-  if (D.ctl) { HIPCHECK(hipFree(D.ctl)); HIPCHECK(hipFree(D.queue)); HIPCHECK(hipFree(D.cnt)); HIPCHECK(hipFree(D.pool)); if (D.times) HIPCHECK(hipFree(D.times)); }
+  df_free(D);
   g_df.erase(it);
 }
 template <typename PIX> void run_deblock(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S) {

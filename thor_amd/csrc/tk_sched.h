@@ -1,0 +1,163 @@
+// tk_sched.h - ready-task queues of the persistent superblock kernel (thor_hip.cpp:k_superblocks).
+//
+// SB(k,l) of a stream needs SB(k,l-1) and SB(k-1,l+1) of the same stream (enc/encode_frame.c walks the superblocks in raster
+// order; the dependencies are those of the motion-vector / intra / context neighbours).  One launch per
+// frame covers every superblock of every stream; resident workgroups take ready (stream, SB) tasks until all are taken.  A
+// finishing task bumps the dependency counters of its successors and pushes those that became ready.  Every task is pushed
+// exactly once, a workgroup only ever holds a task that is ready and running tasks never wait: no deadlock whatever the
+// dispatch order or residency.  Publication uses agent-scope release (push) / acquire (after the pop), which also orders the
+// data across the 8 XCD L2s.
+//
+// Two queue disciplines over the same `queue` array (one slot per task of the frame, single use, no wrap-around):
+//  * FIFO (nb == 0): pushes take a tail ticket, idle workgroups take a head ticket and wait for that slot to be filled.
+//  * laggards first (nb > 0): one single-use FIFO per anti-diagonal b = l + 2k of the superblock grid (the step of the
+//    62-step dependency chain of a 3840x2160 frame a task belongs to), laid out back to back (bucket b starts at bbase[b] and
+//    holds S * #{(k,l): l + 2k = b} tasks).  An idle workgroup claims from the lowest bucket that has an unclaimed pushed task
+//    (compare-and-swap on the bucket's claim count): streams that have fallen behind are served first, so the frame does
+//    not end with a few slow streams walking their chains alone (profiles/r03_sched_policy_model.md).
+//
+// The functions below are written against a small set of atomics macros so that tests/hostsim/sched_stress.cpp can run the
+// very same protocol with OS threads (THOR_SCHED_HOSTTEST); the device build maps them to agent-scope HIP atomics.
+#pragma once
+#include <stdint.h>
+
+#if defined(THOR_SCHED_HOSTTEST)
+#include <sched.h>
+#include <time.h>
+#define DF_FN static inline
+#define DF_HD static inline
+// (acquire loads instead of relaxed loads + the fence the kernel executes after the pop: ThreadSanitizer does not model fences)
+#define DF_LOAD(p) __atomic_load_n((p), __ATOMIC_ACQUIRE)
+#define DF_ADD(p, v) __atomic_fetch_add((p), (v), __ATOMIC_RELAXED)
+#define DF_ADD_ACQ_REL(p, v) __atomic_fetch_add((p), (v), __ATOMIC_ACQ_REL)
+#define DF_CAS(p, expected, desired) __atomic_compare_exchange_n((p), &(expected), (desired), false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)
+#define DF_STORE_RELEASE(p, v) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
+#define DF_EXCHANGE(p, v) __atomic_exchange_n((p), (v), __ATOMIC_RELAXED)
+#define DF_BACKOFF() sched_yield()
+static inline unsigned long long df_clock() {  // 100 MHz ticks like the device's wall clock
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (unsigned long long)ts.tv_sec * 100000000ull + (unsigned long long)ts.tv_nsec / 10ull;
+}
+#else
+#define DF_FN __device__ inline
+#define DF_HD __host__ __device__ inline
+#define DF_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define DF_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define DF_ADD_ACQ_REL(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+#define DF_CAS(p, expected, desired) \
+  __hip_atomic_compare_exchange_strong((p), &(expected), (desired), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define DF_STORE_RELEASE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
+#define DF_EXCHANGE(p, v) __hip_atomic_exchange((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// ~14 us between polls: an idle workgroup must not compete with the working ones for the L2
+#define DF_BACKOFF() do { for (int i_ = 0; i_ < 4; i_++) __builtin_amdgcn_s_sleep(127); } while (0)
+__device__ inline unsigned long long df_clock() { return wall_clock64(); }
+#endif
+
+namespace tk {
+
+struct DfCtl {
+  unsigned head, tail;   // FIFO discipline: pop / push tickets
+  unsigned error;
+  unsigned claimed;      // laggards-first discipline: tasks claimed so far (all disciplines end with `total` tasks handed out)
+};
+struct DfArgs {
+  DfCtl* ctl;
+  unsigned* queue;             // [S*nsb] task ids (stream*nsb + sb), 0xffffffff = not filled yet
+  unsigned* cnt;               // [S*nsb] finished-dependency counters
+  uint8_t* pool;               // one BigWs scratch slot per wavefront
+  size_t slot_bytes;
+  unsigned long long* times;   // optional [S*nsb][3] pop/start/end wall clock (100 MHz)
+  int S, nsb, cols, rows;
+  unsigned long long spin_limit;  // wall-clock ticks a workgroup may wait
+  // laggards first: nb buckets (0 = FIFO discipline); bq[2b] = tasks claimed from bucket b, bq[2b+1] = tasks pushed to it
+  int nb;
+  unsigned* bq;
+  const unsigned* bbase;       // [nb+1] first queue slot of every bucket
+};
+static const unsigned kDfEmpty = 0xffffffffu;
+
+// Number of buckets of a rows x cols superblock grid and the bucket of SB(k,l).
+DF_HD int df_num_buckets(int rows, int cols) { return cols + 2 * (rows - 1); }
+DF_HD int df_bucket(int k, int l) { return l + 2 * k; }
+
+// Wait until `slot` holds a task id.  Polls with RELAXED agent-scope loads: an acquire load in the loop would issue a
+// buffer_inv (a whole-L2 invalidate on this XCD) per poll and starve every working wavefront; the single acquire fence the
+// caller executes afterwards orders the dependent reads.  kDfEmpty: another workgroup reported an error, or the wait limit.
+DF_FN unsigned df_wait_slot(const DfArgs& A, unsigned slot) {
+  const unsigned long long t0 = df_clock();
+  unsigned n = 0, v;
+  while ((v = DF_LOAD(&A.queue[slot])) == kDfEmpty) {
+    DF_BACKOFF();
+    if ((++n & 63u) == 0) {
+      if (DF_LOAD(&A.ctl->error)) return kDfEmpty;
+      if (df_clock() - t0 > A.spin_limit) { DF_EXCHANGE(&A.ctl->error, 1u); return kDfEmpty; }
+    }
+  }
+  return v;
+}
+
+// Task `id` = SB(k,l) of some stream has become ready.
+DF_FN void df_push(const DfArgs& A, unsigned id, int k, int l) {
+  if (A.nb) {
+    const unsigned b = (unsigned)df_bucket(k, l);
+    const unsigned p = DF_ADD(&A.bq[2 * b + 1], 1u);
+    DF_STORE_RELEASE(&A.queue[A.bbase[b] + p], id);
+  } else {
+    const unsigned p = DF_ADD(&A.ctl->tail, 1u);
+    DF_STORE_RELEASE(&A.queue[p], id);
+  }
+}
+
+// A dependency of SB(k,l) of the stream whose tasks start at `base` has finished.
+DF_FN void df_done_dep(const DfArgs& A, unsigned base, int k, int l) {
+  const unsigned id = base + (unsigned)(k * A.cols + l);
+  const unsigned need = (l > 0 ? 1u : 0u) + (k > 0 ? 1u : 0u);
+  const unsigned old = DF_ADD_ACQ_REL(&A.cnt[id], 1u);
+  if (old + 1 == need) df_push(A, id, k, l);
+}
+
+// SB(k,l) of the stream whose tasks start at `base` has finished: release its successors.
+DF_FN void df_finish(const DfArgs& A, unsigned base, int k, int l) {
+  if (l + 1 < A.cols) df_done_dep(A, base, k, l + 1);               // right neighbour: its left dependency
+  if (k + 1 < A.rows) {
+    if (l >= 1) df_done_dep(A, base, k + 1, l - 1);                 // down-left: its up-right dependency
+    if (l == A.cols - 1) df_done_dep(A, base, k + 1, l);            // last column: the SB below uses (k,l) as "up-right"
+  }
+}
+
+// Next task for an idle workgroup (called by ONE thread of it), kDfEmpty when every task of the frame has been handed out
+// (or on error).  `lo`: per-workgroup state of the laggards-first discipline (lowest bucket that may still hold tasks; start 0).
+DF_FN unsigned df_next(const DfArgs& A, unsigned total, unsigned& lo) {
+  if (!A.nb) {
+    const unsigned slot = DF_ADD(&A.ctl->head, 1u);
+    return slot < total ? df_wait_slot(A, slot) : kDfEmpty;
+  }
+  const unsigned long long t0 = df_clock();
+  unsigned n = 0;
+  for (;;) {
+    if (DF_LOAD(&A.ctl->claimed) >= total) return kDfEmpty;
+    for (unsigned b = lo; b < (unsigned)A.nb; b++) {
+      const unsigned cap = A.bbase[b + 1] - A.bbase[b];
+      unsigned h = DF_LOAD(&A.bq[2 * b]);
+      if (h >= cap) {              // every task of this bucket has been claimed
+        if (b == lo) lo = b + 1;
+        continue;
+      }
+      const unsigned t = DF_LOAD(&A.bq[2 * b + 1]);
+      while (h < t) {              // a pushed task nobody has claimed yet: claim slot h (a failed CAS reloads h)
+        if (DF_CAS(&A.bq[2 * b], h, h + 1u)) {
+          DF_ADD(&A.ctl->claimed, 1u);
+          return df_wait_slot(A, A.bbase[b] + h);   // the pusher took its ticket before it filled the slot: a short wait at most
+        }
+      }
+    }
+    DF_BACKOFF();
+    if ((++n & 63u) == 0) {
+      if (DF_LOAD(&A.ctl->error)) return kDfEmpty;
+      if (df_clock() - t0 > A.spin_limit) { DF_EXCHANGE(&A.ctl->error, 1u); return kDfEmpty; }
+    }
+  }
+}
+
+}  // namespace tk
