@@ -1203,7 +1203,7 @@ TK_DEVNI void md_item_bipred(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>&
   }
 }
 
-// MD_REF: the motion searches of one reference (encode_block.c:2011-2034) - partition after partition, each one seeded by
+// MD_REF: the motion searches of one reference (encode_block.c:1966-1984) - partition after partition, each one seeded by
 // the candidates the earlier ones left in mvcand[r].  The vectors of a partition are published as soon as it is searched.
 template <typename PIX, int SP>
 TK_DEVNI void md_item_ref(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& M, int r) {
@@ -1231,7 +1231,7 @@ TK_DEVNI void md_item_ref(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& M,
   }
 }
 
-// MD_TRIAL: the RDO trials of one (reference, partition): tb_param -1 (no residual), 0 and 1 share one prediction.
+// MD_TRIAL: the RDO trials of one (reference, partition) (encode_block.c:1993-2012): tb_param -1 (no residual), 0 and 1 share one prediction.
 template <typename PIX, int SP>
 TK_DEVNI void md_item_trial(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& M, int r, int part) {
   const auto& c = J.cfg;
