@@ -4,7 +4,8 @@
 #   r3final = 1fc3cf8 (last library measured on the MI355X: 93.2 Mpx/s driver regime), es = + early-skip reuse (29ce444),
 #   split = + search / trial queue items, dd = + no vector evaluated twice (HEAD).
 # Build the variants in the container first (the libraries travel with the snapshot):
-#   scripts/build_at_commit.sh 1fc3cf8 r3final; scripts/build_at_commit.sh 29ce444 es; scripts/build_at_commit.sh <split commit> split
+#   scripts/build_at_commit.sh 1fc3cf8 r3final; scripts/build_at_commit.sh 29ce444 es; scripts/build_at_commit.sh bf8d06b split
+#   scripts/build_variant.sh prof -DTHOR_PROF        (phase profile of HEAD, last step of this script)
 R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -31,3 +32,10 @@ for q in fifo lag; do
   THOR_SCHED=$q timeout 500 python bench.py --warmup 5 --steps 2 --no-verify --no-cpu-baseline > $O/r4c1_sched_$q.log 2>&1
   echo "sched $q: $(grep -o '"value": [0-9.]*' $O/r4c1_sched_$q.log | head -1) $(grep -o '"ms_per_step": [0-9.]*' $O/r4c1_sched_$q.log)"
 done
+# phase profile of HEAD (the shares in DESIGN 8 predate the round-3 end changes)
+if [ -f $R/thor_amd/libthor_hip_prof.so ]; then
+  mkdir -p /tmp/w; python3 -m thor_amd.synth /tmp/w/hd.yuv 1920 1080 7 2
+  gcc -O2 -std=c99 -D_POSIX_C_SOURCE=200809L -o /tmp/w/thorenc_prof tools/thorenc_hip.c -Lthor_amd -l:libthor_hip_prof.so -Wl,-rpath,$R/thor_amd
+  THOR_PROF=1 timeout 300 /tmp/w/thorenc_prof -cf $R/configs/ldb_high_efficiency.cfg -if /tmp/w/hd.yuv -width 1920 -height 1080 -qp 32 -f 30 -n 6 -streams 128 -wrap 7 > $O/r4c1_prof.log 2>&1
+  echo "prof rc=$?"; grep -v "^[WIE]2026" $O/r4c1_prof.log | tail -36
+fi
