@@ -26,6 +26,7 @@
 #include <time.h>
 #define DF_FN static inline
 #define DF_HD static inline
+#define DF_FN_NOINLINE static
 // (acquire loads instead of relaxed loads + the fence the kernel executes after the pop: ThreadSanitizer does not model fences)
 #define DF_LOAD(p) __atomic_load_n((p), __ATOMIC_ACQUIRE)
 #define DF_ADD(p, v) __atomic_fetch_add((p), (v), __ATOMIC_RELAXED)
@@ -42,6 +43,8 @@ static inline unsigned long long df_clock() {  // 100 MHz ticks like the device'
 #else
 #define DF_FN __device__ inline
 #define DF_HD __host__ __device__ inline
+// out of line: the claim loop must not add to the register pressure of the kernel body it is called from (once per superblock)
+#define DF_FN_NOINLINE __device__ __noinline__
 #define DF_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define DF_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define DF_ADD_ACQ_REL(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
@@ -126,13 +129,9 @@ DF_FN void df_finish(const DfArgs& A, unsigned base, int k, int l) {
   }
 }
 
-// Next task for an idle workgroup (called by ONE thread of it), kDfEmpty when every task of the frame has been handed out
-// (or on error).  `lo`: per-workgroup state of the laggards-first discipline (lowest bucket that may still hold tasks; start 0).
-DF_FN unsigned df_next(const DfArgs& A, unsigned total, unsigned& lo) {
-  if (!A.nb) {
-    const unsigned slot = DF_ADD(&A.ctl->head, 1u);
-    return slot < total ? df_wait_slot(A, slot) : kDfEmpty;
-  }
+// Laggards-first discipline: claim from the lowest bucket that has an unclaimed pushed task.  `lo`: lowest bucket that may
+// still hold tasks (per-workgroup state, starts at 0).
+DF_FN_NOINLINE unsigned df_next_lag(const DfArgs& A, unsigned total, unsigned& lo) {
   const unsigned long long t0 = df_clock();
   unsigned n = 0;
   for (;;) {
@@ -158,6 +157,14 @@ DF_FN unsigned df_next(const DfArgs& A, unsigned total, unsigned& lo) {
       if (df_clock() - t0 > A.spin_limit) { DF_EXCHANGE(&A.ctl->error, 1u); return kDfEmpty; }
     }
   }
+}
+
+// Next task for an idle workgroup (called by ONE thread of it), kDfEmpty when every task of the frame has been handed out
+// (or on error).  `lo`: per-workgroup state of the laggards-first discipline (start 0).
+DF_FN unsigned df_next(const DfArgs& A, unsigned total, unsigned& lo) {
+  if (A.nb) return df_next_lag(A, total, lo);
+  const unsigned slot = DF_ADD(&A.ctl->head, 1u);
+  return slot < total ? df_wait_slot(A, slot) : kDfEmpty;
 }
 
 }  // namespace tk
