@@ -301,7 +301,7 @@ template void run_make_ref<uint16_t>(const FrameJob<uint16_t>*, const Plane3<uin
 
 namespace tk { long long g_prune_stat[8]; }
 int main(int argc, char** argv) {
-  struct R { ~R() { if (getenv("THOR_PRUNE_STAT")) fprintf(stderr, "prune: intra %lld/%lld inter %lld/%lld quadrant checks %lld early %lld at-4th %lld\n", tk::g_prune_stat[1], tk::g_prune_stat[0], tk::g_prune_stat[3], tk::g_prune_stat[2], tk::g_prune_stat[4], tk::g_prune_stat[5], tk::g_prune_stat[6]); } } r_;
+  struct R { ~R() { if (getenv("THOR_PRUNE_STAT")) fprintf(stderr, "prune: intra %lld/%lld inter %lld/%lld quadrant checks %lld early %lld at-4th %lld at-entry %lld\n", tk::g_prune_stat[1], tk::g_prune_stat[0], tk::g_prune_stat[3], tk::g_prune_stat[2], tk::g_prune_stat[4], tk::g_prune_stat[5], tk::g_prune_stat[6], tk::g_prune_stat[7]); } } r_;
   tk::init_tables(&tk::g_tab);
   tk::CliArgs a = tk::cli_parse(argc, argv);
   if (a.sp.bitdepth != a.sp.input_bitdepth) { fprintf(stderr, "bitdepth != input_bitdepth is not supported\n"); return 2; }

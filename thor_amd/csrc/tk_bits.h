@@ -352,25 +352,12 @@ TK_DEV BlkParam uniform_blk(const BlkParam& a) {
   return u;
 }
 
-// E = false: cooperative counting (every lane of the team calls, b.emit == 0, tm != nullptr) - the instance all RDO trials
-// use; E = true: emission by ONE lane (or serial counting when tm == nullptr).
-// SCC: address space of the CHROMA coefficient buffers in counting mode (luma is always SP_LDS on the device).
-template <bool E, int SCC = SP_LDS>
-TK_DEVNI int bs_block_t(BitSink& b, const SynCtx& s_in, const BlkParam& p_in, const int16_t* cy, const int16_t* cu,
-                    const int16_t* cv, const Team* tm, const int* ybits) {
-  // only in cooperative counting mode: the emitting call is made by one lane alone
-  const bool coop = !E;
-  const SynCtx s = coop ? uniform_syn(s_in) : s_in;
-  const BlkParam p = coop ? uniform_blk(p_in) : p_in;
-  const int start = b.pos;
-  const int size = s.size, size_uv = size >> 1;
+// The part of write_block that does not depend on the residual: super-mode, intra mode / partition and vector differences /
+// candidate index (enc/write_bits.c:360-470).  bs_block_t starts with it; the RDO trials use its length as the first term of
+// their lower bounds (tk_block.h: PruneCtx::head_bits).
+template <bool E> TK_DEV void bs_block_head_t(BitSink& b, const SynCtx& s, const BlkParam& p) {
   const int mode = p.mode;
-  const int coeff_type = (mode == M_INTRA) << 1;
-  // coefficient offset of TU t of a tb-split block: t * qs^2, qs = min(TU size, 16)
-  const int qy = size / 2 < kMaxQuant ? size / 2 : kMaxQuant, qc = size_uv / 2 < kMaxQuant ? size_uv / 2 : kMaxQuant;
-  const int sty = qy * qy, stc = qc * qc;
   bs_super_mode_t<E>(b, s, mode, p.ref0, 0);
-
   if (mode == M_INTRA) {
     if (s.num_intra_modes <= 4) bs_put_t<E>(b, 2, (uint32_t)p.intra_mode);
     else bs_vlc_t<E>(b, 8, (uint32_t)p.intra_mode);
@@ -403,6 +390,26 @@ TK_DEVNI int bs_block_t(BitSink& b, const SynCtx& s_in, const BlkParam& p_in, co
     else if (nvec == 3) bs_vlc_t<E>(b, 12, (uint32_t)p.skip_idx);
     else if (nvec == 2) bs_put_t<E>(b, 1, (uint32_t)p.skip_idx);
   }
+}
+
+// E = false: cooperative counting (every lane of the team calls, b.emit == 0, tm != nullptr) - the instance all RDO trials
+// use; E = true: emission by ONE lane (or serial counting when tm == nullptr).
+// SCC: address space of the CHROMA coefficient buffers in counting mode (luma is always SP_LDS on the device).
+template <bool E, int SCC = SP_LDS>
+TK_DEVNI int bs_block_t(BitSink& b, const SynCtx& s_in, const BlkParam& p_in, const int16_t* cy, const int16_t* cu,
+                    const int16_t* cv, const Team* tm, const int* ybits) {
+  // only in cooperative counting mode: the emitting call is made by one lane alone
+  const bool coop = !E;
+  const SynCtx s = coop ? uniform_syn(s_in) : s_in;
+  const BlkParam p = coop ? uniform_blk(p_in) : p_in;
+  const int start = b.pos;
+  const int size = s.size, size_uv = size >> 1;
+  const int mode = p.mode;
+  const int coeff_type = (mode == M_INTRA) << 1;
+  // coefficient offset of TU t of a tb-split block: t * qs^2, qs = min(TU size, 16)
+  const int qy = size / 2 < kMaxQuant ? size / 2 : kMaxQuant, qc = size_uv / 2 < kMaxQuant ? size_uv / 2 : kMaxQuant;
+  const int sty = qy * qy, stc = qc * qc;
+  bs_block_head_t<E>(b, s, p);
 
   if (mode != M_SKIP) {
     const int tb_split = p.tb_split;

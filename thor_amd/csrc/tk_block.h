@@ -487,6 +487,7 @@ struct PruneCtx {
   int pruned;         // out
   long long ssd_part; // tb-split luma: SSD / bits of the quadrants coded so far
   int bits_part;
+  int head_bits;      // bits of the trial that do not depend on its residual (tk_bits.h:bs_block_head_t): part of every bound
 };
 
 // tb-split luma: call after quadrant `tu` (0..3, size s2 at (i,j) of the block) has been coded.  The first three
@@ -506,7 +507,7 @@ TK_DEV int prune_after_quadrant(const Team t, JobR<PIX> J, WsP<PIX> ws, int nd_s
   pc->ybits[tu] = bit ? coeff_bits_team<SP_LDS>(t, coef, s2, intra << 1) : 0;  // luma coefficients: always SmallWs (LDS)
   pc->bits_part += pc->ybits[tu];
   if (tu == 3) { pc->ssd_y = pc->ssd_part; pc->have_ybits = 1; }
-  unsigned long long lb = ((unsigned long long)pc->ssd_part >> (J.cfg.bitdepth * 2 - 16)) + (unsigned long long)(long long)mul_add_nofma(pc->lambda, (double)pc->bits_part, 0.5);
+  unsigned long long lb = ((unsigned long long)pc->ssd_part >> (J.cfg.bitdepth * 2 - 16)) + (unsigned long long)(long long)mul_add_nofma(pc->lambda, (double)(pc->bits_part + pc->head_bits), 0.5);
   if (lb > (1ull << 30)) lb = 1ull << 30;
 #if TK_HOST
   { extern long long g_prune_stat[8]; g_prune_stat[4] += 1; if (prune_hit(pc, lb)) g_prune_stat[5 + (tu == 3)] += 1; }
@@ -537,7 +538,7 @@ TK_DEV int prune_after_luma(const Team t, JobR<PIX> J, WsP<PIX> ws, int size, in
     }
   }
   pc->have_ybits = 1;
-  unsigned long long lb = (ssd >> (J.cfg.bitdepth * 2 - 16)) + (unsigned long long)(long long)mul_add_nofma(pc->lambda, (double)bits, 0.5);
+  unsigned long long lb = (ssd >> (J.cfg.bitdepth * 2 - 16)) + (unsigned long long)(long long)mul_add_nofma(pc->lambda, (double)(bits + pc->head_bits), 0.5);
   if (lb > (1ull << 30)) lb = 1ull << 30;
 #if TK_HOST
   { extern long long g_prune_stat[8]; g_prune_stat[p.mode == M_INTRA ? 0 : 2] += 1; if (prune_hit(pc, lb)) g_prune_stat[p.mode == M_INTRA ? 1 : 3] += 1; }
@@ -711,11 +712,30 @@ TK_DEVNI int encode_block(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd_, Blk
 template <typename PIX, int SP>
 TK_DEV unsigned rdo_trial(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd, BlkParam& p, double lambda,
                           int reuse_pred = 0, unsigned prune_thr = 0xffffffffu, const unsigned long long* bestkey = nullptr,
-                          unsigned order = 0, int* nbits_out = nullptr) {
+                          unsigned order = 0, int* nbits_out = nullptr, int* untouched = nullptr) {
   BitSink cnt;
   cnt.buf = nullptr; cnt.pos = 0; cnt.cap = 0; cnt.emit = 0; cnt.ovf = 0;
   PruneCtx pc;
   pc.thr = prune_thr; pc.bestkey = bestkey; pc.order = order; pc.lambda = lambda; pc.ssd_y = -1; pc.have_ybits = 0; pc.pruned = 0; pc.ssd_part = 0; pc.bits_part = 0;
+  pc.head_bits = 0;
+  if (bestkey) {
+    // Parallel decision: the bits that do not depend on the residual (super-mode, partition, vector differences, intra mode,
+    // candidate index) are known before anything is predicted or transformed, and the cost is monotone in every term: a trial
+    // whose key with SSD = 0 and no other bits already exceeds the shared minimum is dropped before it starts (`untouched`:
+    // the prediction buffers still hold what they held), and the later bounds (luma coded) start from these bits.
+    BitSink hb = cnt;
+    bs_block_head_t<false>(hb, uniform_syn(lds_ld(&nd.syn)), uniform_blk(p));
+    pc.head_bits = hb.pos;
+    unsigned long long lb0 = (unsigned long long)(long long)mul_add_nofma(lambda, (double)hb.pos, 0.5);
+    if (lb0 > (1ull << 30)) lb0 = 1ull << 30;
+#if TK_HOST
+    { extern long long g_prune_stat[8]; g_prune_stat[7] += prune_hit(&pc, lb0); }
+#endif
+    if (team_bcast0(t, prune_hit(&pc, lb0))) {
+      if (untouched) *untouched = 1;
+      return kCostInit;
+    }
+  }
   int nbits = encode_block<PIX, SP>(t, J, ws, nd, p, cnt, reuse_pred, &pc);
   if (nbits_out) *nbits_out = nbits;
   if (pc.pruned) return kCostInit;  // lower bound >= threshold: cannot be selected
@@ -1144,10 +1164,12 @@ template <typename PIX> struct MdCtx {
   unsigned long long mykey;  // best key among this wave's trials
 };
 
+// Returns 0 when the trial was dropped before it touched the prediction buffers (rdo_trial: `untouched`), 1 otherwise.
 template <typename PIX, int SP>
-TK_DEV void par_trial(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& M, BlkParam& p, unsigned order, int reuse_pred) {
-  const unsigned cost = rdo_trial<PIX, SP>(t, J, ws, *M.nd, p, J.lambda, reuse_pred, 0xffffffffu, &M.sh->bestkey, order);
-  if (cost == (unsigned)kCostInit) return;  // pruned: cannot have the smallest key
+TK_DEV int par_trial(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& M, BlkParam& p, unsigned order, int reuse_pred) {
+  int untouched = 0;
+  const unsigned cost = rdo_trial<PIX, SP>(t, J, ws, *M.nd, p, J.lambda, reuse_pred, 0xffffffffu, &M.sh->bestkey, order, nullptr, &untouched);
+  if (cost == (unsigned)kCostInit) return !untouched;  // pruned: cannot have the smallest key
   const unsigned long long key = ((unsigned long long)cost << 32) | order;
   if (key < M.mykey) {
     M.mykey = key;
@@ -1159,6 +1181,7 @@ TK_DEV void par_trial(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& M, Blk
     snapshot_trial<PIX, SP>(t, ws, tk_uniform(ldsc(M.nd)->size), p);
     t.sync();
   }
+  return 1;
 }
 
 template <typename PIX, int SP>
@@ -1179,9 +1202,9 @@ TK_DEVNI void md_item_bipred(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>&
   p.mode = M_BIPRED; p.pb_part = P_NONE;
   p.ref0 = (int8_t)r0; p.ref1 = (int8_t)r1;
   for (int i = 0; i < 4; i++) { p.mv0[i] = a0[i]; p.mv1[i] = a1[i]; }
-  for (int tb = 0; tb <= max_tb - 1; tb++) {
+  for (int tb = 0, have_pred = 0; tb <= max_tb - 1; tb++) {
     p.tb_param = (int8_t)tb;
-    par_trial<PIX, SP>(t, J, ws, M, p, 54u + (unsigned)tb, tb > 0);
+    have_pred |= par_trial<PIX, SP>(t, J, ws, M, p, 54u + (unsigned)tb, have_pred);
   }
   if (J.frame_type == F_B) {
     // joint +mv / -mv search (search_bipred_prediction_params me_mode 1, encode_block.c:1708-1737, 2052-2068)
@@ -1262,9 +1285,9 @@ TK_DEVNI void md_item_trial(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& 
   p.ref0 = p.ref1 = (int8_t)r;
   p.pb_part = (int8_t)part;
   for (int i = 0; i < 4; i++) { p.mv0[i] = mv_all[part][i]; p.mv1[i] = mv_all[part][i]; }
-  for (int tb = -1; tb <= max_tb - 1; tb++) {
+  for (int tb = -1, have_pred = 0; tb <= max_tb - 1; tb++) {
     p.tb_param = (int8_t)tb;
-    par_trial<PIX, SP>(t, J, ws, M, p, 6u + 12u * (unsigned)r + 3u * (unsigned)part + (unsigned)(tb + 1), tb > -1);
+    have_pred |= par_trial<PIX, SP>(t, J, ws, M, p, 6u + 12u * (unsigned)r + 3u * (unsigned)part + (unsigned)(tb + 1), have_pred);
   }
 }
 
@@ -1388,9 +1411,9 @@ TK_DEVNI void md_worker_sp(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws) 
     } else if (kind == MD_MERGE) {
       BlkParam p = blank_param();
       set_cand(p, lds_ld(&M.nd->merge[ia]), ia, M_MERGE);
-      for (int tb = 0; tb <= max_tb - 1; tb++) {
+      for (int tb = 0, have_pred = 0; tb <= max_tb - 1; tb++) {
         p.tb_param = (int8_t)tb;
-        par_trial<PIX, SP>(t, J, ws, M, p, 2u + 2u * (unsigned)ia + (unsigned)tb, tb > 0);
+        have_pred |= par_trial<PIX, SP>(t, J, ws, M, p, 2u + 2u * (unsigned)ia + (unsigned)tb, have_pred);
       }
     } else if (kind == MD_INTRA) {
       BlkParam p = blank_param();
