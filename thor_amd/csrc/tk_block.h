@@ -718,11 +718,13 @@ TK_DEV unsigned rdo_trial(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd, BlkP
   PruneCtx pc;
   pc.thr = prune_thr; pc.bestkey = bestkey; pc.order = order; pc.lambda = lambda; pc.ssd_y = -1; pc.have_ybits = 0; pc.pruned = 0; pc.ssd_part = 0; pc.bits_part = 0;
   pc.head_bits = 0;
-  if (bestkey) {
-    // Parallel decision: the bits that do not depend on the residual (super-mode, partition, vector differences, intra mode,
-    // candidate index) are known before anything is predicted or transformed, and the cost is monotone in every term: a trial
-    // whose key with SSD = 0 and no other bits already exceeds the shared minimum is dropped before it starts (`untouched`:
-    // the prediction buffers still hold what they held), and the later bounds (luma coded) start from these bits.
+  if (bestkey || prune_thr != 0xffffffffu) {
+    // The bits that do not depend on the residual (super-mode, partition, vector differences, intra mode, candidate index) are
+    // known before anything is predicted or transformed, and the cost is monotone in every term: a trial whose bound with
+    // SSD = 0 and no other bits already reaches the threshold / exceeds the shared minimum is dropped before it starts
+    // (`untouched`: the prediction buffers still hold what they held), and the later bounds (luma coded) start from these
+    // bits.  (A later trial of the same candidate has the same header bits against a threshold that has not grown: it is
+    // dropped the same way and never asks for the prediction an earlier one did not build.)
     BitSink hb = cnt;
     bs_block_head_t<false>(hb, uniform_syn(lds_ld(&nd.syn)), uniform_blk(p));
     pc.head_bits = hb.pos;
