@@ -525,6 +525,18 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
   // same way); a hexagon refinement that starts on the centre of the last grid would only revisit it and is skipped.
   mv_t g_ctr = mk_mv(0, 0);
   int g_step = 0;   // spacing of the last telescope grid evaluated (0: none)
+  // all four grids, for candidates that are not grid points themselves (the per-SB candidate list): a list entry that lies on
+  // any of them has been evaluated
+  mv_t gc32 = mk_mv(0, 0), gc16 = mk_mv(0, 0), gc8 = mk_mv(0, 0);   // centres of the grids of step 32, 16, 8 (step 4: g_ctr); named
+                                                                      // scalars, not an array: nothing here is indexed at run time
+  auto on_grid_of = [&](mv_t m, mv_t ctr, int gs) -> int {
+    const int dx = m.x - ctr.x, dy = m.y - ctr.y;
+    return !((dx | dy) & (gs - 1)) && iabs(dx) <= 2 * gs && iabs(dy) <= 2 * gs;
+  };
+  auto on_any_grid = [&](mv_t m) -> int {
+    // g_step == 4: the telescope has run (all four steps, encoder_speed 0) - the four centres are this search's
+    return g_step == 4 && (on_grid_of(m, gc32, 32) | on_grid_of(m, gc16, 16) | on_grid_of(m, gc8, 8) | on_grid_of(m, g_ctr, 4));
+  };
   auto on_grid = [&](mv_t m) -> int {
     const int dx = m.x - g_ctr.x, dy = m.y - g_ctr.y;
     return g_step && !((dx | dy) & (g_step - 1)) && iabs(dx) <= 2 * g_step && iabs(dy) <= 2 * g_step;
@@ -574,6 +586,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
       if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = tele((int)(unsigned)k).mv; }
     }
     g_ctr = centre; g_step = a.speed == 0 ? step : 0;
+    if (step == 32) gc32 = centre; else if (step == 16) gc16 = centre; else if (step == 8) gc8 = centre;
     mv_ref = mv_opt;
   }
 
@@ -596,12 +609,28 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
         if ((unsigned)(bestk >> 32) < min_sad) { min_sad = (unsigned)(bestk >> 32); mv_opt = cmv_get((int)(unsigned)bestk); }
         t.sync();
       } else {
-        // candidates that lie on the last telescope grid have been evaluated (see on_grid): a list of nothing else is skipped
-        int fresh = 0;
-        for (int c = t.rank; c < n; c += t.size) fresh |= !on_grid(cmv_get(c));
-        if (team_ballot(t, fresh) != 0ull) {
+        // Entries that lie on one of the telescope grids have been evaluated (a clipped vector that coincides with a grid point
+        // was evaluated as itself: clip_mv is idempotent): the list - previous results of this superblock, clustered around the
+        // motion the telescope has just walked to - is compacted in place to the others, in list order (45-56 % go on the test
+        // content); nothing left: no pass.
+        int cnt = n;
+        if (a.speed == 0) {
+          cnt = 0;
+          for (int c0 = 0; c0 < n; c0 += t.size) {
+            const int c = c0 + t.rank;
+            const mv_t m = cmv_get(c < n ? c : 0);
+            const int keep = c < n && !on_any_grid(m);
+            const unsigned long long mask = team_ballot(t, keep);
+            t.sync();   // every lane holds its entry before lower slots are rewritten
+            if (keep) cmv_set(cnt + __builtin_popcountll(mask & ((1ull << t.rank) - 1ull)), m);
+            cnt += __builtin_popcountll(mask);
+          }
+          t.sync();
+          cnt = TKU(cnt);
+        }
+        if (cnt > 0) {
           auto cl = [&](int c) -> FP { return mk_fp(cmv_get(c), 1); };  // cmv already clipped (clip_mv is idempotent)
-          unsigned long long k = eval_fullpel<SP>(t, n, org, a.ostride, a.rstride, a.width, a.height, win, cl, fp_cost);
+          unsigned long long k = eval_fullpel<SP>(t, cnt, org, a.ostride, a.rstride, a.width, a.height, win, cl, fp_cost);
           if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = cmv_get((int)(unsigned)k); }
         }
         t.sync();
