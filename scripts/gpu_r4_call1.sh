@@ -1,10 +1,11 @@
 #!/bin/bash
 # round 4, call 1 (prepared at the end of round 3, whose GPU budget was spent before these changes existed): parity and A/B of the
-# three exact work-avoidance / scheduling steps that were verified in the host simulations only -
+# exact work-avoidance / scheduling steps that were verified in the host simulations only -
 #   r3final = 1fc3cf8 (last library measured on the MI355X: 93.2 Mpx/s driver regime), es = + early-skip reuse (29ce444),
-#   split = + search / trial queue items, dd = + no vector evaluated twice, head = + header bits in every pruning bound (HEAD).
+#   split = + search / trial queue items, dd = + no vector evaluated twice (telescope / hexagon), hb = + header bits in every pruning
+#   bound, head = + candidate-list compaction (HEAD).
 # Build the variants in the container first (the libraries travel with the snapshot):
-#   scripts/build_at_commit.sh 1fc3cf8 r3final; scripts/build_at_commit.sh 29ce444 es; scripts/build_at_commit.sh bf8d06b split; scripts/build_at_commit.sh 395596c dd
+#   scripts/build_at_commit.sh 1fc3cf8 r3final; scripts/build_at_commit.sh 29ce444 es; scripts/build_at_commit.sh bf8d06b split; scripts/build_at_commit.sh 395596c dd; scripts/build_at_commit.sh 8062e71 hb
 #   scripts/build_variant.sh prof -DTHOR_PROF        (phase profile of HEAD, last step of this script)
 R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
 export TMPDIR=/tmp
@@ -18,7 +19,7 @@ ab() {
   THOR_HIP_LIB=$lib timeout 300 python bench.py --width 1920 --height 1080 --streams 128 --warmup 4 --steps 2 --no-verify --no-cpu-baseline > $O/r4c1_ab_$tag.log 2>&1
   echo "ab $tag: $(grep -o '"value": [0-9.]*' $O/r4c1_ab_$tag.log | head -1) $(grep -o '"ms_per_step": [0-9.]*' $O/r4c1_ab_$tag.log)"
 }
-ab r3final; ab es; ab split; ab dd; ab head
+ab r3final; ab es; ab split; ab dd; ab hb; ab head
 abra() {
   tag=$1; lib=$R/thor_amd/libthor_hip_$tag.so; [ "$tag" = head ] && lib=$R/thor_amd/libthor_hip.so
   [ -f $lib ] || return
