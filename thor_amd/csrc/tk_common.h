@@ -180,6 +180,15 @@ TK_DEV void wg_pause() {
   __builtin_amdgcn_s_sleep(8);
 #endif
 }
+// A wait on another wave that cannot end (a protocol error): stop the kernel / the simulation loudly instead of spinning for ever.
+TK_DEV void wg_wait_failed() {
+#if TK_HOST
+  fprintf(stderr, "thor: a wavefront waited for another one for ever\n");
+  abort();
+#else
+  __builtin_trap();
+#endif
+}
 TK_DEV unsigned long long wg_load64(const unsigned long long* p) {
 #if TK_HOST
   return __atomic_load_n(p, __ATOMIC_RELAXED);
