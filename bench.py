@@ -48,6 +48,7 @@ CONFIGS = {  # operating points of BASELINE.json: config file, default qp
 }
 REF_ENC = os.path.join(ROOT, 'oracle', '_ref', 'Thorenc')
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+PMC_JSON = 'r04_pmc_bench.json'
 # v_sad_u8: 4 sample differences per lane and instruction, 64 lanes, one wave64 VALU instruction per 4 clocks and SIMD,
 # 1024 SIMDs at 2.4 GHz (MI355X_MICROARCH.md) -> pixel-differences per second the chip could accumulate
 SAD_PEAK_PXOPS = 1024 * 2.4e9 / 4 * 64 * 4
@@ -150,25 +151,46 @@ def stream_prefix(bits, nframes):
 
 
 # ---- CPU legs: the checker and the reported baseline (host processes, started BEFORE the timed region) ------------
+def csrc_digest():
+    """sha1 over the engine sources (thor_amd/csrc/*, include/*): identifies the library a profile was taken from (the GPU box
+    has no .git; scripts/pmc_summary.py stamps the same digest into the PMC summaries bench.py reads)."""
+    hsh = hashlib.sha1()
+    for d in ('thor_amd/csrc', 'include'):
+        for f in sorted(os.listdir(os.path.join(ROOT, d))):
+            hsh.update(f.encode())
+            hsh.update(open(os.path.join(ROOT, d, f), 'rb').read())
+    return hsh.hexdigest()[:16]
+
+
 class CpuLegs:
     """Live runs of the reference encoder on host cores, one process per leg:
        'v<sid>'  stream sid, first nv coded frames, stream + reconstruction   (bit-exactness of the GPU path)
        'b'       stream of the first verify leg, nv - 1 frames                (1-core baseline: t[v] - t[b] = one frame at the
                                                                                benched geometry with every reference in use)
        'm<k>'    further streams, min(nv, 3) frames                           (N-process figure: N cores busy at once)
-    The legs run while the GPU encodes; collect() waits for them after the timed region."""
+    The legs run while the GPU encodes.  Every process has a reaper thread that blocks in wait4(): the leg's wall time ends
+    when the process EXITS (not when somebody polls it) and its CPU time (user + system, from the kernel's rusage) does not
+    depend on scheduling at all; collect() joins the reapers after the timed region."""
 
     def __init__(self, cfg_path, w, h, qp, extra, total_frames, reordered):
         self.cfg, self.w, self.h, self.qp, self.extra = cfg_path, w, h, qp, list(extra)
         self.total, self.reordered = total_frames, reordered
         self.dir = tempfile.TemporaryDirectory()
-        self.procs = []  # (tag, n, t0, Popen)
+        self.procs = []  # dicts: tag, n, t0, popen, thread, wall, cpu, rc
         self.ncores = os.cpu_count() or 1
 
     def available(self):
         return os.path.exists(REF_ENC)
 
+    @staticmethod
+    def _reap(it):
+        _, status, ru = os.wait4(it['popen'].pid, 0)
+        it['wall'] = time.perf_counter() - it['t0']
+        it['cpu'] = ru.ru_utime + ru.ru_stime
+        it['rc'] = os.waitstatus_to_exitcode(status)
+
     def start(self, tag, frames_bytes, n, with_rec):
+        import threading
         d = self.dir.name
         path = os.path.join(d, tag + '.yuv')
         if not os.path.exists(path):
@@ -179,22 +201,38 @@ class CpuLegs:
                '-n', str(n), '-f', '30', '-of', os.path.join(d, f'{tag}_{n}.bit')] + self.extra
         if with_rec:
             cmd += ['-rf', os.path.join(d, f'{tag}_{n}.yuv')]
-        self.procs.append([tag, n, time.perf_counter(), subprocess.Popen(cmd, stdout=subprocess.DEVNULL), None])
+        it = {'tag': tag, 'n': n, 't0': time.perf_counter(), 'popen': subprocess.Popen(cmd, stdout=subprocess.DEVNULL),
+              'wall': None, 'cpu': None, 'rc': None}
+        it['thread'] = threading.Thread(target=self._reap, args=(it,), daemon=True)
+        it['thread'].start()
+        self.procs.append(it)
 
     def collect(self):
-        pending = [p for p in self.procs if p[4] is None]
-        while pending:  # poll so that every process gets its own wall time
-            for it in list(pending):
-                if it[3].poll() is not None:
-                    if it[3].returncode != 0:
-                        raise RuntimeError(f'reference encoder failed ({it[0]})')
-                    it[4] = time.perf_counter() - it[2]
-                    pending.remove(it)
-            time.sleep(0.05)
-        return {(p[0], p[1]): p[4] for p in self.procs}
+        """-> {(tag, n): (wall seconds until exit, CPU seconds)}"""
+        for it in self.procs:
+            it['thread'].join()
+            if it['rc'] != 0:
+                raise RuntimeError(f"reference encoder failed ({it['tag']}, -n {it['n']}): exit code {it['rc']}")
+        return {(it['tag'], it['n']): (it['wall'], it['cpu']) for it in self.procs}
 
     def read(self, tag, n, what):
         return open(os.path.join(self.dir.name, f'{tag}_{n}.{what}'), 'rb').read()
+
+
+def one_frame_baseline(t_hi, t_lo, frame_px, what):
+    """1-core figure from two legs that differ by one coded frame: (wall, cpu) of the longer and the shorter run.  CPU seconds
+    (rusage) are the measure; the result must be a plausible single-core rate of this encoder - a difference that is not
+    (a leg timed when it was polled instead of when it ended, a leg that lost its core) is an ERROR, never a number."""
+    d_cpu, d_wall = t_hi[1] - t_lo[1], t_hi[0] - t_lo[0]
+    per_frame_lo = t_lo[1] / max(what['frames_lo'], 1)
+    if d_cpu <= 0 or d_cpu < 0.1 * per_frame_lo:
+        raise RuntimeError(f'cpu_baseline: the two reference legs differ by {d_cpu:.3f} CPU-seconds for one more frame '
+                           f'({t_hi[1]:.1f} s vs {t_lo[1]:.1f} s; the shorter run spends {per_frame_lo:.1f} s per frame): timing is broken')
+    v = frame_px / d_cpu / 1e6
+    if not 0.01 < v < 8.0:
+        raise RuntimeError(f'cpu_baseline: {v:.3f} Mpixels/s is not a single-core rate of the reference encoder '
+                           f'(t = {t_hi[1]:.2f} s - {t_lo[1]:.2f} s of CPU time)')
+    return v, d_cpu, d_wall
 
 
 def main():
@@ -293,35 +331,44 @@ def main():
         return torch.cat([Y.reshape(-1), U.reshape(-1), V.reshape(-1)])
 
     # ---- checker / CPU baseline: reference processes start NOW and run beside the GPU ------------------------------
-    nv = a.verify_frames if a.verify_frames is not None else max(a.warmup + 2, 7)
+    # Verified frames: at least I + the frames that fill the reference list + two timed frames (7 with the driver's flags);
+    # more when the reference legs can be expected to finish inside the GPU run anyway (one host core codes a frame of this
+    # geometry in ~w*h/0.33e6 s; the GPU run takes ~frames * w*h*S / 90e6 s): they cost no wall time.
+    nv = a.verify_frames
+    if nv is None:
+        nv = max(a.warmup + 2, 7)
+        t_cpu_frame = w * h / 0.33e6 * (1.3 if hbd else 1.0)
+        est_gpu_s = nframes * w * h * S / (90e6 if a.config == 'ldb' and not hbd else 40e6)
+        nv = max(nv, int(est_gpu_s / t_cpu_frame))
     nv = max(1, min(nv, nframes))
+    hq = int(p.HQperiod) if not reordered else 0
+    if hq > 1 and nv - 1 > 0 and (nv - 1) % hq == 0:   # the baseline frame (coded frame nv - 1) must not be a high-quality frame
+        nv = nv + 1 if nv + 1 <= nframes else nv - 1
     legs = CpuLegs(cfg_path, w, h, qp, ref_extra, nframes, reordered)
-    verify = {}        # local stream index -> [host frames, gpu bits, gpu recon of coded frame nv-1]
+    verify = {}        # local stream index -> [host frames, {coded frame: (display index, md5 of the GPU reconstruction)}]
     do_verify = rank == 0 and not a.no_verify and legs.available()
-    do_base = rank == 0 and not a.no_cpu_baseline and legs.available() and world == 1
+    do_base = rank == 0 and not a.no_cpu_baseline and legs.available()
     n_ref = nframes if reordered else nv   # with frame reordering the coding order depends on the chunk length: run it all
-    base_legs = []
     if rank == 0 and (do_verify or do_base):
-        vs = sorted({0, S - 1}) if do_verify else [0]
+        vs = sorted({0, S // 2, S - 1}) if do_verify else [0]
         for s in vs:
             fr = host_stream_frames(my_ids[s])
-            verify[s] = [fr, None, None]
-            if do_verify:
-                legs.start(f'v{my_ids[s]}', [x.tobytes() for x in fr[:n_ref]], n_ref, True)
-        if do_base and not reordered and nv >= 2:
+            verify[s] = [fr, {}]
+            if do_verify or s == vs[0]:
+                legs.start(f'v{my_ids[s]}', [x.tobytes() for x in fr[:n_ref]], n_ref, do_verify)
+        if do_base:
             s0 = vs[0]
-            if do_verify:
-                legs.start(f'v{my_ids[s0]}', None, nv - 1, False)
-            else:
-                legs.start(f'v{my_ids[s0]}', [x.tobytes() for x in verify[s0][0][:nv]], nv, False)
-                legs.start(f'v{my_ids[s0]}', None, nv - 1, False)
+            # second leg of the 1-core figure: one frame less (LDB: the difference is coded frame nv - 1 with every reference in
+            # use); with frame reordering the I frame alone (the difference is every other frame of the chunk)
+            n_lo = 1 if reordered else nv - 1
+            if n_lo >= 1 and n_lo < n_ref:
+                legs.start(f'v{my_ids[s0]}', None, n_lo, False)
             # N-process figure: fill the remaining host cores (one is left to this process) with further chunks
             nm = max(0, min(legs.ncores - 1, 8) - len(legs.procs))
-            km = min(nv, 3)
+            km = min(n_ref, 3)
             for k in range(nm):
                 sid = my_ids[(1 + k) % S]
                 legs.start(f'm{k}', [x.tobytes() for x in host_stream_frames(sid)[:km]], km, False)
-                base_legs.append((f'm{k}', km))
     if rank == 0 and verify:
         s_chk = sorted(verify)[-1]
         assert np.array_equal(dev_stream_frame(my_ids[s_chk], 0).cpu().numpy().view(np.uint8), verify[s_chk][0][0].view(np.uint8)), \
@@ -348,9 +395,9 @@ def main():
             idx = [coded[0]] * S
         enc.encode_staged(idx)      # blocks until all streams' bits are on the host
         coded[0] += 1
-        if do_verify and coded[0] == nv:
-            for s in verify:
-                verify[s][2] = (idx[s], enc.recon(s))   # (display index, samples) of coded frame nv-1
+        if do_verify and coded[0] <= nv:
+            for s in verify:   # reconstruction of every verified coded frame: (display index, md5)
+                verify[s][1][coded[0] - 1] = (idx[s], hashlib.md5(enc.recon(s).tobytes()).hexdigest())
 
     for _ in range(a.warmup):
         step()
@@ -400,36 +447,51 @@ def main():
             ok = True
             fbytes = fpx * bps
             for s in sorted(verify):
-                fr, _, rec = verify[s]
+                fr, recs = verify[s]
                 tag = f'v{my_ids[s]}'
                 rbits = legs.read(tag, n_ref, 'bit')
                 rrec = legs.read(tag, n_ref, 'yuv')
-                gbits = local_bits[s]
-                same = stream_prefix(gbits, nv) == stream_prefix(rbits, nv)
-                rec_ok = None
-                if rec is not None:
-                    di, px = rec   # the reference writes its reconstruction in DISPLAY order
-                    rec_ok = rrec[di * fbytes:(di + 1) * fbytes] == px.tobytes()
-                    same = same and rec_ok
+                gpre, rpre = stream_prefix(local_bits[s], nv), stream_prefix(rbits, nv)
+                same = gpre is not None and rpre is not None and gpre == rpre   # a stream with fewer than nv frames is a failure
+                rec_frames = []
+                for cf in sorted(recs):   # the reference writes its reconstruction in DISPLAY order
+                    di, md5 = recs[cf]
+                    r_ok = len(rrec) >= (di + 1) * fbytes and hashlib.md5(rrec[di * fbytes:(di + 1) * fbytes]).hexdigest() == md5
+                    rec_frames.append(cf)
+                    same = same and r_ok
                 res['checked'].append({'stream': my_ids[s], 'frames': nv, 'timed_frames_covered': max(0, nv - a.warmup),
-                                       'bitstream_bytes': len(stream_prefix(rbits, nv) or b''), 'recon_checked': rec_ok is not None, 'ok': bool(same)})
+                                       'timed_coded_frames_compared': list(range(a.warmup, nv)),
+                                       'bitstream_bytes': len(rpre or b''), 'recon_checked': bool(rec_frames),
+                                       'recon_coded_frames_compared': rec_frames, 'ok': bool(same)})
                 ok = ok and same
             res['bit_exact'] = bool(ok)
-        if do_base and not reordered and nv >= 2:
+            res['bit_exact_scope'] = (f'{len(verify)} of {S} streams (first, middle, last), coded frames 0..{nv - 1} of {nframes}: bitstream prefix + reconstruction of '
+                                      f'every one of those frames equal the live reference run; timed frames {a.warmup}..{nv - 1} of {a.warmup}..{nframes - 1} are covered')
+        if do_base:
             tag = f'v{my_ids[sorted(verify)[0]]}'
-            t_hi, t_lo = times[(tag, nv)], times[(tag, nv - 1)]
-            dtc = max(t_hi - t_lo, 1e-9)
+            n_lo = 1 if reordered else nv - 1
             nproc = len(legs.procs)
-            # aggregate of all concurrently running reference processes: pixels coded / wall of the slowest
-            agg_px = sum(n for (_, n) in times) * float(w) * h
-            agg = agg_px / max(times.values()) / 1e6
-            res['cpu_baseline'] = {
-                'value': round(w * h / dtc / 1e6, 4), 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'reference',
-                'sample': f'stream {my_ids[sorted(verify)[0]]} of the same workload at the benched geometry {w}x{h}: coded frame {nv - 1} '
-                          f'({min(int(p.max_num_ref), nv - 1)} references) = t[{nv} frames] - t[{nv - 1} frames] = {t_hi:.1f} s - {t_lo:.1f} s; '
-                          f'Thorenc SIMD build, 1 thread per process, {nproc} reference processes running at the same time beside the GPU job',
-                'n_process': {'procs': nproc, 'host_cores': legs.ncores, 'value': round(agg, 4), 'unit': 'Mpixels/s',
-                              'note': 'all concurrently running reference processes (verify + baseline + fill-up chunks): pixels coded / wall of the slowest'}}
+            try:
+                if not (n_lo >= 1 and n_lo < n_ref):
+                    raise RuntimeError(f'cpu_baseline needs two reference runs of different length (have {n_ref} frames)')
+                t_hi, t_lo = times[(tag, n_ref)], times[(tag, n_lo)]
+                v1, d_cpu, d_wall = one_frame_baseline(t_hi, t_lo, float(w) * h * (n_ref - n_lo), {'frames_lo': n_lo})
+                # aggregate of all concurrently running reference processes: pixels coded / wall of the slowest
+                agg_px = sum(n for (_, n) in times) * float(w) * h
+                agg = agg_px / max(t[0] for t in times.values()) / 1e6
+                what = (f'coded frame {nv - 1} ({min(int(p.max_num_ref), nv - 1)} references)' if not reordered
+                        else f'coded frames 1..{n_ref - 1} of the chunk (everything but the I frame)')
+                res['cpu_baseline'] = {
+                    'value': round(v1, 4), 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'reference',
+                    'sample': f'stream {my_ids[sorted(verify)[0]]} of the same workload at the benched geometry {w}x{h}: {what} = CPU time (user + system, '
+                              f'wait4 rusage) of the {n_ref}-frame run - of the {n_lo}-frame run = {t_hi[1]:.1f} s - {t_lo[1]:.1f} s = {d_cpu:.1f} s '
+                              f'(wall until exit: {t_hi[0]:.1f} s - {t_lo[0]:.1f} s = {d_wall:.1f} s); Thorenc SIMD build, 1 thread per process, '
+                              f'{nproc} reference processes running at the same time beside the GPU job on rank 0 of {world}',
+                    'n_process': {'procs': nproc, 'host_cores': legs.ncores, 'value': round(agg, 4), 'unit': 'Mpixels/s',
+                                  'note': f'N = {nproc} concurrently running reference processes (verify + baseline + fill-up chunks): pixels coded / wall of the slowest'}}
+            except (RuntimeError, KeyError) as e:
+                print(f'bench.py: {e}', file=sys.stderr)
+                res['cpu_baseline'] = {'value': None, 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'reference', 'sample': None, 'error': str(e)}
         if res['bit_exact'] is False:
             value, rc = 0.0, 1
         # roofline of the dominant kernel (k_superblocks): algorithmic HBM bytes per luma pixel of a P frame with R
@@ -441,14 +503,17 @@ def main():
         alg_bytes_per_launch = (w * h * a.steps * S * bytes_per_px) / max(launches, 1)
         avg_launch_s = (sb_ms / 1e3) / max(launches, 1)
         achieved = alg_bytes_per_launch / max(avg_launch_s, 1e-12) / 1e9
-        # HBM traffic and SQ figures: only from a committed PMC pass of THIS workload geometry (profiles/r03_pmc_bench.json,
-        # written by scripts/pmc_summary.py from rocprofv3 --pmc passes of the same bench command); otherwise null.
+        # HBM traffic and SQ figures: only from a committed PMC pass of THIS workload geometry AND of this very library
+        # (profiles/r04_pmc_bench.json, written by scripts/pmc_summary.py from rocprofv3 --pmc passes of the same bench geometry; it
+        # carries csrc_digest() of the sources it profiled); otherwise null - a counter of other code is not attached to this line.
         traffic, traffic_src, valu_util = None, None, None
         try:
-            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_bench.json')))
-            if pm.get('width') == w and pm.get('height') == h and pm.get('streams') == S and pm.get('config', 'ldb') == a.config:
+            pm = json.load(open(os.path.join(ROOT, 'profiles', PMC_JSON)))
+            if pm.get('csrc_digest') != csrc_digest():
+                traffic_src = f'profiles/{PMC_JSON} describes other engine sources (digest {pm.get("csrc_digest")} != {csrc_digest()}): not attached'
+            elif pm.get('width') == w and pm.get('height') == h and pm.get('streams') == S and pm.get('config', 'ldb') == a.config:
                 traffic = round((pm['fetch_bytes_per_px'] + pm['write_bytes_per_px']) * w * h * S * a.steps / max(launches, 1))
-                traffic_src = 'profiles/r03_pmc_bench.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this geometry (%s)' % pm['workload']
+                traffic_src = f'profiles/{PMC_JSON[:-5]}.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this geometry and of these sources (%s)' % pm['workload']
                 valu_util = pm.get('valu_util_chip')
         except (OSError, KeyError, ValueError):
             pass
@@ -461,13 +526,13 @@ def main():
             'fps': round(value * 1e6 / (w * h), 3),
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt * 1e3 / max(a.steps, 1), 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u16' if hbd else 'u8', 'data': 'synthetic',
-            'bit_exact': res['bit_exact'], 'bit_exact_checked': res['checked'],
+            'bit_exact': res['bit_exact'], 'bit_exact_scope': res.get('bit_exact_scope'), 'bit_exact_checked': res['checked'],
             'config': {'workload': f'{w}x{h} {a.bitdepth}-bit 4:2:0, {cfg_name[:-4]} (configs/{cfg_name}), qp {qp}, '
                                    f'{S} independent closed streams per GPU in lock step, timed frames = coded frames {a.warmup}..{nframes - 1} of each stream '
                                    f'({R:.2f} references on average), synthetic content sigma {a.sigma:g}',
                        'streams_per_gpu': S, 'frames_timed_per_stream': a.steps, 'parallelism': f'stream-sharded x{world}',
                        'per_stream_fps': round(a.steps / dt, 4), 'per_stream_mpx_s': round(w * h * a.steps / dt / 1e6, 4),
-                       'superblock_queue': os.environ.get('THOR_SCHED', 'fifo')},   # thor_amd/csrc/tk_sched.h: fifo | lag
+                       'superblock_queue': os.environ.get('THOR_SCHED', 'fifo'), 'csrc_digest': csrc_digest()},   # thor_amd/csrc/tk_sched.h: fifo | lag
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 4), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 8), 'traffic': traffic, 'traffic_unit': 'bytes per launch', 'traffic_source': traffic_src,
                          'alg_bytes_per_launch': round(alg_bytes_per_launch),

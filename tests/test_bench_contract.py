@@ -70,3 +70,71 @@ def test_bench_prints_one_contract_line(monkeypatch):
         for k in ('value', 'unit', 'cores', 'kind', 'sample'):
             assert k in c, k
         assert c['cores'] == 1 and c['kind'] == 'reference' and c['unit'] == d['unit']
+
+
+class _SlowFakeEncoder(_FakeEncoder):
+    """Every lock-step frame takes a while: the reference legs of a small geometry finish long BEFORE the timed region ends
+    (the situation of the driver's 25-frame run, where round 3's poll-time stamps produced 73 Mpixels/s)."""
+    def encode_staged(self, slots):
+        import time
+        time.sleep(0.4)
+        super().encode_staged(slots)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, 'oracle', '_ref', 'Thorenc')), reason='oracle/_ref/Thorenc not built')
+def test_cpu_baseline_is_a_single_core_rate_when_the_legs_finish_early(monkeypatch):
+    import thor_amd
+    import bench
+    monkeypatch.setattr(thor_amd, 'Encoder', _SlowFakeEncoder)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--streams', '2', '--width', '320', '--height', '192', '--steps', '3', '--warmup', '4', '--no-verify'])
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    d = json.loads([l for l in buf.getvalue().splitlines() if l.strip()][0])
+    c = d['cpu_baseline']
+    assert c.get('error') is None, c
+    assert 0.05 < c['value'] < 5.0, c            # Mpixels/s of ONE host core, not "pixels / poll jitter"
+    assert 'CPU time' in c['sample'] and c['n_process']['procs'] >= 2
+    assert d['io']['cpu_legs_wait_s'] < 0.3      # the legs had exited before collect() was called
+
+
+def test_one_frame_baseline_rejects_broken_timing():
+    import bench
+    # round 3's artefact: both legs "took" the time until somebody looked
+    with pytest.raises(RuntimeError):
+        bench.one_frame_baseline((276.9, 150.00), (276.8, 149.99), 3840 * 2160, {'frames_lo': 6})
+    v, d_cpu, _ = bench.one_frame_baseline((180.0, 175.0), (155.0, 150.0), 3840 * 2160, {'frames_lo': 6})
+    assert abs(d_cpu - 25.0) < 1e-9 and 0.3 < v < 0.35
+
+
+def test_stream_prefix_of_a_short_stream_is_none():
+    import bench
+    one = (5).to_bytes(4, 'big') + b'abcde'
+    assert bench.stream_prefix(one + one, 2) == one + one and bench.stream_prefix(one, 2) is None
+
+
+class _ReorderFakeEncoder(_FakeEncoder):
+    def begin_sequence(self, stream, first, n, total):
+        self.next = getattr(self, 'next', {})
+        self.next[stream] = 0
+
+    def next_frame(self, stream):
+        self.next[stream] += 1
+        return self.next[stream] - 1
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, 'oracle', '_ref', 'Thorenc')), reason='oracle/_ref/Thorenc not built')
+def test_cpu_baseline_with_frame_reordering_subtracts_the_intra_frame(monkeypatch):
+    import thor_amd
+    import bench
+    monkeypatch.setattr(thor_amd, 'Encoder', _ReorderFakeEncoder)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'ra', '--streams', '2', '--width', '192', '--height', '128', '--steps', '8', '--warmup', '1', '--no-verify'])
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    d = json.loads([l for l in buf.getvalue().splitlines() if l.strip()][0])
+    c = d['cpu_baseline']
+    assert c.get('error') is None and 0.02 < c['value'] < 5.0, c
+    assert 'coded frames 1..8' in c['sample'] and '9-frame run' in c['sample'] and '1-frame run' in c['sample']

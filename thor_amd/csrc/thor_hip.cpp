@@ -362,13 +362,17 @@ static void df_free(DfState& D) {
   if (D.times) HIPCHECK(hipFree(D.times));
   if (D.bq) { HIPCHECK(hipFree(D.bq)); HIPCHECK(hipFree(D.bbase)); }
 }
-// Queue discipline of the superblock scheduler (tk_sched.h): THOR_SCHED=fifo (default) | lag (laggards first).
+// Queue discipline of the superblock scheduler (tk_sched.h): THOR_SCHED=fifo (default) | lag (laggards first).  Read once per
+// process; an unknown value is reported and the default is used (a library does not abort its host over an environment variable).
 static int df_lag_discipline() {
-  const char* e = getenv("THOR_SCHED");
-  if (!e || !strcmp(e, "fifo")) return 0;
-  if (!strcmp(e, "lag")) return 1;
-  fprintf(stderr, "Run-time error...\nthor_hip: THOR_SCHED must be fifo or lag (got %s)\n...now exiting to system...\n", e);
-  abort();
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("THOR_SCHED");
+    mode = 0;
+    if (e && !strcmp(e, "lag")) mode = 1;
+    else if (e && strcmp(e, "fifo")) fprintf(stderr, "thor_hip: THOR_SCHED=%s is not a queue discipline (fifo | lag): using fifo\n", e);
+  }
+  return mode;
 }
 
 template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S) {
@@ -437,7 +441,13 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
   HIPCHECK(hipGetLastError());
   DfCtl hc;
   HIPCHECK(hipMemcpyAsync(&hc, D.ctl, sizeof(hc), hipMemcpyDeviceToHost, g_stream));
-  HIPCHECK(hipStreamSynchronize(g_stream));
+  if (hipError_t e = hipStreamSynchronize(g_stream)) {
+    // an aborted launch: the kernel traps when a wavefront waits for another wave of its workgroup beyond kWgWaitLimit
+    // (tk_block.h:md_item_trial - a protocol error of the block decision's work queue, never a matter of load)
+    fprintf(stderr, "Run-time error...\nthor_hip: k_superblocks was aborted: %s (a trap inside the kernel = an intra-workgroup wait that did not end)\n...now exiting to system...\n",
+            hipGetErrorString(e));
+    abort();
+  }
   const unsigned handed_out = nb ? hc.claimed : hc.tail;
   if (hc.error || handed_out != (unsigned)total) {
     fprintf(stderr, "Run-time error...\nthor_hip: superblock scheduler failed (error %u, %u of %zu tasks released)\n...now exiting to system...\n", hc.error, handed_out, total);
@@ -1050,7 +1060,10 @@ static int kat_sad_batch(const PIX* org, int w, int h, const PIX* ref_plane, int
   }
   if (!ensure_init(g_inited ? g_device : 0)) return 3;
   PIX* d_org = to_dev(org, (size_t)w * h);
-  PIX* d_ref = to_dev(ref_plane, (size_t)rstride * plane_h + 16);   // the evaluator reads whole 16-byte row segments
+  // the evaluator reads whole 16-byte row segments: 16 zeroed samples of slack behind the plane on the device (dev_alloc clears);
+  // only the caller's rstride * plane_h samples are read from the host buffer
+  PIX* d_ref = to_dev<PIX>(nullptr, (size_t)rstride * plane_h + 16);
+  backend::h2d(d_ref, ref_plane, (size_t)rstride * plane_h * sizeof(PIX));
   int* d_c = to_dev(cand, (size_t)2 * n);
   uint32_t* d_o = to_dev<uint32_t>(nullptr, n);
   hipLaunchKernelGGL(k_kat_sad<PIX>, dim3(1), dim3(64), 0, g_stream, d_org, w, h, d_ref, rstride, bx, by, d_c, n, d_o);

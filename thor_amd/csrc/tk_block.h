@@ -1263,12 +1263,14 @@ TK_DEVNI void md_item_trial(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& 
   const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
   r = tk_uniform(r); part = tk_uniform(part);
   WgShared* const sh_ = tk_uniform_ptr(M.sh);
-  for (unsigned spins = 0;; spins++) {   // the reference's search item was taken from the queue before this one: it is finished or running on another wave
+  // the reference's search item was taken from the queue before this one: it is finished or running on another wave.  A wait of
+  // kWgWaitLimit wall-clock ticks (a search item takes milliseconds) is a protocol error: wg_wait_failed() stops the kernel / the
+  // simulation loudly instead of hanging the GPU (the host reports the aborted launch, thor_hip.cpp:run_superblocks).
+  const unsigned long long w0 = wg_clock();
+  for (unsigned spins = 1;; spins++) {
     const int d = wg_load_acquire(&sh_->parts_done[r]);   // every lane acquires (one broadcast LDS read)
     if (team_bcast0(t, d) > part) break;
-#if !TK_HOST
-    if (spins == (1u << 25)) wg_wait_failed();   // ~8 s of back-off sleeps; a search item takes milliseconds
-#endif
+    if ((spins & 1023u) == 0 && tk_uniform64(wg_clock() - w0) > (unsigned long long)kWgWaitLimit) wg_wait_failed();
     wg_pause();
   }
   mv_t mv_all[4][4];

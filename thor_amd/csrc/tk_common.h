@@ -180,6 +180,22 @@ TK_DEV void wg_pause() {
   __builtin_amdgcn_s_sleep(8);
 #endif
 }
+// Wall clock for the limit of such a wait: 100 MHz ticks on the device (s_memrealtime) and on the host.
+#if TK_HOST
+}  // namespace tk
+#include <time.h>
+namespace tk {
+#endif
+enum { kWgWaitLimit = 800000000 };   // 8 s
+TK_DEV unsigned long long wg_clock() {
+#if TK_HOST
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (unsigned long long)ts.tv_sec * 100000000ull + (unsigned long long)ts.tv_nsec / 10ull;
+#else
+  return wall_clock64();
+#endif
+}
 // A wait on another wave that cannot end (a protocol error): stop the kernel / the simulation loudly instead of spinning for ever.
 TK_DEV void wg_wait_failed() {
 #if TK_HOST
