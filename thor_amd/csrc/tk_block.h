@@ -36,7 +36,10 @@ struct Node {
 // up to 128x128 in a global scratch arena that stays L1/L2 resident).
 enum { kProfSlots = 32 };
 enum { kMdMaxItems = 48 };
-enum { kLdsBlk = 16 };   // coding blocks up to this size keep their sample buffers in LDS
+#ifndef TK_LDSBLK
+#define TK_LDSBLK 16
+#endif
+enum { kLdsBlk = TK_LDSBLK };   // coding blocks up to this size keep their sample buffers in LDS (16 or 32)
 enum { MD_SKIP = 0, MD_MERGE, MD_REF, MD_INTRA, MD_BIPRED, MD_TRIAL };
 enum { WG_CMD_EXIT = 0, WG_CMD_MD = 1 };
 struct MdItem { int8_t kind, a, b, pad; };
