@@ -202,6 +202,20 @@ template <typename PIX> TK_DEV TeamWs<PIX> make_ws(SmallWs<PIX>* s, WgShared* sh
   return w;
 }
 
+// -DTHOR_PROF -DTHOR_PROF_MD: slots 16..25 hold the time of the decision's work-queue items by kind (all waves) and of the phases
+// the master runs alone, instead of the transform-unit sizes: 16 skip/merge items, 17 intra items, 18 search items (MD_REF),
+// 19 trial items incl. their wait for the vectors, 20 wait of the trial items alone, 21 queue set-up (master), 22 block entry
+// (contexts, candidates, original block), 23 early-skip path (check + trial + final encode), 24 final encode of decided blocks,
+// 25 number of parallel decisions.
+#if defined(THOR_PROF_MD) && defined(THOR_PROF) && !TK_HOST
+#define TK_PROFMD_MARK(v) TK_PROF_MARK(v)
+#define TK_PROFMD_ACC(ws, id, v) TK_PROF_ACC(ws, id, v)
+#define TK_PROFMD_CNT(ws, id) TK_PROF_CNT(ws, id)
+#else
+#define TK_PROFMD_MARK(v) do {} while (0)
+#define TK_PROFMD_ACC(ws, id, v) do {} while (0)
+#define TK_PROFMD_CNT(ws, id) do {} while (0)
+#endif
 enum { PF_SB = 0, PF_ESKIP, PF_ME_FULL, PF_ME_SUB, PF_PRED_INTER, PF_PRED_INTRA, PF_TU, PF_BITS, PF_COST, PF_FINAL,
        PF_CFL, PF_BIPRED_PREP, PF_QUANT };
 
@@ -1270,12 +1284,14 @@ TK_DEVNI void md_item_trial(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& 
   // kWgWaitLimit wall-clock ticks (a search item takes milliseconds) is a protocol error: wg_wait_failed() stops the kernel / the
   // simulation loudly instead of hanging the GPU (the host reports the aborted launch, thor_hip.cpp:run_superblocks).
   const unsigned long long w0 = wg_clock();
+  TK_PROFMD_MARK(pwt_);
   for (unsigned spins = 1;; spins++) {
     const int d = wg_load_acquire(&sh_->parts_done[r]);   // every lane acquires (one broadcast LDS read)
     if (team_bcast0(t, d) > part) break;
     if ((spins & 1023u) == 0 && tk_uniform64(wg_clock() - w0) > (unsigned long long)kWgWaitLimit) wg_wait_failed();
     wg_pause();
   }
+  TK_PROFMD_ACC(ws, 20, pwt_);
   mv_t mv_all[4][4];
   for (int q = 0; q <= part; q++)
     for (int i = 0; i < 4; i++) mv_all[q][i] = lds_ld(&sh_->ref_mv[r][q][i]);
@@ -1414,6 +1430,7 @@ TK_DEVNI void md_worker_sp(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws) 
     i = team_bcast0(t, i);
     if (i >= n_items) break;
     const int kind = team_bcast0(t, sh->items[i].kind), ia = team_bcast0(t, sh->items[i].a), ib = team_bcast0(t, sh->items[i].b);
+    TK_PROFMD_MARK(pk_);
     if (kind == MD_SKIP) {
       BlkParam p = blank_param();
       set_cand(p, lds_ld(&M.nd->skip[ia]), ia, M_SKIP);
@@ -1441,6 +1458,7 @@ TK_DEVNI void md_worker_sp(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws) 
     } else if (kind == MD_TRIAL) {
       md_item_trial<PIX, SP>(t, J, ws, M, ia, ib);
     }
+    TK_PROFMD_ACC(ws, (kind == MD_SKIP || kind == MD_MERGE) ? 16 : kind == MD_INTRA ? 17 : kind == MD_REF ? 18 : 19, pk_);
   }
   if (sh->do_bipred == 2) {  // uniform over the workgroup: every wave takes part (same number of barriers)
     t.sync();
@@ -1488,6 +1506,8 @@ TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, JobR<PIX> J, WsP<
   const auto nd = ldsc(&sh_->stack[node]);
   const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
   const int inter = J.frame_type != F_I;
+  TK_PROFMD_MARK(pqs_);
+  TK_PROFMD_CNT(ws, 25);
   mv_t mvp = mk_mv(0, 0);
   if (inter) mvp = get_mv_pred(J.cells, J.cell_stride, nd->ypos, nd->xpos, c.width, c.height, nd->size, kMaxSb);
   t.sync();
@@ -1519,6 +1539,7 @@ TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, JobR<PIX> J, WsP<
     sh->cmd = WG_CMD_MD;
   }
   t.sync();
+  TK_PROFMD_ACC(ws, 21, pqs_);
   wg.barrier();   // fork
 #ifdef THOR_PROF
   { TK_PROF_MARK(pw_); md_worker(wg, t, J, ws); TK_PROF_ACC(ws, 5, pw_); t.sync(); wg.barrier(); TK_PROF_ACC(ws, 29, pw_); }
@@ -1753,6 +1774,7 @@ TK_DEV void process_sb(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int 
       // ---- entry
       const int size = nd.size, ypos = nd.ypos, xpos = nd.xpos;
       if (ypos + kMinBlk > fh || xpos + kMinBlk > fw) { ret = 0; have_ret = 1; sp--; continue; }
+      TK_PROFMD_MARK(pen_);
       ws_select(ws, tk_uniform(size));
       t.sync();
       if (t.rank == 0) {
@@ -1778,6 +1800,8 @@ TK_DEV void process_sb(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int 
       }
       t.sync();
       org_select(t, J, ws, tk_uniform(size), ypos, xpos, tk_uniform(nd.bw), tk_uniform(nd.bh), 1);
+      TK_PROFMD_ACC(ws, 22, pen_);
+      TK_PROFMD_MARK(pes_);
       // ---- early skip
       const int lds_blk = tk_uniform(size <= kLdsBlk);   // address space of this block's sample buffers (SP_LDS / SP_GLOBAL instances)
       if (nd.encode_this_size && J.frame_type != F_I && c.early_skip_thr > 0.0f) {
@@ -1819,9 +1843,11 @@ TK_DEV void process_sb(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int 
 #endif
           have_ret = 1;
           sp--;
+          TK_PROFMD_ACC(ws, 23, pes_);
           continue;
         }
       }
+      TK_PROFMD_ACC(ws, 23, pes_);
       // ---- split signalling + children (bottom-up), unless this is a top-down 16x16 (encode_block.c:2418)
       const int top_down = size == 2 * kMinBlk && nd.encode_this_size && J.frame_type != F_I && c.encoder_speed > 0;
       if (size > kMinBlk && !top_down) {
@@ -1920,8 +1946,10 @@ TK_DEV void process_sb(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int 
           out.pos = nd.bitpos0;
           // decided just now by the parallel decision: the winner's wave still holds its trial (snapshot_trial)
           const BigWs<PIX>* snap = snap_wave >= 0 ? (const BigWs<PIX>*)ldsc(ws->sh)->wsnap[snap_wave] : nullptr;
+          TK_PROFMD_MARK(pfe_);
           if (nd.size <= kLdsBlk) final_encode<PIX, SP_LDS>(t, J, ws, nd, out, snap);
           else final_encode<PIX, SP_GLOBAL>(t, J, ws, nd, out, snap);
+          TK_PROFMD_ACC(ws, 24, pfe_);
         }
       }
       ret = cost < nd.cost_small ? cost : nd.cost_small;

@@ -341,7 +341,7 @@ TK_DEVNI int code_tu_sp(const Team t, XformWs* ws, const PIX* org, int ostride, 
     copy_block<SP, SP>(t, rec, rstride, pred, pstride, size, size);
     t.sync();
   }
-#ifndef THOR_PROF_ME   // -DTHOR_PROF_ME: slots 16..25 hold the motion-search cycles / calls by coding-block size instead
+#if !defined(THOR_PROF_ME) && !defined(THOR_PROF_MD)   // -DTHOR_PROF_ME / _MD: slots 16..25 hold the motion-search cycles by block size / the work-queue items by kind instead
   TK_PROF_ADD(ws, (size <= 4 ? 16 : size == 8 ? 17 : size == 16 ? 18 : size == 32 ? 19 : 20));
   TK_PROF_CNT(ws, (size <= 4 ? 21 : size == 8 ? 22 : size == 16 ? 23 : size == 32 ? 24 : 25));
 #endif

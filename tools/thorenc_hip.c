@@ -96,9 +96,16 @@ int main(int argc, char** argv) {
     static const char* nm[32] = {"sb_total", "early_skip", "me_fullpel", "me_subpel", "pred_inter", "md_worker_all_waves", "code_tu", "bits", "cost", "final", "subpel_loop",
                                  "me_calls(n)", "quant", "me_telescope", "me_cands", "me_hex", "tu4", "tu8", "tu16", "tu32", "tu64+",
                                  "tu4(n)", "tu8(n)", "tu16(n)", "tu32(n)", "tu64+(n)", "wg_barrier_wait(all waves)", "bipred_lockstep(all waves, incl. barriers)", "helpers_parked(master alone)", "md_fork_to_join(master)", "tu_fwd", "tu_inv"};
+    /* THOR_PROF=md: the library was built with -DTHOR_PROF_MD (slots 16..25 = work-queue items by kind / master-alone phases, tk_block.h);
+       THOR_PROF=me: -DTHOR_PROF_ME (motion-search cycles and calls by coding-block size) */
+    static const char* nm_md[10] = {"items skip/merge", "items intra", "items search (MD_REF)", "items trial (incl. wait)", "trial items: wait for vectors", "queue set-up (master)",
+                                    "block entry (master)", "early-skip path (master)", "final encode of decided blocks (master)", "parallel decisions(n)"};
+    static const char* nm_me[10] = {"me cb8", "me cb16", "me cb32", "me cb64", "me cb128", "me cb8(n)", "me cb16(n)", "me cb32(n)", "me cb64(n)", "me cb128(n)"};
+    if (!strcmp(getenv("THOR_PROF"), "md")) for (int k = 0; k < 10; k++) nm[16 + k] = nm_md[k];
+    if (!strcmp(getenv("THOR_PROF"), "me")) for (int k = 0; k < 10; k++) nm[16 + k] = nm_me[k];
     long long pr[32];
     thor_hip_read_prof(e, pr);
-    for (int k = 0; k < 32; k++) fprintf(stdout, "prof %-14s %16lld %6.2f%%\n", nm[k], pr[k], pr[0] ? 100.0 * pr[k] / pr[0] : 0.0);
+    for (int k = 0; k < 32; k++) fprintf(stdout, "prof %-40s %16lld %6.2f%%\n", nm[k], pr[k], pr[0] ? 100.0 * pr[k] / pr[0] : 0.0);
   }
   for (int s = 0; s < S; s++) {
     if (fr[s]) fclose(fr[s]);
