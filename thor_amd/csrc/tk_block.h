@@ -205,8 +205,8 @@ template <typename PIX> TK_DEV TeamWs<PIX> make_ws(SmallWs<PIX>* s, WgShared* sh
 // -DTHOR_PROF -DTHOR_PROF_MD: slots 16..25 hold the time of the decision's work-queue items by kind (all waves) and of the phases
 // the master runs alone, instead of the transform-unit sizes: 16 skip/merge items, 17 intra items, 18 search items (MD_REF),
 // 19 trial items incl. their wait for the vectors, 20 wait of the trial items alone, 21 queue set-up (master), 22 block entry
-// (contexts, candidates, original block), 23 early-skip path (check + trial + final encode), 24 final encode of decided blocks,
-// 25 number of parallel decisions.
+// (contexts, candidates, original block), 23 early-skip path (check + trial + final encode), 24 final encode of decided blocks: bit emission
+// (one lane), 25 final encode of decided blocks: reconstruction copy + cell state.
 #if defined(THOR_PROF_MD) && defined(THOR_PROF) && !TK_HOST
 #define TK_PROFMD_MARK(v) TK_PROF_MARK(v)
 #define TK_PROFMD_ACC(ws, id, v) TK_PROF_ACC(ws, id, v)
@@ -336,9 +336,51 @@ TK_DEV void find_contexts(const DbCell* cells, int cs, int ypos, int xpos, int f
 // SP: address space of both sample blocks.
 template <typename PIX> struct SsdT { typedef unsigned long long type; };
 template <> struct SsdT<uint8_t> { typedef unsigned type; };
+// 8-bit samples, four at a time: sum (a-b)^2 = sum a^2 + sum b^2 - 2 sum ab as three packed dot products (v_dot4_u32_u8) on the
+// dwords as loaded; the partial sums wrap modulo 2^32 and the difference is exact (the true value fits, see above).
+TK_DEV unsigned udot4_u8(unsigned a, unsigned b, unsigned c) {
+#if TK_HOST
+  for (int k = 0; k < 4; k++) c += ((a >> (8 * k)) & 0xffu) * ((b >> (8 * k)) & 0xffu);
+  return c;
+#else
+  return __builtin_amdgcn_udot4(a, b, c, false);
+#endif
+}
+template <int SP, int NW> TK_DEV unsigned ssd_rows_u8(const Team t, const uint8_t* a_, int as, const uint8_t* b_, int bs, int w, int h) {
+  // NW dwords (4 * NW samples) per lane and step; w a multiple of 4 * NW, rows and pointers aligned to 4 * NW bytes
+  const int ppr = w / (4 * NW);
+  const int lg = (ppr & (ppr - 1)) ? -1 : ilog2((unsigned)ppr);
+  unsigned sq = 0, ab = 0;
+  for (int k = t.rank; k < ppr * h; k += t.size) {
+    int i, j;
+    if (lg >= 0) { i = k >> lg; j = k & (ppr - 1); } else { i = k / ppr; j = k - i * ppr; }
+    uint32_t x[NW], y[NW];
+#if TK_HOST
+    __builtin_memcpy(x, a_ + i * as + j * 4 * NW, 4 * NW);
+    __builtin_memcpy(y, b_ + i * bs + j * 4 * NW, 4 * NW);
+#else
+    typedef uint32_t __attribute__((ext_vector_type(NW))) vec_t;
+    const vec_t xv = *(typename SpT<SP, const vec_t>::ptr)(spc<SP>(a_) + i * as + j * 4 * NW);
+    const vec_t yv = *(typename SpT<SP, const vec_t>::ptr)(spc<SP>(b_) + i * bs + j * 4 * NW);
+    __builtin_memcpy(x, &xv, 4 * NW);
+    __builtin_memcpy(y, &yv, 4 * NW);
+#endif
+#if !TK_HOST
+#pragma unroll
+#endif
+    for (int q = 0; q < NW; q++) { sq = udot4_u8(x[q], x[q], udot4_u8(y[q], y[q], sq)); ab = udot4_u8(x[q], y[q], ab); }
+  }
+  return sq - 2u * ab;
+}
 template <int SP, typename PIX>
 TK_DEV typename SsdT<PIX>::type ssd_part(const Team t, const PIX* a_, int as, const PIX* b_, int bs, int w, int h) {
   a_ = tk_uniform_ptr(a_); b_ = tk_uniform_ptr(b_); as = tk_uniform(as); bs = tk_uniform(bs); w = tk_uniform(w); h = tk_uniform(h);
+  if constexpr (sizeof(PIX) == 1) {
+    const unsigned al = (unsigned)(uintptr_t)a_ | (unsigned)(uintptr_t)b_ | (unsigned)as | (unsigned)bs | (unsigned)w;
+    if (!(al & 15u)) return ssd_rows_u8<SP, 4>(t, a_, as, b_, bs, w, h);
+    if (!(al & 7u)) return ssd_rows_u8<SP, 2>(t, a_, as, b_, bs, w, h);
+    if (!(al & 3u)) return ssd_rows_u8<SP, 1>(t, a_, as, b_, bs, w, h);
+  }
   const auto a = spc<SP>(a_);
   const auto b = spc<SP>(b_);
   typename SsdT<PIX>::type local = 0;
@@ -1507,7 +1549,6 @@ TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, JobR<PIX> J, WsP<
   const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
   const int inter = J.frame_type != F_I;
   TK_PROFMD_MARK(pqs_);
-  TK_PROFMD_CNT(ws, 25);
   mv_t mvp = mk_mv(0, 0);
   if (inter) mvp = get_mv_pred(J.cells, J.cell_stride, nd->ypos, nd->xpos, c.width, c.height, nd->size, kMaxSb);
   t.sync();
@@ -1673,6 +1714,7 @@ template <typename PIX, int SP>
 TK_DEVNI int final_encode(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd, BitSink& out, const BigWs<PIX>* snap = nullptr,
                           int trial_bits = -1) {
   TK_PROF_T0();
+  TK_PROFMD_MARK(pfe0_);
   BlkParam p = lds_ld(&nd.best);
   const int size = nd.size, sc = size >> 1;
   const int yc = nd.ypos >> 1, xc = nd.xpos >> 1;
@@ -1689,6 +1731,7 @@ TK_DEVNI int final_encode(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd, BitS
     }
     nbits = team_bcast0(t, nbits);
     out.pos += nbits;
+    TK_PROFMD_ACC(ws, 24, pfe0_);
     copy_block<SP_GLOBAL, SP_GLOBAL>(t, J.rec.y + nd.ypos * J.rec.sy + nd.xpos, J.rec.sy, snap->best_y, size, nd.bw, nd.bh);
     copy_block<SP_GLOBAL, SP_GLOBAL>(t, J.rec.u + yc * J.rec.sc + xc, J.rec.sc, snap->best_u, sc, nd.bw >> 1, nd.bh >> 1);
     copy_block<SP_GLOBAL, SP_GLOBAL>(t, J.rec.v + yc * J.rec.sc + xc, J.rec.sc, snap->best_v, sc, nd.bw >> 1, nd.bh >> 1);
@@ -1949,7 +1992,7 @@ TK_DEV void process_sb(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int 
           TK_PROFMD_MARK(pfe_);
           if (nd.size <= kLdsBlk) final_encode<PIX, SP_LDS>(t, J, ws, nd, out, snap);
           else final_encode<PIX, SP_GLOBAL>(t, J, ws, nd, out, snap);
-          TK_PROFMD_ACC(ws, 24, pfe_);
+          TK_PROFMD_ACC(ws, 25, pfe_);   // whole call; slot 24 holds the emission part of the snapshot path
         }
       }
       ret = cost < nd.cost_small ? cost : nd.cost_small;

@@ -297,9 +297,36 @@ TK_DEV void inv_transform_recon(const Team t, XformWs* ws, const PIX* pred_, int
   t.sync();
 }
 
+// Row-wise copy with V-byte pieces (V = 16, 8 or 4): one piece per lane and step instead of one sample.
+template <int SD, int SS, int V> TK_DEV void copy_rows_vec(const Team t, void* dst_, int dpitch, const void* src_, int spitch, int rowbytes, int h) {
+  const int ppr = rowbytes / V;   // pieces per row (a power of two for every block this is used on, or any number: divided below)
+#if TK_HOST
+  for (int k = t.rank; k < ppr * h; k += t.size) {
+    const int i = k / ppr, j = k - i * ppr;
+    __builtin_memcpy((char*)dst_ + (size_t)i * dpitch + j * V, (const char*)src_ + (size_t)i * spitch + j * V, V);
+  }
+#else
+  typedef uint32_t __attribute__((ext_vector_type(V / 4))) vec_t;
+  const auto dst = spc<SD>((char*)dst_);
+  const auto src = spc<SS>((const char*)src_);
+  const int lg = (ppr & (ppr - 1)) ? -1 : ilog2((unsigned)ppr);
+  for (int k = t.rank; k < ppr * h; k += t.size) {
+    int i, j;
+    if (lg >= 0) { i = k >> lg; j = k & (ppr - 1); } else { i = k / ppr; j = k - i * ppr; }
+    *(typename SpT<SD, vec_t>::ptr)(dst + i * dpitch + j * V) = *(typename SpT<SS, const vec_t>::ptr)(src + i * spitch + j * V);
+  }
+#endif
+}
 template <int SD, int SS, typename PIX>
 TK_DEV void copy_block(const Team t, PIX* dst_, int dstride, const PIX* src_, int sstride, int w, int h) {
   dst_ = tk_uniform_ptr(dst_); src_ = tk_uniform_ptr(src_); dstride = tk_uniform(dstride); sstride = tk_uniform(sstride); w = tk_uniform(w); h = tk_uniform(h);
+  // widest piece that divides the row and keeps every access aligned (wave-uniform): a 64x64 block moves in 4 steps of 16-byte
+  // pieces instead of 64 steps of single samples
+  const int S = (int)sizeof(PIX);
+  const unsigned al = (unsigned)(uintptr_t)dst_ | (unsigned)(uintptr_t)src_ | (unsigned)(dstride * S) | (unsigned)(sstride * S) | (unsigned)(w * S);
+  if (!(al & 15u)) { copy_rows_vec<SD, SS, 16>(t, dst_, dstride * S, src_, sstride * S, w * S, h); return; }
+  if (!(al & 7u)) { copy_rows_vec<SD, SS, 8>(t, dst_, dstride * S, src_, sstride * S, w * S, h); return; }
+  if (!(al & 3u)) { copy_rows_vec<SD, SS, 4>(t, dst_, dstride * S, src_, sstride * S, w * S, h); return; }
   const auto dst = spc<SD>(dst_);
   const auto src = spc<SS>(src_);
   if ((w & (w - 1)) == 0) {

@@ -99,7 +99,7 @@ int main(int argc, char** argv) {
     /* THOR_PROF=md: the library was built with -DTHOR_PROF_MD (slots 16..25 = work-queue items by kind / master-alone phases, tk_block.h);
        THOR_PROF=me: -DTHOR_PROF_ME (motion-search cycles and calls by coding-block size) */
     static const char* nm_md[10] = {"items skip/merge", "items intra", "items search (MD_REF)", "items trial (incl. wait)", "trial items: wait for vectors", "queue set-up (master)",
-                                    "block entry (master)", "early-skip path (master)", "final encode of decided blocks (master)", "parallel decisions(n)"};
+                                    "block entry (master)", "early-skip path (master)", "final encode of decided blocks: emission (master)", "final encode of decided blocks: whole (master)"};
     static const char* nm_me[10] = {"me cb8", "me cb16", "me cb32", "me cb64", "me cb128", "me cb8(n)", "me cb16(n)", "me cb32(n)", "me cb64(n)", "me cb128(n)"};
     if (!strcmp(getenv("THOR_PROF"), "md")) for (int k = 0; k < 10; k++) nm[16 + k] = nm_md[k];
     if (!strcmp(getenv("THOR_PROF"), "me")) for (int k = 0; k < 10; k++) nm[16 + k] = nm_me[k];
