@@ -44,9 +44,6 @@ __device__ Tables g_tab;
 // the workgroup barrier and take work items of the block decisions (tk_block.h:mode_decision_par).  3 workgroups of
 // 4 waves per CU = 3 waves per SIMD (168 VGPRs each), 768 workgroups resident on the chip.
 enum { kWgThreads = 64 * kWaves };
-#ifndef TK_OCC
-#define TK_OCC 3
-#endif
 enum { kOcc = TK_OCC };   // wavefronts per SIMD the register allocation is sized for (168 VGPRs); 2 and 4 measured slower (profiles/r02_ab_variants.md)
 template <typename PIX> __global__ __launch_bounds__(kWgThreads, kOcc) void k_superblocks(const FrameJob<PIX>* jobs, DfArgs A) {
   __shared__ FrameJob<PIX> sJ;

@@ -40,7 +40,7 @@ enum { kMdMaxItems = 48 };
 #define TK_LDSBLK 16
 #endif
 enum { kLdsBlk = TK_LDSBLK };   // coding blocks up to this size keep their sample buffers in LDS (16 or 32)
-enum { MD_SKIP = 0, MD_MERGE, MD_REF, MD_INTRA, MD_BIPRED, MD_TRIAL };
+enum { MD_SKIP = 0, MD_MERGE, MD_REF, MD_INTRA, MD_BIPRED, MD_TRIAL, MD_BIJOINT };
 enum { WG_CMD_EXIT = 0, WG_CMD_MD = 1 };
 struct MdItem { int8_t kind, a, b, pad; };
 struct WgShared {
@@ -64,6 +64,12 @@ struct WgShared {
   int bp_skip[4];                // per step: its inputs equal those of the previous step of the same list (see bipred_par)
   int bp_ref0, bp_ref1;
   mv_t bp_min0[4], bp_min1[4];
+  // B frames: the telescope of the joint +mv / -mv search (motion_estimate_bi) runs as a queue item of its own (MD_BIJOINT) as soon as
+  // the PART_NONE vector of its first reference is known; whoever gets there first - the item or the bi-prediction item that
+  // needs its result - claims it (0 -> 1) and publishes the result (-> 2)
+  int bj_state;
+  unsigned bj_sad;
+  mv_t bj_mv;
   int node;                      // index of the node being decided in `stack`
   mv_t mvp;
   mv_t mv_center[kMaxRefs];
@@ -76,8 +82,13 @@ struct WgShared {
   // loaded once by the master, read by every trial of every wave instead of the frame in global memory
   alignas(16) unsigned char org_raw[kLdsBlk * kLdsBlk * 3];
 };
+// Bytes of per-wave LDS that extend the motion search's window beyond the transform workspace it borrows (tk_me.h:MeWin).  With
+// two workgroups per CU a workgroup has 80 KB: the windows of 8-bit PUs up to 64x64 (reach 20) and of 16-bit PUs up to 32x32
+// (reach 16) fit; with three workgroups per CU there is no room (window = transform workspace: 8-bit PUs up to 16x16).
+template <typename PIX> struct WinExtra { enum { bytes = TK_OCC == 2 ? (sizeof(PIX) == 1 ? 7680 : 5632) : 16 }; };
 template <typename PIX> struct SmallWs {
   XformWs xf;
+  alignas(16) unsigned char win_extra[WinExtra<PIX>::bytes];   // must directly follow xf
   MeWs me;
   IntraEdge<PIX> edge;
   // quantised coefficients of the current trial; TU t of a tb-split block at offset t * qs^2 with
@@ -87,7 +98,7 @@ template <typename PIX> struct SmallWs {
   unsigned long long acc[12];
   // sample blocks (prediction, the two bi-prediction inputs, reconstruction, 2*org-pred) of coding blocks up to
   // kLdsBlk x kLdsBlk: the trials of the small blocks - the bulk of all trials - never round-trip through global memory
-  PIX lbuf[7 * kLdsBlk * kLdsBlk];
+  alignas(16) PIX lbuf[7 * kLdsBlk * kLdsBlk];
 #if defined(THOR_PROF)
   long long prof[kProfSlots];
 #else
@@ -189,9 +200,11 @@ template <typename PIX> TK_DEV TeamWs<PIX> make_ws(SmallWs<PIX>* s, WgShared* sh
   TeamWs<PIX> w;
   w.xfp = &s->xf; w.mep = &s->me; w.edgep = &s->edge;
   w.sh = sh; s->xf.tabs = &sh->tabs; s->me.lists = &sh->lists;
-  // the search window of a motion search lives in the transform workspace (in | tmp | coef: contiguous), idle during a search
-  static_assert(offsetof(XformWs, flag) - offsetof(XformWs, in) >= (size_t)kMeWinBytes, "search window does not fit the transform workspace");
-  s->me.win = sizeof(PIX) == 1 ? (uint32_t*)s->xf.in : nullptr;
+  // the search window of a motion search lives in the transform workspace (in | tmp | coef: contiguous), idle during a search,
+  // and continues into win_extra
+  static_assert(offsetof(SmallWs<PIX>, win_extra) == offsetof(SmallWs<PIX>, xf) + sizeof(XformWs), "win_extra must directly follow the transform workspace");
+  s->me.win = (uint32_t*)s->xf.in;
+  s->me.win_cap = (int)(sizeof(XformWs) - offsetof(XformWs, in)) + (int)WinExtra<PIX>::bytes;
   w.coef_y = s->coef_y; w.coef_u = s->coef_u; w.coef_v = s->coef_v;
   w.coef_u_small = s->coef_u; w.coef_v_small = s->coef_v; w.coef_u_big = g->coef_u_big; w.coef_v_big = g->coef_v_big;
   w.acc = s->acc; w.stack = sh->stack; w.prof = s->prof;
@@ -1245,6 +1258,49 @@ TK_DEV int par_trial(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& M, BlkP
   return 1;
 }
 
+// Wait (with the limit of every intra-workgroup wait) until *p, an LDS word another wave releases, reaches `at_least`.
+template <typename PIX> TK_DEV void wg_wait_at_least(const Team t, WsP<PIX> ws, int* p, int at_least) {
+  (void)ws;
+  const unsigned long long w0 = wg_clock();
+  for (unsigned spins = 1;; spins++) {
+    const int d = wg_load_acquire(p);   // every lane acquires (one broadcast LDS read)
+    if (team_bcast0(t, d) >= at_least) break;
+    if ((spins & 1023u) == 0 && tk_uniform64(wg_clock() - w0) > (unsigned long long)kWgWaitLimit) wg_wait_failed();
+    wg_pause();
+  }
+}
+// Telescope of the joint +mv / -mv search of a B frame (search_bipred_prediction_params me_mode 1, encode_block.c:1708-1737): claimed
+// by the first wave that gets to it; result in sh->bj_sad / bj_mv, bj_state = 2.  Returns 0 when another wave has claimed it.
+template <typename PIX, int SP>
+TK_DEVNI int md_bijoint_telescope(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& M) {
+  const auto& c = J.cfg;
+  WgShared* const sh_ = tk_uniform_ptr(M.sh);
+  int mine = 0;
+  if (t.rank == 0) mine = wg_cas(&sh_->bj_state, 0, 1);
+  if (!team_bcast0(t, mine)) return 0;
+  const auto ndl = ldsc(M.nd);
+  struct { int size, ypos, xpos; } nd = {TKU(ndl->size), TKU(ndl->ypos), TKU(ndl->xpos)};
+  const int ri0 = J.interp_ref ? 1 : 0, ri1 = J.interp_ref ? 2 : 1;
+  const Plane3<PIX> f0 = lds_ld(&J.ref[ri0]);
+  const Plane3<PIX> f1 = lds_ld(&J.ref[ri1]);
+  MeArgs a;
+  a.cb_size = nd.size; a.ostride = ws->org_sy; a.width = nd.size; a.height = nd.size; a.rstride = f0.sy; a.sign = 0;
+  a.fwidth = c.width; a.fheight = c.height; a.xpos = nd.xpos; a.ypos = nd.ypos; a.enable_bipred = 1;
+  a.bitdepth = c.bitdepth; a.lam = J.sqrt_lambda; a.speed = c.encoder_speed; a.pu_x = nd.xpos; a.pu_y = nd.ypos;
+  mv_t mvb = mk_mv(0, 0);
+  const mv_t ctr = lds_ld(&sh_->ref_mv[ri0][0][0]);   // PART_NONE vector of the first reference = mv_center[ri0]
+  const unsigned sad = motion_estimate_bi<PIX, SP>(t, ws->mep, ws->org_y, f0.y + nd.ypos * f0.sy + nd.xpos, f1.y + nd.ypos * f1.sy + nd.xpos, a, ctr,
+                                                   lds_ld(&sh_->mvp), ri0, &mvb, 1);
+  t.sync();
+  if (t.rank == 0) {
+    *ldsc(&sh_->bj_sad) = sad;
+    lds_st(&sh_->bj_mv, mvb);
+    wg_store_release(&sh_->bj_state, 2);
+  }
+  t.sync();
+  return 1;
+}
+
 template <typename PIX, int SP>
 TK_DEVNI void md_item_bipred(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& M) {
   const auto& c = J.cfg;
@@ -1277,8 +1333,13 @@ TK_DEVNI void md_item_bipred(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>&
     a.cb_size = size; a.ostride = ws->org_sy; a.width = size; a.height = size; a.rstride = f0.sy; a.sign = 0;
     a.fwidth = c.width; a.fheight = c.height; a.xpos = nd.xpos; a.ypos = nd.ypos; a.enable_bipred = 1;
     a.bitdepth = c.bitdepth; a.lam = J.sqrt_lambda; a.speed = c.encoder_speed; a.pu_x = nd.xpos; a.pu_y = nd.ypos;
-    mv_t mvb;
-    motion_estimate_bi<PIX, SP>(t, ws->mep, oy, f0.y + nd.ypos * f0.sy + nd.xpos, f1.y + nd.ypos * f1.sy + nd.xpos, a, mv_center[ri0], mvp, ri0, &mvb);
+    // the telescope of the joint search has run (or is running) on the wave that took the MD_BIJOINT item - or runs here if nobody
+    // has claimed it yet; the extra candidates read the candidate list as the searches above left it
+    WgShared* const sh_ = tk_uniform_ptr(M.sh);
+    if (!md_bijoint_telescope<PIX, SP>(t, J, ws, M)) wg_wait_at_least(t, ws, &sh_->bj_state, 2);
+    mv_t mvb = lds_ld(&sh_->bj_mv);
+    const unsigned sad0 = (unsigned)tk_uniform((int)*ldsc(&sh_->bj_sad));
+    motion_estimate_bi<PIX, SP>(t, ws->mep, oy, f0.y + nd.ypos * f0.sy + nd.xpos, f1.y + nd.ypos * f1.sy + nd.xpos, a, mv_center[ri0], mvp, ri0, &mvb, 2, sad0);
     p.mode = M_BIPRED; p.pb_part = P_NONE;
     p.ref0 = (int8_t)ri0; p.ref1 = (int8_t)ri1;
     for (int i = 0; i < 4; i++) { p.mv0[i] = mvb; p.mv1[i] = mvb; }
@@ -1499,8 +1560,12 @@ TK_DEVNI void md_worker_sp(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws) 
       }
     } else if (kind == MD_TRIAL) {
       md_item_trial<PIX, SP>(t, J, ws, M, ia, ib);
+    } else if (kind == MD_BIJOINT) {
+      // its first reference's search item left the queue earlier: the PART_NONE vector is there or on its way
+      wg_wait_at_least(t, ws, &sh_->parts_done[J.interp_ref ? 1 : 0], 1);
+      md_bijoint_telescope<PIX, SP>(t, J, ws, M);
     }
-    TK_PROFMD_ACC(ws, (kind == MD_SKIP || kind == MD_MERGE) ? 16 : kind == MD_INTRA ? 17 : kind == MD_REF ? 18 : 19, pk_);
+    TK_PROFMD_ACC(ws, (kind == MD_SKIP || kind == MD_MERGE) ? 16 : kind == MD_INTRA ? 17 : (kind == MD_REF || kind == MD_BIJOINT) ? 18 : 19, pk_);
   }
   if (sh->do_bipred == 2) {  // uniform over the workgroup: every wave takes part (same number of barriers)
     t.sync();
@@ -1555,12 +1620,13 @@ TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, JobR<PIX> J, WsP<
   if (t.rank == 0) {
     int n = 0;
     auto push = [&](int kind, int a, int b) { sh->items[n].kind = (int8_t)kind; sh->items[n].a = (int8_t)a; sh->items[n].b = (int8_t)b; sh->items[n].pad = 0; n++; };
-    static_assert(2 + 2 + kMaxRefs + 2 * kNumIntraModes + 4 * kMaxRefs <= kMdMaxItems, "work queue too small");
+    static_assert(2 + 2 + kMaxRefs + 1 + 2 * kNumIntraModes + 4 * kMaxRefs <= kMdMaxItems, "work queue too small");
     static_assert(6 + 12 * kMaxRefs <= 54, "evaluation-order layout: the reference trials must end before the bi-prediction trials");
     if (inter) {
       for (int k = 0; k < nd->syn.num_skip; k++) push(MD_SKIP, k, 0);
       for (int k = 0; k < nd->syn.num_merge; k++) push(MD_MERGE, k, 0);
       for (int r = 0; r < J.num_ref; r++) push(MD_REF, r, 0);
+      if (J.num_ref > 1 && c.enable_bipred && J.frame_type == F_B) push(MD_BIJOINT, 0, 0);   // B frames: telescope of the joint search
       nd->syn.mvp.x = mvp.x; nd->syn.mvp.y = mvp.y;
     }
     for (int m = 0; m < J.num_intra_modes; m++)
@@ -1572,7 +1638,7 @@ TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, JobR<PIX> J, WsP<
     sh->n_items = n; sh->next_item = 0;
     sh->refs_done = 0; sh->n_ref_items = inter ? J.num_ref : 0;
     sh->do_bipred = (inter && J.num_ref > 1 && c.enable_bipred) ? (J.frame_type == F_P ? 2 : 1) : 0;
-    sh->bp_min_sad = 1u << 30; sh->bp_ref0 = 0; sh->bp_ref1 = 0;
+    sh->bp_min_sad = 1u << 30; sh->bp_ref0 = 0; sh->bp_ref1 = 0; sh->bj_state = 0;
     for (int i = 0; i < 4; i++) { lds_st(&sh_->bp_min0[i], mvp); lds_st(&sh_->bp_min1[i], mvp); }
     sh->node = node; lds_st(&sh_->mvp, mvp);
     sh->bestkey = ~0ull;

@@ -172,6 +172,22 @@ TK_DEV int wg_load_acquire(const int* p) {
   return __hip_atomic_load((const __attribute__((address_space(3))) int*)p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
 }
+TK_DEV void wg_store_release(int* p, int v) {
+#if TK_HOST
+  __atomic_store_n(p, v, __ATOMIC_RELEASE);
+#else
+  __hip_atomic_store((__attribute__((address_space(3))) int*)p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+// compare-and-swap; returns 1 when *p was `expected` and is now `desired`
+TK_DEV int wg_cas(int* p, int expected, int desired) {
+#if TK_HOST
+  return __atomic_compare_exchange_n(p, &expected, desired, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE) ? 1 : 0;
+#else
+  return __hip_atomic_compare_exchange_strong((__attribute__((address_space(3))) int*)p, &expected, desired, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE,
+                                              __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0;
+#endif
+}
 // Back-off inside a wait on another wave of the workgroup.
 TK_DEV void wg_pause() {
 #if TK_HOST
@@ -506,6 +522,11 @@ typedef TK_LDS int16_t lds_i16;
 // SP_GLOBAL, chosen once per block decision) and the leaf loops re-type their pointers with spc<SP>().  Workspace structures
 // that ALWAYS live in LDS on the device (XformWs, MeWs, WgShared, ...) are re-typed with ldsc().  Identity on the host.
 enum { SP_GLOBAL = 0, SP_LDS = 1 };
+// Wavefronts per SIMD the superblock kernel's register allocation is sized for (thor_hip.cpp:k_superblocks): 3 (168 VGPRs, three
+// workgroups per CU, 53 KB of LDS each) or 2 (256 VGPRs, two workgroups per CU, 80 KB of LDS each).
+#ifndef TK_OCC
+#define TK_OCC 3
+#endif
 #if TK_HOST
 template <int SP, class T> TK_DEV T* spc(T* p) { return p; }
 template <class T> TK_DEV T* ldsc(T* p) { return p; }

@@ -27,7 +27,8 @@ struct MeWs {  // per wavefront
   mv_t cmv[64];
   MeLists* lists;
   long long* prof;
-  uint32_t* win;  // kMeWinBytes of per-wave LDS for the search window (8-bit samples), nullptr: none (see MeWin below)
+  uint32_t* win;  // per-wave LDS for the search window (see MeWin below), nullptr: none
+  int win_cap;    // its size in bytes
 };
 TK_DEV int mv_len1(int a) {
   a = iabs(a);
@@ -128,18 +129,22 @@ template <typename PIX, int NB> TK_DEV int seg_sad(const Seg16& a, const Seg16& 
 #endif
 }
 
-// LDS search window of one motion search (8-bit samples, PUs up to 16x16): the (w + 2R) x (h + 2R) samples of the reference
-// plane around the search centre, staged once per search with coalesced 16-byte row loads; the telescope, candidate-list,
-// 5-offset, hexagon and sub-pel passes whose blocks lie inside read it with aligned ds_read + v_alignbyte instead of
-// gathering from the vector L1 (whose tag look-ups - one per lane and row - are what the waves queue for; profiles/r03_*).
-// Row pitch = width + 4 bytes: consecutive rows start in different banks.  Origin (ox, oy) is relative to the PU's
-// co-located position in the reference plane.  The window lives in the wave's transform workspace (idle during a search).
+// LDS search window of one motion search: the (w + 2R) x (h + 2R) samples of the reference plane around the search centre, staged
+// once per search with coalesced 16-byte row loads; the telescope, candidate-list, 5-offset, hexagon and sub-pel passes whose
+// blocks lie inside read it with aligned ds_read + v_alignbyte instead of gathering from the vector L1 (one coalesced global
+// round trip per search instead of one gather round trip per pass; profiles/r03_ubench_l1gather.log).  Samples of 1 or 2 bytes;
+// the reach R is the largest multiple of 4 up to kMeWinR for which the window fits the wave's LDS budget (MeWs::win_cap), at
+// least kMeWinRmin - otherwise the search reads the plane.  Row pitch = row bytes + 4: consecutive rows start in different banks.
+// Origin (ox, oy) is relative to the PU's co-located position in the reference plane.  The window lives in the wave's transform
+// workspace (idle during a search) and the bytes that follow it (SmallWs::win_extra).
 struct MeWin {
   const uint32_t* w32;
-  int ox, oy, Ww, Wh, pitch;
+  int ox, oy, Ww, Wh;   // samples
+  int pitch;            // bytes
   int on;
 };
-enum { kMeWinR = 20, kMeWinMaxPu = 16, kMeWinBytes = (kMeWinMaxPu + 2 * kMeWinR + 4) * (kMeWinMaxPu + 2 * kMeWinR) + 4 };
+enum { kMeWinR = 20, kMeWinRmin = 8 };
+TK_DEV int me_win_bytes(int w, int h, int R, int S) { return ((w + 2 * R) * S + 4) * (h + 2 * R) + 4; }
 // NB bytes at byte offset `off` of the window (any alignment): NB/4 + 1 aligned dwords, funnel-shifted
 template <int NB> TK_DEV Seg16 win_seg(const uint32_t* w32, int off) {
   Seg16 r;
@@ -183,15 +188,14 @@ TK_DEV void seg_sads_iter(const Team t, int n, int c0, int P, int G, int slot, i
   for (int u = 0; u < U; u++) {
     const int c = c0 + u * P + slot;
     x[u] = cand(c < n ? c : 0);
-    if (sizeof(PIX) == 1)
-      outside |= !(x[u].dx >= win.ox && x[u].dx + width <= win.ox + win.Ww && x[u].dy >= win.oy && x[u].dy + height <= win.oy + win.Wh);
+    outside |= !(x[u].dx >= win.ox && x[u].dx + width <= win.ox + win.Ww && x[u].dy >= win.oy && x[u].dy + height <= win.oy + win.Wh);
   }
-  const int use_win = sizeof(PIX) == 1 && win.on && team_ballot(t, outside) == 0ull;
+  const int use_win = win.on && team_ballot(t, outside) == 0ull;
   if (use_win) {
 #if !TK_HOST
 #pragma unroll
 #endif
-    for (int u = 0; u < U; u++) r[u] = win_seg<NB>(win.w32, x[u].dy * win.pitch + x[u].dx + woff);
+    for (int u = 0; u < U; u++) r[u] = win_seg<NB>(win.w32, x[u].dy * win.pitch + x[u].dx * (int)sizeof(PIX) + woff);
   } else {
 #if !TK_HOST
 #pragma unroll
@@ -223,7 +227,7 @@ TK_DEV void seg_sads_nb(const Team t, int n_, const PIX* org, int ostride, int r
     const int i = sub >> lgr, j = (sub & ((1 << lgr) - 1)) * lw;
     const Seg16 o = seg_load<SP, NB>(org + i * ostride + j);
     const int roff = i * rstride + j;
-    const int woff = (i - win.oy) * win.pitch + (j - win.ox);
+    const int woff = (i - win.oy) * win.pitch + (j - win.ox) * (int)sizeof(PIX);   // bytes
     if (n <= P) seg_sads_iter<SP, PIX, NB, 1>(t, n, 0, P, G, slot, sub, o, roff, woff, width, height, win, cand, sink);
     else if (n <= 2 * P) seg_sads_iter<SP, PIX, NB, 2>(t, n, 0, P, G, slot, sub, o, roff, woff, width, height, win, cand, sink);
     else
@@ -232,6 +236,9 @@ TK_DEV void seg_sads_nb(const Team t, int n_, const PIX* org, int ostride, int r
     const int ipl = nit >> lgG;  // a multiple of 4 except on teams smaller than a wavefront (host simulation)
     for (int c = 0; c < n; c++) {
       const auto x = cand(c);
+      // the whole wave works on this candidate: one wave-uniform decision whether its block lies inside the staged window
+      const int use_win = TKU(win.on && x.dx >= win.ox && x.dx + width <= win.ox + win.Ww && x.dy >= win.oy && x.dy + height <= win.oy + win.Wh);
+      const int wbase = (x.dy - win.oy) * win.pitch + (x.dx - win.ox) * (int)sizeof(PIX);
       int sad = 0;
       for (int k0 = 0; k0 < ipl; k0 += 4) {
         Seg16 o[4], r[4];
@@ -242,7 +249,8 @@ TK_DEV void seg_sads_nb(const Team t, int n_, const PIX* org, int ostride, int r
           if (k0 + k < ipl) {
             const int q = sub + (k0 + k) * G, i = q >> lgr, j = (q & ((1 << lgr) - 1)) * lw;
             o[k] = seg_load<SP, NB>(org + i * ostride + j);
-            r[k] = seg_load<SP_GLOBAL, NB>(x.p + i * rstride + j);
+            if (use_win) r[k] = win_seg<NB>(win.w32, wbase + i * win.pitch + j * (int)sizeof(PIX));
+            else r[k] = seg_load<SP_GLOBAL, NB>(x.p + i * rstride + j);
           }
 #if !TK_HOST
 #pragma unroll
@@ -441,24 +449,29 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
   // when the whole window lies inside the padded reference plane (otherwise every pass of this search reads the plane).
   MeWin win;
   win.on = 0; win.w32 = nullptr; win.ox = win.oy = win.Ww = win.Wh = win.pitch = 0;
-  if constexpr (sizeof(PIX) == 1) {
-    if (w->win && a.width <= kMeWinMaxPu && a.height <= kMeWinMaxPu && a.speed == 0) {
-      win.Ww = a.width + 2 * kMeWinR; win.Wh = a.height + 2 * kMeWinR; win.pitch = win.Ww + 4;
-      win.ox = s * (mv_ref.x >> 2) - kMeWinR; win.oy = s * (mv_ref.y >> 2) - kMeWinR;
+  {
+    const int S = (int)sizeof(PIX);
+    const int cap = TKU(w->win_cap);
+    int R = kMeWinR;
+    while (R >= kMeWinRmin && me_win_bytes(a.width, a.height, R, S) > cap) R -= 4;   // wave-uniform
+    if (w->win && R >= kMeWinRmin && a.speed == 0) {
+      win.Ww = a.width + 2 * R; win.Wh = a.height + 2 * R; win.pitch = win.Ww * S + 4;
+      win.ox = s * (mv_ref.x >> 2) - R; win.oy = s * (mv_ref.y >> 2) - R;
       win.w32 = lds_ld(&w_->win);
       win.on = TKU(a.pu_x + win.ox >= -kPadY && a.pu_x + win.ox + win.Ww <= a.fwidth + kPadY && a.pu_y + win.oy >= -kPadY &&
                    a.pu_y + win.oy + win.Wh <= a.fheight + kPadY);
     }
     if (win.on) {
-      const int spr = (win.Ww + 15) >> 4, total = spr * win.Wh;   // 16-byte segments per row; the last one may read past the row (inside the plane's allocation)
+      const int rowb = win.Ww * S;   // a multiple of 4
+      const int spr = (rowb + 15) >> 4, total = spr * win.Wh;   // 16-byte segments per row; the last one may read past the row (inside the plane's allocation)
       t.sync();
       for (int k0 = 0; k0 < total; k0 += t.size) {
         const int k = k0 + t.rank;
         if (k < total) {
           const int row = k / spr, sg = k - row * spr;
-          const Seg16 v = seg_load<SP_GLOBAL, 16>(ref + (win.oy + row) * a.rstride + win.ox + 16 * sg);
+          const Seg16 v = seg_load<SP_GLOBAL, 16>((const char*)(ref + (win.oy + row) * a.rstride + win.ox) + 16 * sg);
           const int d = (row * win.pitch + 16 * sg) >> 2;
-          const int nd = tmin(4, (win.Ww - 16 * sg) >> 2);   // dwords of this segment that belong to the row
+          const int nd = tmin(4, (rowb - 16 * sg) >> 2);   // dwords of this segment that belong to the row
 #if TK_HOST
           for (int q = 0; q < nd; q++) ((uint32_t*)win.w32)[d + q] = v.d[q];
 #else
@@ -727,7 +740,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
         usp.ver_frac = tk_uniform(usp.ver_frac); usp.hor_frac = tk_uniform(usp.hor_frac);
         k8[c] = subk8_make(usp, tk_uniform(cand[c].sp.ver_int - ctr.ver_int + 1), tk_uniform(cand[c].sp.hor_int - ctr.hor_int + 1), a.enable_bipred);
       }
-      const int sub_in_win = TKU(sizeof(PIX) == 1 && win.on && ctr.hor_int - 3 >= win.ox && ctr.hor_int + a.width + 5 <= win.ox + win.Ww &&
+      const int sub_in_win = TKU(win.on && ctr.hor_int - 3 >= win.ox && ctr.hor_int + a.width + 5 <= win.ox + win.Ww &&
                                  ctr.ver_int - 3 >= win.oy && ctr.ver_int + a.height + 5 <= win.oy + win.Wh);
       if (sizeof(PIX) == 1 && a.width * a.height >= 512) {
         // large PUs: a lane takes a vertical strip of eight samples of one column (tk_pred.h:subk8_strip)
@@ -738,10 +751,18 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
             const int i0 = st << 3;
             const PIX* p0 = ref + (i0 + ctr.ver_int - 3) * a.rstride + (j + ctr.hor_int - 3);
             unsigned long long wb[15];
+            if (sub_in_win) {   // the rows come out of the staged window
+              const int woff = (i0 + ctr.ver_int - 3 - win.oy) * win.pitch + (j + ctr.hor_int - 3 - win.ox);
 #if !TK_HOST
 #pragma unroll
 #endif
-            for (int q = 0; q < 15; q++) wb[q] = gload64(p0 + q * a.rstride) ^ 0x8080808080808080ull;
+              for (int q = 0; q < 15; q++) { const Seg16 sg = win_seg<8>(win.w32, woff + q * win.pitch); wb[q] = (((unsigned long long)sg.d[1] << 32) | sg.d[0]) ^ 0x8080808080808080ull; }
+            } else {
+#if !TK_HOST
+#pragma unroll
+#endif
+              for (int q = 0; q < 15; q++) wb[q] = gload64(p0 + q * a.rstride) ^ 0x8080808080808080ull;
+            }
             int o8[8];
 #if !TK_HOST
 #pragma unroll
@@ -751,6 +772,40 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
 #pragma unroll
 #endif
             for (int c = 0; c < 8; c++) sad8[c] = subk8_strip(wb, k8[c], o8, sad8[c]);
+          }
+        }
+      } else if (sizeof(PIX) == 2) {
+        // 16-bit samples: eight window rows of eight samples per prediction sample (window or plane), candidates by v_dot2 (tk_pred.h:SubK16)
+        if constexpr (sizeof(PIX) == 2) {
+          SubK16 k16[8];
+          for (int c = 0; c < 8; c++) {
+            SubPel usp = cand[c].sp;
+            for (int m = 0; m < 6; m++) { usp.tv[m] = tk_uniform(usp.tv[m]); usp.th[m] = tk_uniform(usp.th[m]); }
+            usp.ver_frac = tk_uniform(usp.ver_frac); usp.hor_frac = tk_uniform(usp.hor_frac);
+            k16[c] = subk16_make(usp, tk_uniform(cand[c].sp.ver_int - ctr.ver_int + 1), tk_uniform(cand[c].sp.hor_int - ctr.hor_int + 1), a.enable_bipred);
+          }
+          for (int r = t.rank; r < a.width * a.height; r += t.size) {
+            int i, j;
+            split2(dw, r, i, j);
+            uint32_t rows[8][4];
+            if (sub_in_win) {
+              const int woff = (i + ctr.ver_int - 3 - win.oy) * win.pitch + (j + ctr.hor_int - 3 - win.ox) * 2;
+#if !TK_HOST
+#pragma unroll
+#endif
+              for (int q = 0; q < 8; q++) { const Seg16 sg = win_seg<16>(win.w32, woff + q * win.pitch); rows[q][0] = sg.d[0]; rows[q][1] = sg.d[1]; rows[q][2] = sg.d[2]; rows[q][3] = sg.d[3]; }
+            } else {
+              const PIX* p0 = ref + (i + ctr.ver_int - 3) * a.rstride + (j + ctr.hor_int - 3);
+#if !TK_HOST
+#pragma unroll
+#endif
+              for (int q = 0; q < 8; q++) { const Seg16 sg = seg_load<SP_GLOBAL, 16>(p0 + q * a.rstride); rows[q][0] = sg.d[0]; rows[q][1] = sg.d[1]; rows[q][2] = sg.d[2]; rows[q][3] = sg.d[3]; }
+            }
+            const int o = (int)orgs[i * a.ostride + j];
+#if !TK_HOST
+#pragma unroll
+#endif
+            for (int c = 0; c < 8; c++) sad8[c] += iabs(o - subk16_sample(rows, k16[c], a.bitdepth));
           }
         }
       } else
@@ -840,15 +895,19 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
 // and (0,0) without touching the count) and its use of the list's full-pel entries
 // as quarter-pel vectors.  The vector is clipped for ref0's sign and then AGAIN for ref1's sign; ref0 is
 // predicted with the once-clipped vector, ref1 and the cost use the twice-clipped one.
+// The search has two phases: the telescope (phase bit 1), which depends only on the block, the two reference planes, mvc and mvp,
+// and the six extra candidates (phase bit 2), which read - and clobber - the candidate list as it stands after the bi-prediction
+// search of the block.  The block decision of a B frame runs the telescope early on another wavefront (tk_block.h:MD_BIJOINT) and
+// hands its result (min_sad_in, *mv_out) to the second phase; phase 3 = both, back to back.
 template <typename PIX, int SP>
 TK_DEVNI unsigned motion_estimate_bi(const Team t, MeWs* w_, const PIX* org_, const PIX* ref0, const PIX* ref1, const MeArgs& a,
-                                    mv_t mvc, mv_t mvp, int r_idx0, mv_t* mv_out) {
+                                    mv_t mvc, mv_t mvp, int r_idx0, mv_t* mv_out, int phase = 3, unsigned min_sad_in = kCostInit) {
   const auto org = spc<SP>(org_);
   const auto lists = ldsc(lds_ld(&w_->lists));
   const int sh = a.bitdepth - 8;
   const int size = a.cb_size;
-  unsigned min_sad = kCostInit;
-  mv_t mv_opt = mk_mv(0, 0);
+  unsigned min_sad = (phase & 1) ? (unsigned)kCostInit : min_sad_in;
+  mv_t mv_opt = (phase & 1) ? mk_mv(0, 0) : *mv_out;
   mv_t mv_ref = mk_mv(((mvc.x + 2) >> 2) << 2, ((mvc.y + 2) >> 2) << 2);
   struct BI { mv_t mv; SubPel s0, s1; };
   auto mk_bi = [&](mv_t mv) -> BI {
@@ -871,7 +930,7 @@ TK_DEVNI unsigned motion_estimate_bi(const Team t, MeWs* w_, const PIX* org_, co
   auto bi_cost = [&](int, const BI& x, int sad) -> unsigned {
     return ((unsigned)sad >> sh) + mv_cost(a.lam, (int16_t)(x.mv.y - mvp.y), (int16_t)(x.mv.x - mvp.x));
   };
-  for (int step = 32; step > 0; step >>= 1) {
+  for (int step = (phase & 1) ? 32 : 0; step > 0; step >>= 1) {
     // candidate list of this step in the reference's (k outer = y, l inner = x) order
     int ox[9], oy[9], n = 0;
     const int vf = mv_ref.y & 3, hf = mv_ref.x & 3;
@@ -899,6 +958,7 @@ TK_DEVNI unsigned motion_estimate_bi(const Team t, MeWs* w_, const PIX* org_, co
     }
     mv_ref = mv_opt;
   }
+  if (!(phase & 2)) { *mv_out = mv_opt; return min_sad; }
   // extra candidates (+ side effect on the shared list)
   t.sync();
   if (t.rank == 0) {

@@ -291,6 +291,89 @@ TK_DEV int subk8_strip(const unsigned long long* wb, const SubK8& k, const int* 
   return subk8_strip_dy<2>(wb, k, o, sad);
 }
 
+// 16-bit samples: the same sub-pel evaluation with packed int16 dot products (v_dot2_i32_i16).  A window row is eight samples
+// in four dwords (row q = reference row centre.ver_int - 3 + q, sample n = column centre.hor_int - 3 + n); a candidate at integer
+// offset (dy, dx) in 0..2 from centre - 1 takes samples dx .. dx+5 of rows dy .. dy+5 as three sample pairs - the dwords as
+// loaded for an even dx, one v_alignbyte per pair for dx = 1 - against the horizontal taps packed in pairs: a six-tap row sum is
+// three v_dot2, the vertical pass six v_mad_i32_i24 (|row sum| <= 94 * 4095 < 2^19).  Every fractional position except the
+// (1/2, 1/2) centre filter is this one separable form (see SubK8).
+struct SubK16 {
+  uint32_t th2[3];   // horizontal taps (t0,t1) (t2,t3) (t4,t5), low half = first tap
+  int tv[6];
+  int centre, dy, dx;
+};
+TK_DEV SubK16 subk16_make(const SubPel& s, int dy, int dx, int bipred) {
+  SubK16 k;
+  for (int q = 0; q < 3; q++) k.th2[q] = (uint32_t)(uint16_t)(int16_t)s.th[2 * q] | ((uint32_t)(uint16_t)(int16_t)s.th[2 * q + 1] << 16);
+  for (int m = 0; m < 6; m++) k.tv[m] = s.tv[m];
+  k.centre = s.ver_frac == 2 && s.hor_frac == 2 && bipred < 2;
+  k.dy = dy; k.dx = dx;
+  return k;
+}
+TK_DEV int dot2_i16(uint32_t a, uint32_t b, int c) {
+#if TK_HOST
+  return c + (int)(int16_t)(a & 0xffffu) * (int)(int16_t)(b & 0xffffu) + (int)(int16_t)(a >> 16) * (int)(int16_t)(b >> 16);
+#else
+  typedef short __attribute__((ext_vector_type(2))) s16x2;
+  s16x2 x, y;
+  __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4);
+  return __builtin_amdgcn_sdot2(x, y, c, false);
+#endif
+}
+// sample pair q (0..2) of a row (four dwords d) for a candidate at horizontal offset DX
+template <int DX> TK_DEV uint32_t row_pair16(const uint32_t* d, int q) {
+  if constexpr (DX == 0) return d[q];
+  else if constexpr (DX == 2) return d[q + 1];
+  else {
+#if TK_HOST
+    return (d[q] >> 16) | (d[q + 1] << 16);
+#else
+    return __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2);
+#endif
+  }
+}
+// rows: 8 x 4 dwords (row-major)
+template <int DY, int DX> TK_DEV int subk16_sample_t(const uint32_t (*rows)[4], const SubK16& k, int bitdepth) {
+  if (k.centre) {  // 12-tap centre filter (inter_prediction.c:146-160): rows 1 and 4 weigh columns {0,0,1,1,0,0}, rows 2 and 3 {0,1,2,2,1,0}
+    int sum = 8;
+    sum = dot2_i16(0x00010001u, row_pair16<DX>(rows[DY + 1], 1), sum);
+    sum = dot2_i16(0x00010001u, row_pair16<DX>(rows[DY + 4], 1), sum);
+#if !TK_HOST
+#pragma unroll
+#endif
+    for (int m = 2; m <= 3; m++) {
+      sum = dot2_i16(0x00010000u, row_pair16<DX>(rows[DY + m], 0), sum);
+      sum = dot2_i16(0x00020002u, row_pair16<DX>(rows[DY + m], 1), sum);
+      sum = dot2_i16(0x00000001u, row_pair16<DX>(rows[DY + m], 2), sum);
+    }
+    return sat_pix(sum >> 4, bitdepth);
+  }
+  int sum = 2048;
+#if !TK_HOST
+#pragma unroll
+#endif
+  for (int m = 0; m < 6; m++) {
+    const uint32_t* d = rows[DY + m];
+    const int h = dot2_i16(k.th2[0], row_pair16<DX>(d, 0), dot2_i16(k.th2[1], row_pair16<DX>(d, 1), dot2_i16(k.th2[2], row_pair16<DX>(d, 2), 0)));
+    sum += mul24(k.tv[m], h);
+  }
+  return sat_pix(sum >> 12, bitdepth);
+}
+TK_DEV int subk16_sample(const uint32_t (*rows)[4], const SubK16& k, int bitdepth) {
+  // (dy, dx) are wave-uniform: one scalar branch picks the straight-line instance
+  switch (k.dy * 3 + k.dx) {
+    case 0: return subk16_sample_t<0, 0>(rows, k, bitdepth);
+    case 1: return subk16_sample_t<0, 1>(rows, k, bitdepth);
+    case 2: return subk16_sample_t<0, 2>(rows, k, bitdepth);
+    case 3: return subk16_sample_t<1, 0>(rows, k, bitdepth);
+    case 4: return subk16_sample_t<1, 1>(rows, k, bitdepth);
+    case 5: return subk16_sample_t<1, 2>(rows, k, bitdepth);
+    case 6: return subk16_sample_t<2, 0>(rows, k, bitdepth);
+    case 7: return subk16_sample_t<2, 1>(rows, k, bitdepth);
+    default: return subk16_sample_t<2, 2>(rows, k, bitdepth);
+  }
+}
+
 // get_inter_prediction_luma for a whole PU (team-parallel over samples).
 template <int SP, typename PIX>
 TK_DEV void pred_luma(const Team t, PIX* dst_, int dstride, const PIX* ref, int rstride, int width, int height, mv_t mv,

@@ -56,13 +56,16 @@ struct XformWs {
   // stage 1, so the inverse transform's stage-1 buffer (itmp, TRANSPOSED [sample j][coef col i], 32*16 entries) lives in
   // the same storage.  Every stage is a set of dot products of two CONTIGUOUS int16 vectors (a basis row and a data row),
   // read with 16-byte ds_read and multiplied two terms at a time (v_dot2_i32_i16).
-  alignas(16) int16_t in[32 * 32];
-  alignas(16) int16_t tmp[16 * 32];   // forward stage-1 output, TRANSPOSED: tmp[coef i][row j] (stride size1)
-  alignas(16) int16_t coef[16 * 16];  // forward coefficients, compact; reused for the de-quantised ones (rcoef, TRANSPOSED)
+  // (the scalars come first: the arrays end the structure, so that the motion search's window - which borrows in | tmp | coef while
+  // no transform is running - continues into the bytes that follow the structure, SmallWs::win_extra)
   int flag;               // team-shared scalar result
   long long* prof;        // cycle counters (THOR_PROF builds)
   const XformTabs* tabs;  // workgroup-shared constant tables
+  alignas(16) int16_t in[32 * 32];
+  alignas(16) int16_t tmp[16 * 32];   // forward stage-1 output, TRANSPOSED: tmp[coef i][row j] (stride size1)
+  alignas(16) int16_t coef[16 * 16];  // forward coefficients, compact; reused for the de-quantised ones (rcoef, TRANSPOSED)
 };
+static_assert(sizeof(XformWs) == offsetof(XformWs, coef) + 16 * 16 * sizeof(int16_t), "XformWs must end with its arrays");
 
 // entry (i, q) of the N-point basis, log2(32/N) = rs
 TK_DEV int dct_at(const XformWs* ws, int rs, int i, int q) { return ws->tabs->dct32[((i << rs) << 5) + q]; }
