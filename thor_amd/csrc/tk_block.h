@@ -82,10 +82,11 @@ struct WgShared {
   // loaded once by the master, read by every trial of every wave instead of the frame in global memory
   alignas(16) unsigned char org_raw[kLdsBlk * kLdsBlk * 3];
 };
-// Bytes of per-wave LDS that extend the motion search's window beyond the transform workspace it borrows (tk_me.h:MeWin).  With
-// two workgroups per CU a workgroup has 80 KB: the windows of 8-bit PUs up to 64x64 (reach 20) and of 16-bit PUs up to 32x32
-// (reach 16) fit; with three workgroups per CU there is no room (window = transform workspace: 8-bit PUs up to 16x16).
-template <typename PIX> struct WinExtra { enum { bytes = TK_OCC == 2 ? (sizeof(PIX) == 1 ? 7680 : 5632) : 16 }; };
+// Bytes of per-wave LDS that extend the motion search's window beyond the transform workspace it borrows (tk_me.h:MeWin).  The
+// 8-bit kernel runs three workgroups per CU (53 KB of LDS each; two measured 12 % slower at full load, profiles/r04_call2_ab.md):
+// 944 bytes more take 32x32 PUs with a reach of 16 samples.  The 16-bit kernel needs 224 VGPRs and runs two workgroups per CU
+// anyway (80 KB each): 16-bit PUs up to 32x32 with a reach of 16.  -DTK_OCC=2 builds: 8-bit PUs up to 64x64.
+template <typename PIX> struct WinExtra { enum { bytes = sizeof(PIX) == 1 ? (TK_OCC == 2 ? 7680 : 944) : 5376 }; };
 template <typename PIX> struct SmallWs {
   XformWs xf;
   alignas(16) unsigned char win_extra[WinExtra<PIX>::bytes];   // must directly follow xf
@@ -359,9 +360,21 @@ TK_DEV unsigned udot4_u8(unsigned a, unsigned b, unsigned c) {
   return __builtin_amdgcn_udot4(a, b, c, false);
 #endif
 }
-template <int SP, int NW> TK_DEV unsigned ssd_rows_u8(const Team t, const uint8_t* a_, int as, const uint8_t* b_, int bs, int w, int h) {
-  // NW dwords (4 * NW samples) per lane and step; w a multiple of 4 * NW, rows and pointers aligned to 4 * NW bytes
-  const int ppr = w / (4 * NW);
+TK_DEV unsigned udot2_u16(unsigned a, unsigned b, unsigned c) {
+#if TK_HOST
+  return c + (a & 0xffffu) * (b & 0xffffu) + (a >> 16) * (b >> 16);
+#else
+  typedef unsigned short __attribute__((ext_vector_type(2))) u16x2;
+  u16x2 x, y;
+  __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4);
+  return __builtin_amdgcn_udot2(x, y, c, false);
+#endif
+}
+// NW dwords per lane and step (4 * NW 8-bit or 2 * NW 16-bit samples); rows and pointers aligned to 4 * NW bytes.  16-bit samples (up
+// to 12 bits): a lane's share is at most 256 samples x 4095^2 < 2^32, so the same modular arithmetic is exact.
+template <int SP, typename PIX, int NW> TK_DEV unsigned ssd_rows(const Team t, const PIX* a_, int as, const PIX* b_, int bs, int w, int h) {
+  const int spp = 4 * NW / (int)sizeof(PIX);   // samples per piece
+  const int ppr = w / spp;
   const int lg = (ppr & (ppr - 1)) ? -1 : ilog2((unsigned)ppr);
   unsigned sq = 0, ab = 0;
   for (int k = t.rank; k < ppr * h; k += t.size) {
@@ -369,31 +382,37 @@ template <int SP, int NW> TK_DEV unsigned ssd_rows_u8(const Team t, const uint8_
     if (lg >= 0) { i = k >> lg; j = k & (ppr - 1); } else { i = k / ppr; j = k - i * ppr; }
     uint32_t x[NW], y[NW];
 #if TK_HOST
-    __builtin_memcpy(x, a_ + i * as + j * 4 * NW, 4 * NW);
-    __builtin_memcpy(y, b_ + i * bs + j * 4 * NW, 4 * NW);
+    __builtin_memcpy(x, a_ + i * as + j * spp, 4 * NW);
+    __builtin_memcpy(y, b_ + i * bs + j * spp, 4 * NW);
 #else
     typedef uint32_t __attribute__((ext_vector_type(NW))) vec_t;
-    const vec_t xv = *(typename SpT<SP, const vec_t>::ptr)(spc<SP>(a_) + i * as + j * 4 * NW);
-    const vec_t yv = *(typename SpT<SP, const vec_t>::ptr)(spc<SP>(b_) + i * bs + j * 4 * NW);
+    const vec_t xv = *(typename SpT<SP, const vec_t>::ptr)(spc<SP>(a_) + i * as + j * spp);
+    const vec_t yv = *(typename SpT<SP, const vec_t>::ptr)(spc<SP>(b_) + i * bs + j * spp);
     __builtin_memcpy(x, &xv, 4 * NW);
     __builtin_memcpy(y, &yv, 4 * NW);
 #endif
 #if !TK_HOST
 #pragma unroll
 #endif
-    for (int q = 0; q < NW; q++) { sq = udot4_u8(x[q], x[q], udot4_u8(y[q], y[q], sq)); ab = udot4_u8(x[q], y[q], ab); }
+    for (int q = 0; q < NW; q++) {
+      if constexpr (sizeof(PIX) == 1) { sq = udot4_u8(x[q], x[q], udot4_u8(y[q], y[q], sq)); ab = udot4_u8(x[q], y[q], ab); }
+      else { sq = udot2_u16(x[q], x[q], udot2_u16(y[q], y[q], sq)); ab = udot2_u16(x[q], y[q], ab); }
+    }
   }
   return sq - 2u * ab;
 }
 template <int SP, typename PIX>
 TK_DEV typename SsdT<PIX>::type ssd_part(const Team t, const PIX* a_, int as, const PIX* b_, int bs, int w, int h) {
   a_ = tk_uniform_ptr(a_); b_ = tk_uniform_ptr(b_); as = tk_uniform(as); bs = tk_uniform(bs); w = tk_uniform(w); h = tk_uniform(h);
-  if constexpr (sizeof(PIX) == 1) {
-    const unsigned al = (unsigned)(uintptr_t)a_ | (unsigned)(uintptr_t)b_ | (unsigned)as | (unsigned)bs | (unsigned)w;
-    if (!(al & 15u)) return ssd_rows_u8<SP, 4>(t, a_, as, b_, bs, w, h);
-    if (!(al & 7u)) return ssd_rows_u8<SP, 2>(t, a_, as, b_, bs, w, h);
-    if (!(al & 3u)) return ssd_rows_u8<SP, 1>(t, a_, as, b_, bs, w, h);
+#ifndef TK_NOVEC
+  {
+    const int S = (int)sizeof(PIX);
+    const unsigned al = (unsigned)(uintptr_t)a_ | (unsigned)(uintptr_t)b_ | (unsigned)(as * S) | (unsigned)(bs * S) | (unsigned)(w * S);
+    if (!(al & 15u)) return ssd_rows<SP, PIX, 4>(t, a_, as, b_, bs, w, h);
+    if (!(al & 7u)) return ssd_rows<SP, PIX, 2>(t, a_, as, b_, bs, w, h);
+    if (!(al & 3u)) return ssd_rows<SP, PIX, 1>(t, a_, as, b_, bs, w, h);
   }
+#endif
   const auto a = spc<SP>(a_);
   const auto b = spc<SP>(b_);
   typename SsdT<PIX>::type local = 0;

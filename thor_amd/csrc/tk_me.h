@@ -129,6 +129,19 @@ template <typename PIX, int NB> TK_DEV int seg_sad(const Seg16& a, const Seg16& 
 #endif
 }
 
+// Truncating average (a + b) >> 1 per sample of two segments (bi-prediction, inter_prediction.c:228-247): per dword
+// (a & b) + (((a ^ b) >> 1) & M), M = every bit but each sample's top one.
+template <typename PIX> TK_DEV Seg16 seg_avg(const Seg16& a, const Seg16& b) {
+  const uint32_t M = sizeof(PIX) == 1 ? 0x7f7f7f7fu : 0x7fff7fffu;
+  Seg16 r;
+  for (int k = 0; k < 4; k++) r.d[k] = (a.d[k] & b.d[k]) + (((a.d[k] ^ b.d[k]) >> 1) & M);
+  return r;
+}
+// A candidate type with a second reference pointer `p2` is bi-predicted: its block is the truncating average of the blocks at p and p2
+// (same stride); such candidates always read the planes.
+template <class T, class = void> struct CandHasP2 { enum { value = 0 }; };
+template <class T> struct CandHasP2<T, decltype((void)((T*)nullptr)->p2)> { enum { value = 1 }; };
+
 // LDS search window of one motion search: the (w + 2R) x (h + 2R) samples of the reference plane around the search centre, staged
 // once per search with coalesced 16-byte row loads; the telescope, candidate-list, 5-offset, hexagon and sub-pel passes whose
 // blocks lie inside read it with aligned ds_read + v_alignbyte instead of gathering from the vector L1 (one coalesced global
@@ -190,7 +203,8 @@ TK_DEV void seg_sads_iter(const Team t, int n, int c0, int P, int G, int slot, i
     x[u] = cand(c < n ? c : 0);
     outside |= !(x[u].dx >= win.ox && x[u].dx + width <= win.ox + win.Ww && x[u].dy >= win.oy && x[u].dy + height <= win.oy + win.Wh);
   }
-  const int use_win = win.on && team_ballot(t, outside) == 0ull;
+  enum { BI = CandHasP2<decltype(cand(0))>::value };
+  const int use_win = !BI && win.on && team_ballot(t, outside) == 0ull;
   if (use_win) {
 #if !TK_HOST
 #pragma unroll
@@ -201,6 +215,12 @@ TK_DEV void seg_sads_iter(const Team t, int n, int c0, int P, int G, int slot, i
 #pragma unroll
 #endif
     for (int u = 0; u < U; u++) r[u] = seg_load<SP_GLOBAL, NB>(x[u].p + roff);
+    if constexpr (BI) {
+#if !TK_HOST
+#pragma unroll
+#endif
+      for (int u = 0; u < U; u++) r[u] = seg_avg<PIX>(r[u], seg_load<SP_GLOBAL, NB>(x[u].p2 + roff));
+    }
   }
 #if !TK_HOST
 #pragma unroll
@@ -237,7 +257,7 @@ TK_DEV void seg_sads_nb(const Team t, int n_, const PIX* org, int ostride, int r
     for (int c = 0; c < n; c++) {
       const auto x = cand(c);
       // the whole wave works on this candidate: one wave-uniform decision whether its block lies inside the staged window
-      const int use_win = TKU(win.on && x.dx >= win.ox && x.dx + width <= win.ox + win.Ww && x.dy >= win.oy && x.dy + height <= win.oy + win.Wh);
+      const int use_win = TKU(!CandHasP2<decltype(cand(0))>::value && win.on && x.dx >= win.ox && x.dx + width <= win.ox + win.Ww && x.dy >= win.oy && x.dy + height <= win.oy + win.Wh);
       const int wbase = (x.dy - win.oy) * win.pitch + (x.dx - win.ox) * (int)sizeof(PIX);
       int sad = 0;
       for (int k0 = 0; k0 < ipl; k0 += 4) {
@@ -251,6 +271,7 @@ TK_DEV void seg_sads_nb(const Team t, int n_, const PIX* org, int ostride, int r
             o[k] = seg_load<SP, NB>(org + i * ostride + j);
             if (use_win) r[k] = win_seg<NB>(win.w32, wbase + i * win.pitch + j * (int)sizeof(PIX));
             else r[k] = seg_load<SP_GLOBAL, NB>(x.p + i * rstride + j);
+            if constexpr (CandHasP2<decltype(cand(0))>::value) r[k] = seg_avg<PIX>(r[k], seg_load<SP_GLOBAL, NB>(x.p2 + i * rstride + j));
           }
 #if !TK_HOST
 #pragma unroll
@@ -953,7 +974,29 @@ TK_DEVNI unsigned motion_estimate_bi(const Team t, MeWs* w_, const PIX* org_, co
         for (int q = 0; q < 9; q++) if (q == c) { x = ox[q]; y = oy[q]; }
         return mk_bi(mk_mv(centre.x + x, centre.y + y));
       };
-      unsigned long long k = eval_min(t, n, size * size, cand, bi_item, bi_cost);
+      // A step whose candidates all sit on integer positions in both references (every step of 4 quarter-pels and more, unless a
+      // frame-edge clamp of luma_setup interferes) predicts by copying: the SAD against the truncating average of the two displaced
+      // blocks runs on the row-segment evaluator of the uni-directional search (16 bytes of each reference per lane and memory
+      // instruction) instead of one sample per lane and step.
+      int all_int = 1;
+      for (int c = 0; c < n; c++) { const BI x = cand(c); all_int = all_int && !(x.s0.ver_frac | x.s0.hor_frac | x.s1.ver_frac | x.s1.hor_frac); }
+      unsigned long long k;
+      if (TKU(all_int)) {
+        struct FB { mv_t mv; const PIX* p; const PIX* p2; int dx, dy; };
+        auto cand_fp = [&](int c) -> FB {
+          const BI x = cand(c);
+          FB f;
+          f.mv = x.mv; f.dx = f.dy = 0;
+          f.p = ref0 + x.s0.ver_int * a.rstride + x.s0.hor_int;
+          f.p2 = ref1 + x.s1.ver_int * a.rstride + x.s1.hor_int;
+          return f;
+        };
+        MeWin nowin;
+        nowin.on = 0; nowin.w32 = nullptr; nowin.ox = nowin.oy = nowin.Ww = nowin.Wh = nowin.pitch = 0;
+        k = eval_fullpel<SP>(t, n, org_, a.ostride, a.rstride, size, size, nowin, cand_fp,
+                             [&](const FB& x, int sad) -> unsigned { return ((unsigned)sad >> sh) + mv_cost(a.lam, (int16_t)(x.mv.y - mvp.y), (int16_t)(x.mv.x - mvp.x)); });
+      } else
+        k = eval_min(t, n, size * size, cand, bi_item, bi_cost);
       if ((unsigned)(k >> 32) < min_sad) { min_sad = (unsigned)(k >> 32); mv_opt = cand((int)(unsigned)k).mv; }
     }
     mv_ref = mv_opt;

@@ -451,35 +451,38 @@ TK_DEVNI void pred_inter_yuv(const Team t, const Plane3<PIX> ref, PIX* py, PIX* 
 }
 
 // average_blocks_all: truncating (a+b)>>1 (inter_prediction.c:228-247).
-// 8-bit samples, four per dword: (a + b) >> 1 per byte = (a & b) + (((a ^ b) >> 1) & 0x7f7f7f7f) (no carry crosses a byte).
-template <int SP> TK_DEV void average_rows_u8(const Team t, uint8_t* d_, const uint8_t* a_, const uint8_t* b_, int stride, int w, int h) {
-  const int ppr = w >> 2;
+// Four 8-bit or two 16-bit samples per dword: (a + b) >> 1 per sample = (a & b) + (((a ^ b) >> 1) & M), M = all bits but each sample's
+// top one (no carry crosses a sample).
+template <int SP, typename PIX> TK_DEV void average_rows(const Team t, PIX* d_, const PIX* a_, const PIX* b_, int stride, int w, int h) {
+  const int spp = 4 / (int)sizeof(PIX);
+  const uint32_t M = sizeof(PIX) == 1 ? 0x7f7f7f7fu : 0x7fff7fffu;
+  const int ppr = w / spp;
   for (int k = t.rank; k < ppr * h; k += t.size) {
     const int i = k / ppr, j = k - i * ppr;   // ppr is a power of two except on frame-edge rectangles
-    const int o = i * stride + 4 * j;
+    const int o = i * stride + spp * j;
 #if TK_HOST
     uint32_t x, y;
     __builtin_memcpy(&x, a_ + o, 4); __builtin_memcpy(&y, b_ + o, 4);
-    const uint32_t r = (x & y) + (((x ^ y) >> 1) & 0x7f7f7f7fu);
+    const uint32_t r = (x & y) + (((x ^ y) >> 1) & M);
     __builtin_memcpy(d_ + o, &r, 4);
 #else
     const uint32_t x = *(typename SpT<SP, const uint32_t>::ptr)(spc<SP>(a_) + o), y = *(typename SpT<SP, const uint32_t>::ptr)(spc<SP>(b_) + o);
-    *(typename SpT<SP, uint32_t>::ptr)(spc<SP>(d_) + o) = (x & y) + (((x ^ y) >> 1) & 0x7f7f7f7fu);
+    *(typename SpT<SP, uint32_t>::ptr)(spc<SP>(d_) + o) = (x & y) + (((x ^ y) >> 1) & M);
 #endif
   }
 }
 template <int SP, typename PIX>
 TK_DEV void average_yuv(const Team t, PIX* dy_, PIX* du_, PIX* dv_, const PIX* ay_, const PIX* au_, const PIX* av_,
                         const PIX* by_, const PIX* bu_, const PIX* bv_, int size, int bw, int bh) {
-  if constexpr (sizeof(PIX) == 1) {
-    // sample blocks are 16-byte aligned with a row pitch of `size` (>= 8): dword pieces whenever the width allows
-    if (tk_uniform(!((bw | size) & 7))) {
-      average_rows_u8<SP>(t, dy_, ay_, by_, size, bw, bh);
-      average_rows_u8<SP>(t, du_, au_, bu_, size >> 1, bw >> 1, bh >> 1);
-      average_rows_u8<SP>(t, dv_, av_, bv_, size >> 1, bw >> 1, bh >> 1);
-      return;
-    }
+#ifndef TK_NOVEC
+  // sample blocks are 16-byte aligned with a row pitch of `size` (>= 8): dword pieces whenever the width allows
+  if (tk_uniform(!((bw | size) & 7))) {
+    average_rows<SP>(t, dy_, ay_, by_, size, bw, bh);
+    average_rows<SP>(t, du_, au_, bu_, size >> 1, bw >> 1, bh >> 1);
+    average_rows<SP>(t, dv_, av_, bv_, size >> 1, bw >> 1, bh >> 1);
+    return;
   }
+#endif
   const auto dy = spc<SP>(dy_); const auto du = spc<SP>(du_); const auto dv = spc<SP>(dv_);
   const auto ay = spc<SP>(ay_); const auto au = spc<SP>(au_); const auto av = spc<SP>(av_);
   const auto by = spc<SP>(by_); const auto bu = spc<SP>(bu_); const auto bv = spc<SP>(bv_);

@@ -326,7 +326,11 @@ TK_DEV void copy_block(const Team t, PIX* dst_, int dstride, const PIX* src_, in
   // widest piece that divides the row and keeps every access aligned (wave-uniform): a 64x64 block moves in 4 steps of 16-byte
   // pieces instead of 64 steps of single samples
   const int S = (int)sizeof(PIX);
+#ifdef TK_NOVEC   // A/B build: sample by sample
+  const unsigned al = 1u;
+#else
   const unsigned al = (unsigned)(uintptr_t)dst_ | (unsigned)(uintptr_t)src_ | (unsigned)(dstride * S) | (unsigned)(sstride * S) | (unsigned)(w * S);
+#endif
   if (!(al & 15u)) { copy_rows_vec<SD, SS, 16>(t, dst_, dstride * S, src_, sstride * S, w * S, h); return; }
   if (!(al & 7u)) { copy_rows_vec<SD, SS, 8>(t, dst_, dstride * S, src_, sstride * S, w * S, h); return; }
   if (!(al & 3u)) { copy_rows_vec<SD, SS, 4>(t, dst_, dstride * S, src_, sstride * S, w * S, h); return; }
