@@ -19,6 +19,9 @@ struct BitSink {
   // is a chain of register operations plus fire-and-forget stores instead of a global read-modify-write per syntax element.
   uint32_t acc = 0;
   int fill = 0;
+  // cooperative emission (every lane of a team runs the same emission code on wave-uniform values): only the lane with store != 0
+  // writes the words
+  int store = 1;
 };
 // Start / finish emitting at b.pos (one lane).  Bits of the last word beyond the end position are unspecified (they always
 // were: positions are rewound and re-emitted during the quadtree walk; consumers read pos bits).
@@ -27,7 +30,7 @@ TK_DEV void bs_open(BitSink& b) {
   b.acc = (b.emit && b.fill && b.pos < b.cap) ? b.buf[b.pos >> 5] >> (32 - b.fill) : 0u;
 }
 TK_DEV void bs_close(BitSink& b) {
-  if (b.emit && b.fill && !b.ovf) b.buf[b.pos >> 5] = b.acc << (32 - b.fill);
+  if (b.emit && b.fill && !b.ovf && b.store) b.buf[b.pos >> 5] = b.acc << (32 - b.fill);
 }
 
 // E = false: counting only (the emission code is not even compiled into the caller: the counting instances are the ones
@@ -45,7 +48,7 @@ template <bool E> TK_DEV void bs_put_t(BitSink& b, int n, uint32_t val) {
         b.fill += n;
       } else {
         const int lo = n - room;  // bits that go to the next word
-        b.buf[b.pos >> 5] = (room >= 32 ? 0u : (b.acc << room)) | (val >> lo);
+        if (b.store) b.buf[b.pos >> 5] = (room >= 32 ? 0u : (b.acc << room)) | (val >> lo);
         b.acc = lo ? (val & ((1u << lo) - 1u)) : 0u;
         b.fill = lo;
       }
@@ -115,22 +118,15 @@ template <bool E> TK_DEV void bs_mv_t(BitSink& b, mv_t mv, mv_t mvp) {
 }
 
 // write_coeff (enc/write_bits.c:145-241). coeff: qsize x qsize row-major (qsize=min(size,16)),
-// type bit0 = chroma, bit1 = intra block.
-TK_DEVNI void bs_coeff(BitSink& b, const int16_t* coeff, int size, int type) {
-  const int qsize = size < kMaxQuant ? size : kMaxQuant;
-  const int N = qsize * qsize;
-  const int16_t* izz = qsize == 4 ? TK_TAB.izz4 : (qsize == 8 ? TK_TAB.izz8 : TK_TAB.izz16);
+// type bit0 = chroma, bit1 = intra block.  get(pos) -> coefficient at scan position pos; last_pos: the last non-zero scan position (0 if none).
+template <class GetF> TK_DEV void bs_coeff_body(BitSink& b, GetF get, int N, int last_pos, int size, int type) {
   const int chroma = type & 1, intra = (type >> 1) & 1;
   int vlc_adaptive = intra && !chroma;
   const uint32_t eob_pos = chroma ? 0u : 2u;
   const int runtab = (chroma && size <= 8) ? 10 : 6;
-
-  int last_pos = N - 1;
-  while (last_pos > 0 && coeff[izz[last_pos]] == 0) last_pos--;
-
   int pos = 0;
   if (chroma) {
-    int c0 = coeff[izz[0]];
+    int c0 = get(0);
     if (last_pos == 0 && iabs(c0) == 1) { bs_put(b, 2, 2u + (c0 < 0)); pos = N; }
     else bs_put(b, 1, 0);
   }
@@ -139,7 +135,7 @@ TK_DEVNI void bs_coeff(BitSink& b, const int16_t* coeff, int size, int type) {
     int c;
     if (level_mode) {
       while (pos <= last_pos && level > 0) {
-        c = coeff[izz[pos++]];
+        c = get(pos++);
         level = iabs(c);
         bs_vlc(b, vlc_adaptive, (uint32_t)level);
         if (level > 0) bs_put(b, 1, c < 0);
@@ -149,7 +145,7 @@ TK_DEVNI void bs_coeff(BitSink& b, const int16_t* coeff, int size, int type) {
     int run = 0;
     c = 0;
     while (c == 0 && pos <= last_pos) {
-      c = coeff[izz[pos++]];
+      c = get(pos++);
       run += !c;
       if (c) {
         level = iabs(c);
@@ -165,6 +161,49 @@ TK_DEVNI void bs_coeff(BitSink& b, const int16_t* coeff, int size, int type) {
   }
   if (pos < N && level_mode) { bs_vlc(b, vlc_adaptive, 0); pos++; }
   if (pos < N) bs_vlc(b, runtab, eob_pos);
+}
+// one lane alone
+TK_DEVNI void bs_coeff(BitSink& b, const int16_t* coeff, int size, int type) {
+  const int qsize = size < kMaxQuant ? size : kMaxQuant;
+  const int N = qsize * qsize;
+  const int16_t* izz = qsize == 4 ? TK_TAB.izz4 : (qsize == 8 ? TK_TAB.izz8 : TK_TAB.izz16);
+  int last_pos = N - 1;
+  while (last_pos > 0 && coeff[izz[last_pos]] == 0) last_pos--;
+  bs_coeff_body(b, [&](int pos) -> int { return (int)coeff[izz[pos]]; }, N, last_pos, size, type);
+}
+// Every lane of the team (cooperative emission, b.store marks the lane that writes).  The one-lane form walks the scan with two
+// dependent memory round trips per position (scan table, coefficient); here the lanes fetch the coefficients of all scan positions
+// at once (up to 256 = four per lane), the last non-zero position comes out of a ballot, and the sequential run / level automaton
+// runs on wave-uniform values read back with v_readlane - scalar code, no memory access per position.
+TK_DEVNI void bs_coeff_team(BitSink& b, const Team t, const int16_t* coeff, int size, int type) {
+  const int qsize = size < kMaxQuant ? size : kMaxQuant;
+  const int N = qsize * qsize;
+#if TK_HOST
+  (void)t;
+  const int16_t* izz = qsize == 4 ? TK_TAB.izz4 : (qsize == 8 ? TK_TAB.izz8 : TK_TAB.izz16);
+  int last_pos = N - 1;
+  while (last_pos > 0 && coeff[izz[last_pos]] == 0) last_pos--;
+  bs_coeff_body(b, [&](int pos) -> int { return (int)coeff[izz[pos]]; }, N, last_pos, size, type);
+#else
+  coeff = tk_uniform_ptr(coeff);
+  const IzzRef izzr = izz_ref(t, qsize);
+  int v[4];
+  int last_pos = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int p = q * 64 + t.rank;
+    v[q] = p < N ? (int)coeff[izzr.z[p]] : 0;
+    const unsigned long long m = __ballot(v[q] != 0);
+    if (m) last_pos = q * 64 + top_set(m);
+  }
+  last_pos = tk_uniform(last_pos);
+  bs_coeff_body(b, [&](int pos) -> int {
+    pos = tk_uniform(pos);
+    const int q = pos >> 6;
+    const int x = q == 0 ? v[0] : q == 1 ? v[1] : q == 2 ? v[2] : v[3];
+    return __builtin_amdgcn_readlane(x, pos & 63);
+  }, N, last_pos, size, type);
+#endif
 }
 
 // Everything write_block / write_super_mode read besides the block parameters.
@@ -327,6 +366,7 @@ TK_DEV int cbp_code(int cbp) {  // cbp_table (enc/write_bits.c:382)
 // `t`: team for cooperative counting (b.emit == 0, all lanes call) or nullptr (single-lane emission).
 template <bool E, int SC> TK_DEV void bs_coeff_any(BitSink& b, const Team* t, const int16_t* coeff, int size, int type) {
   if (!E) b.pos += coeff_bits_team<SC>(*t, coeff, size, type);
+  else if (t) bs_coeff_team(b, *t, coeff, size, type);   // cooperative emission
   else bs_coeff(b, coeff, size, type);
 }
 
@@ -393,13 +433,14 @@ template <bool E> TK_DEV void bs_block_head_t(BitSink& b, const SynCtx& s, const
 }
 
 // E = false: cooperative counting (every lane of the team calls, b.emit == 0, tm != nullptr) - the instance all RDO trials
-// use; E = true: emission by ONE lane (or serial counting when tm == nullptr).
+// use; E = true: emission - by every lane of the team (tm != nullptr, BitSink::store marks the lane that writes) or by one lane alone.
 // SCC: address space of the CHROMA coefficient buffers in counting mode (luma is always SP_LDS on the device).
 template <bool E, int SCC = SP_LDS>
 TK_DEVNI int bs_block_t(BitSink& b, const SynCtx& s_in, const BlkParam& p_in, const int16_t* cy, const int16_t* cu,
                     const int16_t* cv, const Team* tm, const int* ybits) {
-  // only in cooperative counting mode: the emitting call is made by one lane alone
-  const bool coop = !E;
+  // cooperative counting, or cooperative emission (tm != nullptr: every lane of the team runs the emission on the same values);
+  // otherwise the emitting call is made by one lane alone
+  const bool coop = !E || tm != nullptr;
   const SynCtx s = coop ? uniform_syn(s_in) : s_in;
   const BlkParam p = coop ? uniform_blk(p_in) : p_in;
   const int start = b.pos;

@@ -1806,10 +1806,12 @@ TK_DEVNI int final_encode(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd, BitS
   int nbits = 0;
   if (snap) {
     // the winning trial of the parallel decision left its reconstruction and coefficients in its wave's snapshot: emit + copy
-    if (t.rank == 0) {
+    {
+      // cooperative emission: every lane runs the syntax on the same values, lane 0 writes the words (tk_bits.h:bs_coeff_team)
       BitSink w = out;
+      w.store = t.rank == 0;
       bs_open(w);
-      bs_block_t<true>(w, lds_ld(&nd.syn), p, snap->best_cy, snap->best_cu, snap->best_cv, nullptr, nullptr);
+      bs_block_t<true>(w, lds_ld(&nd.syn), p, snap->best_cy, snap->best_cu, snap->best_cv, &t, nullptr);
       bs_close(w);
       out.ovf |= w.ovf;
       nbits = w.pos - out.pos;
@@ -1830,11 +1832,12 @@ TK_DEVNI int final_encode(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd, BitS
       cnt.buf = nullptr; cnt.pos = 0; cnt.cap = 0; cnt.emit = 0; cnt.ovf = 0;
       nbits = encode_block<PIX, SP>(t, J, ws, nd, p, cnt);
     }
-    // bits (one lane), then recon copy and cells (all lanes)
-    if (t.rank == 0) {
+    // bits (cooperative emission), then recon copy and cells
+    {
       BitSink w = out;
+      w.store = t.rank == 0;
       bs_open(w);
-      bs_block_t<true>(w, lds_ld(&nd.syn), p, ws->coef_y, ws->coef_u, ws->coef_v, nullptr, nullptr);
+      bs_block_t<true>(w, lds_ld(&nd.syn), p, ws->coef_y, ws->coef_u, ws->coef_v, &t, nullptr);
       bs_close(w);
       out.ovf |= w.ovf;
     }

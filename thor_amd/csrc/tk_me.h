@@ -805,6 +805,37 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
             usp.ver_frac = tk_uniform(usp.ver_frac); usp.hor_frac = tk_uniform(usp.hor_frac);
             k16[c] = subk16_make(usp, tk_uniform(cand[c].sp.ver_int - ctr.ver_int + 1), tk_uniform(cand[c].sp.hor_int - ctr.hor_int + 1), a.enable_bipred);
           }
+          if (a.width * a.height >= 512) {
+            // large PUs: a lane takes a vertical strip of eight samples of one column (tk_pred.h:subk16_strip)
+            for (int r = t.rank; r < a.width * (a.height >> 3); r += t.size) {
+              int st, j;
+              split2(dw, r, st, j);
+              const int i0 = st << 3;
+              uint32_t wb[15][4];
+              if (sub_in_win) {
+                const int woff = (i0 + ctr.ver_int - 3 - win.oy) * win.pitch + (j + ctr.hor_int - 3 - win.ox) * 2;
+#if !TK_HOST
+#pragma unroll
+#endif
+                for (int q = 0; q < 15; q++) { const Seg16 sg = win_seg<16>(win.w32, woff + q * win.pitch); wb[q][0] = sg.d[0]; wb[q][1] = sg.d[1]; wb[q][2] = sg.d[2]; wb[q][3] = sg.d[3]; }
+              } else {
+                const PIX* p0 = ref + (i0 + ctr.ver_int - 3) * a.rstride + (j + ctr.hor_int - 3);
+#if !TK_HOST
+#pragma unroll
+#endif
+                for (int q = 0; q < 15; q++) { const Seg16 sg = seg_load<SP_GLOBAL, 16>(p0 + q * a.rstride); wb[q][0] = sg.d[0]; wb[q][1] = sg.d[1]; wb[q][2] = sg.d[2]; wb[q][3] = sg.d[3]; }
+              }
+              int o8[8];
+#if !TK_HOST
+#pragma unroll
+#endif
+              for (int q = 0; q < 8; q++) o8[q] = (int)orgs[(i0 + q) * a.ostride + j];
+#if !TK_HOST
+#pragma unroll
+#endif
+              for (int c = 0; c < 8; c++) sad8[c] = subk16_strip(wb, k16[c], o8, sad8[c], a.bitdepth);
+            }
+          } else
           for (int r = t.rank; r < a.width * a.height; r += t.size) {
             int i, j;
             split2(dw, r, i, j);

@@ -374,6 +374,61 @@ TK_DEV int subk16_sample(const uint32_t (*rows)[4], const SubK16& k, int bitdept
   }
 }
 
+// The same for a vertical strip of eight samples of one column (16-bit PUs of 512 samples and more; see subk8_strip): 13 row sums
+// (39 v_dot2) serve eight samples instead of 144, 15 row loads instead of 64.  wb: 15 rows of four dwords starting at reference row
+// centre.ver_int - 3 + (first sample row); o: the eight original samples.
+template <int DY, int DX> TK_DEV int subk16_strip_t(const uint32_t (*wb)[4], const SubK16& k, const int* o, int sad, int bitdepth) {
+  if (k.centre) {
+    int ra[12], rb[12];
+#if !TK_HOST
+#pragma unroll
+#endif
+    for (int q = 1; q < 12; q++) {
+      const uint32_t* d = wb[DY + q];
+      ra[q] = dot2_i16(0x00010001u, row_pair16<DX>(d, 1), 0);
+      rb[q] = dot2_i16(0x00010000u, row_pair16<DX>(d, 0), dot2_i16(0x00020002u, row_pair16<DX>(d, 1), dot2_i16(0x00000001u, row_pair16<DX>(d, 2), 0)));
+    }
+#if !TK_HOST
+#pragma unroll
+#endif
+    for (int p = 0; p < 8; p++) sad += iabs(o[p] - sat_pix((8 + ra[p + 1] + rb[p + 2] + rb[p + 3] + ra[p + 4]) >> 4, bitdepth));
+    return sad;
+  }
+  int hs[13];
+#if !TK_HOST
+#pragma unroll
+#endif
+  for (int q = 0; q < 13; q++) {
+    const uint32_t* d = wb[DY + q];
+    hs[q] = dot2_i16(k.th2[0], row_pair16<DX>(d, 0), dot2_i16(k.th2[1], row_pair16<DX>(d, 1), dot2_i16(k.th2[2], row_pair16<DX>(d, 2), 0)));
+  }
+#if !TK_HOST
+#pragma unroll
+#endif
+  for (int p = 0; p < 8; p++) {
+    int sum = 2048;
+#if !TK_HOST
+#pragma unroll
+#endif
+    for (int m = 0; m < 6; m++) sum += mul24(k.tv[m], hs[p + m]);
+    sad += iabs(o[p] - sat_pix(sum >> 12, bitdepth));
+  }
+  return sad;
+}
+TK_DEV int subk16_strip(const uint32_t (*wb)[4], const SubK16& k, const int* o, int sad, int bitdepth) {
+  switch (k.dy * 3 + k.dx) {
+    case 0: return subk16_strip_t<0, 0>(wb, k, o, sad, bitdepth);
+    case 1: return subk16_strip_t<0, 1>(wb, k, o, sad, bitdepth);
+    case 2: return subk16_strip_t<0, 2>(wb, k, o, sad, bitdepth);
+    case 3: return subk16_strip_t<1, 0>(wb, k, o, sad, bitdepth);
+    case 4: return subk16_strip_t<1, 1>(wb, k, o, sad, bitdepth);
+    case 5: return subk16_strip_t<1, 2>(wb, k, o, sad, bitdepth);
+    case 6: return subk16_strip_t<2, 0>(wb, k, o, sad, bitdepth);
+    case 7: return subk16_strip_t<2, 1>(wb, k, o, sad, bitdepth);
+    default: return subk16_strip_t<2, 2>(wb, k, o, sad, bitdepth);
+  }
+}
+
 // get_inter_prediction_luma for a whole PU (team-parallel over samples).
 template <int SP, typename PIX>
 TK_DEV void pred_luma(const Team t, PIX* dst_, int dstride, const PIX* ref, int rstride, int width, int height, mv_t mv,
