@@ -338,7 +338,7 @@ def main():
     if nv is None:
         nv = max(a.warmup + 2, 7)
         t_cpu_frame = w * h / 0.33e6 * (1.3 if hbd else 1.0)
-        est_gpu_s = nframes * w * h * S / (90e6 if a.config == 'ldb' and not hbd else 40e6)
+        est_gpu_s = nframes * w * h * S / (110e6 if a.config == "ldb" and not hbd else 60e6)
         nv = max(nv, int(est_gpu_s / t_cpu_frame))
     nv = max(1, min(nv, nframes))
     hq = int(p.HQperiod) if not reordered else 0

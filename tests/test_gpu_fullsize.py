@@ -8,6 +8,7 @@ an hour of CPU for these, so they are not run live).  Clips come from the seeded
   * 64 closed 1080p streams in one lock-step run, every stream against its own per-chunk reference run     - 8e / the bench regime
   * round 3, the frames the bench times: 3840x2160 I+5P (4 references + bi-prediction), 1080p 14 frames across HQperiod, and
     the 64-stream set with 6 frames per stream
+  * round 4: 3840x2160 10-bit with a full 16-frame HDB16 sub-GOP (config 5 as specified), 3840x2160 I+5P on the hard (sigma 6) content
 """
 import json
 import os
@@ -39,7 +40,7 @@ def _frames(c):
 
 
 @pytest.mark.parametrize('name', [n for n in ('1080p_ldb_n5_q32', '4k_ldb_n2_q32', '4k_hdb16_10bit_n3_q32', 'hdb16_416x240_10bit_n17_q32',
-                                              '4k_ra_n9_q27', '4k_ldb_n6_q32', '1080p_ldb_n14_q32') if n in BIG])
+                                              '4k_ra_n9_q27', '4k_ldb_n6_q32', '1080p_ldb_n14_q32', '4k_hdb16_10bit_n17_q32', '4k_ldb_sigma6_n6_q32') if n in BIG])
 def test_full_size_configuration_matches_reference_golden(name):
     c = BIG[name]
     bits, rec = _encode(c, [_frames(c)])

@@ -45,7 +45,9 @@ __device__ Tables g_tab;
 // 4 waves per CU = 3 waves per SIMD (168 VGPRs each), 768 workgroups resident on the chip.
 enum { kWgThreads = 64 * kWaves };
 enum { kOcc = TK_OCC };   // wavefronts per SIMD the register allocation is sized for (168 VGPRs); 2 and 4 measured slower (profiles/r02_ab_variants.md)
-template <typename PIX> __global__ __launch_bounds__(kWgThreads, kOcc) void k_superblocks(const FrameJob<PIX>* jobs, DfArgs A) {
+// 16-bit samples: two waves per SIMD (256 VGPRs; the 16-bit instances need ~245 and their 80 KB of LDS per workgroup allow two per CU anyway) -
+// the register budget of a kernel is also the budget of every function only it calls.
+template <typename PIX> __global__ __launch_bounds__(kWgThreads, (sizeof(PIX) == 1 ? (int)kOcc : 2)) void k_superblocks(const FrameJob<PIX>* jobs, DfArgs A) {
   __shared__ FrameJob<PIX> sJ;
   __shared__ WgShared sh;
   __shared__ SmallWs<PIX> sws[kWaves];

@@ -117,6 +117,66 @@ TK_DEV int dot_i16(const lds_i16* a, const lds_i16* b, int n, int rot) {
 
 TK_DEV void fwd_core(const Team t, XformWs* ws, int size1, int qsize, int shift_1);
 
+// NS consecutive samples (NS * sizeof(PIX) = 2, 4, 8 or 16 bytes, aligned to that) as ONE memory instruction.  SP: address space of p.
+template <int SP, typename PIX, int NS> TK_DEV void load_samples(const PIX* p, int* out) {
+  enum { B = NS * (int)sizeof(PIX) };
+  static_assert(B == 2 || B == 4 || B == 8 || B == 16, "piece size");
+  PIX v[NS];
+#if TK_HOST
+  __builtin_memcpy(v, p, B);
+#else
+  if constexpr (B == 2) { const uint16_t x = *(typename SpT<SP, const uint16_t>::ptr)spc<SP>(p); __builtin_memcpy(v, &x, 2); }
+  else {
+    typedef uint32_t __attribute__((ext_vector_type(B / 4))) vec_t;
+    const vec_t x = *(typename SpT<SP, const vec_t>::ptr)spc<SP>(p);
+    __builtin_memcpy(v, &x, B);
+  }
+#endif
+  for (int q = 0; q < NS; q++) out[q] = (int)v[q];
+}
+template <int SP, typename PIX, int NS> TK_DEV void store_samples(PIX* p, const int* in) {
+  enum { B = NS * (int)sizeof(PIX) };
+  PIX v[NS];
+  for (int q = 0; q < NS; q++) v[q] = (PIX)in[q];
+#if TK_HOST
+  __builtin_memcpy(p, v, B);
+#else
+  if constexpr (B == 2) { uint16_t x; __builtin_memcpy(&x, v, 2); *(typename SpT<SP, uint16_t>::ptr)spc<SP>(p) = x; }
+  else {
+    typedef uint32_t __attribute__((ext_vector_type(B / 4))) vec_t;
+    vec_t x;
+    __builtin_memcpy(&x, v, B);
+    *(typename SpT<SP, vec_t>::ptr)spc<SP>(p) = x;
+  }
+#endif
+}
+// box sum of one scale x scale cell of the residual, rows of NS = scale samples per memory instruction (transform.c:262-277: the
+// running sum saturates after every sample, in raster order)
+template <int SP, typename PIX, int NS> TK_DEV int box_residual(const PIX* org, int ostride, const PIX* pred, int pstride) {
+  int sum = 0;
+#if !TK_HOST
+#pragma nounroll   // a rolled row loop: unrolled, the compiler fetches and unpacks all NS x NS samples at once (VGPR budget of the 8-bit kernel)
+#endif
+  for (int m = 0; m < NS; m++) {
+    int o[NS], p[NS];
+    load_samples<SP, PIX, NS>(org + m * ostride, o);
+    load_samples<SP, PIX, NS>(pred + m * pstride, p);
+    for (int n = 0; n < NS; n++) sum = clampi((int16_t)sum + (int16_t)(o[n] - p[n]), -16384, 16383);
+  }
+  return sum;
+}
+template <int SP, typename PIX, int NS> TK_DEV void box_recon(int r, const PIX* pred, int pstride, PIX* rec, int rstride, int bitdepth) {
+#if !TK_HOST
+#pragma nounroll
+#endif
+  for (int m = 0; m < NS; m++) {
+    int p[NS];
+    load_samples<SP, PIX, NS>(pred + m * pstride, p);
+    for (int n = 0; n < NS; n++) p[n] = sat_pix(r + p[n], bitdepth);
+    store_samples<SP, PIX, NS>(rec + m * rstride, p);
+  }
+}
+
 // Forward transform of (org - pred) -> ws->coef (qsize x qsize compact).
 template <typename PIX, int SP>
 TK_DEV void fwd_transform(const Team t, XformWs* ws, const PIX* org_, int ostride, const PIX* pred_, int pstride,
@@ -131,6 +191,48 @@ TK_DEV void fwd_transform(const Team t, XformWs* ws, const PIX* org_, int ostrid
   }
   // residual (+ optional saturating box sum, transform.c:262-277)
   lds_i16* const in_l = TK_LDS_PTR(ws->in);
+#ifndef TK_NOVEC
+  {
+    // four residuals (scale 1) or one box of scale x scale samples per lane and step, rows in single memory instructions; every TU /
+    // block position and stride is a multiple of four samples - checked (wave-uniform), sample by sample otherwise
+    const int S = (int)sizeof(PIX);
+    const unsigned al = (unsigned)(uintptr_t)org_ | (unsigned)(uintptr_t)pred_ | (unsigned)(ostride * S) | (unsigned)(pstride * S);
+    const int step = scale == 1 ? 4 : scale;
+    if (tk_uniform(!(al & (unsigned)(step * S - 1)))) {
+      if (scale == 1) {
+        const int ppr = size1 >> 2, lg = ilog2((unsigned)ppr);
+        for (int k = t.rank; k < ppr * size1; k += t.size) {
+          const int i = k >> lg, j = (k & (ppr - 1)) << 2;
+          int o[4], p[4];
+          load_samples<SP, PIX, 4>(org_ + i * ostride + j, o);
+          load_samples<SP, PIX, 4>(pred_ + i * pstride + j, p);
+          int16_t r4[4];
+          for (int q = 0; q < 4; q++) r4[q] = (int16_t)(o[q] - p[q]);
+#if TK_HOST
+          __builtin_memcpy(ws->in + i * size1 + j, r4, 8);
+#else
+          typedef uint32_t __attribute__((ext_vector_type(2))) v2;
+          v2 x;
+          __builtin_memcpy(&x, r4, 8);
+          *(TK_LDS v2*)(in_l + i * size1 + j) = x;
+#endif
+        }
+      } else {
+        for (int k = t.rank; k < size1 * size1; k += t.size) {
+          int i, j;
+          split2(mk_pow2(size1), k, i, j);
+          const PIX* o = org_ + i * scale * ostride + j * scale;
+          const PIX* p = pred_ + i * scale * pstride + j * scale;
+          in_l[i * size1 + j] = (int16_t)(scale == 2 ? box_residual<SP, PIX, 2>(o, ostride, p, pstride)
+                                          : scale == 4 ? box_residual<SP, PIX, 4>(o, ostride, p, pstride) : box_residual<SP, PIX, 8>(o, ostride, p, pstride));
+        }
+      }
+      t.sync();
+      fwd_core(t, ws, size1, qsize, ilog2(size) + ilog2(scale) + bitdepth - 8);
+      return;
+    }
+  }
+#endif
   for (int k = t.rank; k < size1 * size1; k += t.size) {
     int i, j;
     split2(mk_pow2(size1), k, i, j);
@@ -286,6 +388,47 @@ TK_DEV void inv_transform_recon(const Team t, XformWs* ws, const PIX* pred_, int
     itmp[j * qsize + i] = (int16_t)clampi((sum + 64) >> 7, -32768, 32767);
   }
   t.sync();
+#ifndef TK_NOVEC
+  {
+    const int S = (int)sizeof(PIX);
+    const unsigned al = (unsigned)(uintptr_t)pred_ | (unsigned)(uintptr_t)rec_ | (unsigned)(pstride * S) | (unsigned)(rstride * S);
+    const int step = scale == 1 ? 4 : scale;
+    if (tk_uniform(!(al & (unsigned)(step * S - 1)))) {
+      if (scale == 1) {
+        // four neighbouring samples of a row per lane and step: the stage-1 row is shared, prediction and reconstruction move in one
+        // memory instruction each
+        const int ppr = n >> 2, lg = ilog2((unsigned)ppr);
+        for (int k = t.rank; k < ppr * n; k += t.size) {
+          const int i = k >> lg, j = (k & (ppr - 1)) << 2;
+          int p[4];
+          load_samples<SP, PIX, 4>(pred_ + i * pstride + j, p);
+#if !TK_HOST
+#pragma unroll
+#endif
+          for (int q = 0; q < 4; q++) {
+            const int sum = dot_i16(mt + (j + q) * n, itmp + i * qsize, qsize, j + q);
+            p[q] = sat_pix(clampi((sum + add_2) >> shift_2, -32768, 32767) + p[q], bitdepth);
+          }
+          store_samples<SP, PIX, 4>(rec_ + i * rstride + j, p);
+        }
+      } else {
+        for (int k = t.rank; k < n * n; k += t.size) {
+          int i, j;
+          split2(dn, k, i, j);
+          const int sum = dot_i16(mt + j * n, itmp + i * qsize, qsize, j);
+          const int r = clampi((sum + add_2) >> shift_2, -32768, 32767);
+          const PIX* p = pred_ + scale * i * pstride + scale * j;
+          PIX* o = rec_ + scale * i * rstride + scale * j;
+          if (scale == 2) box_recon<SP, PIX, 2>(r, p, pstride, o, rstride, bitdepth);
+          else if (scale == 4) box_recon<SP, PIX, 4>(r, p, pstride, o, rstride, bitdepth);
+          else box_recon<SP, PIX, 8>(r, p, pstride, o, rstride, bitdepth);
+        }
+      }
+      t.sync();
+      return;
+    }
+  }
+#endif
   for (int k = t.rank; k < n * n; k += t.size) {
     int i, j;
     split2(dn, k, i, j);
