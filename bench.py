@@ -5,8 +5,8 @@
 Workload ("step"): one lock-step frame of S independent closed streams (sequence chunks - the only partition of this
 path that is bit-exact, SURVEY.md 8e: stream s is exactly what the reference produces with -skip/-n for its chunk).
 128 streams per GPU: a stream's superblocks form a 62-step dependency chain at 3840x2160, so a frame takes at least 62
-superblock times whatever the number of streams; 128 streams keep ~85 % of the 768 resident workgroups busy through the
-ramp-up / ramp-down of the dependency wavefront (96: 74 %, 144: 86 %, profiles/r03_sbtimes_4k_*.log).
+superblock times whatever the number of streams; 128 streams keep 88 % of the 768 resident workgroups busy through the
+ramp-up / ramp-down of the dependency wavefront (profiles/r04_sbtimes_4k_s128_fifo.log).
 Warm-up steps include each stream's I frame; the timed K steps are the following frames in coding order.  Defaults:
 warm-up 1 (the I frame) + 4 timed P frames, the last of which searches all 4 reference frames of the operating point; the
 driver's `--steps 20 --warmup 5` times P frames 5..24, all with 4 references + bi-prediction.  Inputs are resident in HBM
@@ -15,18 +15,24 @@ and hands them to the encoder device-to-device.
 value = luma pixels coded by all ranks / max-over-ranks wall time.
 
 The line is self-verifying.  BEFORE the timed region rank 0 starts live runs of the reference encoder
-(oracle/_ref/Thorenc: the checker and the reported CPU baseline - never the thing measured) on the first and the last of
-its streams; they run on host cores concurrently with the GPU work and cover `verify_frames` = min(frames, max(warmup + 2, 7))
-frames, i.e. they reach INTO the timed region (with the driver's flags: I, P1..P4 and the timed 4-reference frames P5, P6).
-The GPU bitstream prefix of those frames and the reconstruction of the last of them must equal the reference's;
-"bit_exact": false zeroes the metric and the exit code is 1.
+(oracle/_ref/Thorenc: the checker and the reported CPU baseline - never the thing measured) on the first, the middle and the
+last of its streams; they run on host cores concurrently with the GPU work and cover `verify_frames` coded frames: at least
+max(warmup + 2, 7), more when the reference can be expected to finish inside the GPU run anyway - i.e. they reach INTO the
+timed region (with the driver's flags: I, P1..P4 and the first timed 4-reference frames).  The GPU bitstream prefix of those
+frames and the reconstruction of EVERY one of them must equal the reference's; `bit_exact_scope` says which timed frames that
+covers; "bit_exact": false zeroes the metric and the exit code is 1.  `--verify recorded` (the RA / HDB16 operating points at
+3840x2160, whose reference runs take 5-11 minutes per stream) compares every frame of the three streams with reference runs
+recorded in the build container (scripts/record_bench_refs.py -> tests/golden/bench_refs.json).
+cpu_baseline: CPU seconds (wait4 rusage) of two reference runs that differ by one coded frame (LDB) or by everything but the I
+frame (reordered configs), taken when the processes exit; an implausible value is an error, not a number.
 
   python bench.py --gpus N --steps K --warmup W [--streams S] [--width 3840 --height 2160] [--config ldb|ra|hdb16]
-                  [--bitdepth 8|10] [--sigma 2.0]
+                  [--bitdepth 8|10] [--sigma 2.0] [--verify live|recorded] [--cpu-sample WxH]
 For N > 1 launch with torch.distributed.run (one rank per GPU); streams are sharded across ranks with no data-path
 collective in the timed region ("weak" scaling: S streams per GPU); RCCL carries a consistency broadcast of the input
 before it and the ordered gather of the per-chunk bitstreams + the all-reduce of the bit/frame counts after it.  A launch
-through torch.distributed.run with ONE process runs the same collectives over RCCL on one GPU.
+through torch.distributed.run with ONE process runs the same collectives over RCCL on one GPU.  Rank 0 runs the reference
+legs (verification + cpu_baseline) whatever N is.
 """
 import argparse
 import hashlib
@@ -136,6 +142,37 @@ def gather_bitstreams(local_streams, dist, dst=0):
             out.append(raw[pos:pos + n])
             pos += n
     return out
+
+
+# ---- the streams of the workload (shared with scripts/record_bench_refs.py) ------------------------------------------------------
+CONTENT_SEED = lambda config, w: {'ldb': 4 if w >= 3840 else 2, 'ra': 3, 'hdb16': 5}[config]   # cfg 4 / 2 / 3 / 5 content seeds
+EXTRA_FRAMES = 3   # the base clip is this much longer than a chunk: streams start at different offsets
+
+
+def host_stream_frames(base, sid, nframes, bitdepth):
+    """Frames (flat planar 4:2:0, uint8 or little-endian uint16) of stream `sid`: a window of the seeded base clip, flipped / offset per
+    stream so that the streams do different work (8-bit: thor_amd.synth.make_stream_frames; 10-bit: the same rule on uint16 samples)."""
+    from thor_amd import synth
+    if bitdepth == 8:
+        return synth.make_stream_frames(base, sid, nframes)
+    maxv = (1 << bitdepth) - 1
+    off = sid % max(1, len(base) - nframes + 1)
+    mode = (sid // 3) % 4
+    out = []
+    for f in range(nframes):
+        Y, U, V = base[off + f]
+        if mode & 1:
+            Y, U, V = Y[:, ::-1], U[:, ::-1], V[:, ::-1]
+        if mode & 2:
+            Y, U, V = Y[::-1], U[::-1], V[::-1]
+        Y = np.clip(Y.astype(np.int32) + (sid % 5), 0, maxv).astype('<u2')
+        out.append(np.concatenate([np.ascontiguousarray(Y).ravel(), np.ascontiguousarray(U).ravel(), np.ascontiguousarray(V).ravel()]))
+    return out
+
+
+def ref_key(config, w, h, bitdepth, qp, nframes, sigma, sid):
+    """Key of a recorded reference run (tests/golden/bench_refs.json, scripts/record_bench_refs.py)."""
+    return f'{config}_{w}x{h}_{bitdepth}b_q{qp}_n{nframes}_sigma{sigma:g}_s{sid}'
 
 
 # ---- bitstream helpers ---------------------------------------------------------------------------
@@ -250,6 +287,11 @@ def main():
     ap.add_argument('--verify-frames', type=int, default=None, help='coded frames compared with the live reference (default: min(frames, max(warmup + 2, 7)))')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-verify', action='store_true')
+    ap.add_argument('--verify', choices=('live', 'recorded'), default='live',
+                    help='live: reference processes beside the GPU run (default); recorded: every frame of three streams against reference runs recorded with '
+                         'scripts/record_bench_refs.py (tests/golden/bench_refs.json) - for operating points whose reference runs take many minutes per stream')
+    ap.add_argument('--cpu-sample', default=None, metavar='WxH',
+                    help='with --verify recorded: geometry of the live CPU-baseline sample (top-left crop of stream 0, all frames); default: the benched geometry')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -283,11 +325,11 @@ def main():
     ref_extra = ['-bitdepth', str(a.bitdepth), '-input_bitdepth', str(a.bitdepth)] if hbd else []
     nframes = a.warmup + a.steps           # coded frames = display frames of every chunk
     fpx = w * h * 3 // 2                   # samples per frame
-    extra = 3
+    extra = EXTRA_FRAMES
     reordered = a.config != 'ldb'
     # ---- input: every rank generates the seeded clip; chunks are cut on the GPU --------------------------------------
     t_in = time.perf_counter()
-    seed = {'ldb': 4 if w >= 3840 else 2, 'ra': 3, 'hdb16': 5}[a.config]     # cfg 4 / 2 / 3 / 5 content seeds
+    seed = CONTENT_SEED(a.config, w)
     base = synth.make_clip(w, h, nframes + extra, seed, a.sigma, a.bitdepth)
     flat = np.concatenate([np.concatenate([p.ravel() for p in fr]) for fr in base])
     my_ids = stream_ids(S * world, world, rank)
@@ -302,22 +344,8 @@ def main():
     c2 = (w // 2) * (h // 2)
     maxv = (1 << a.bitdepth) - 1
 
-    def host_stream_frames(sid):
-        if not hbd:
-            return synth.make_stream_frames(base, sid, nframes)
-        # 10-bit: same window / flip / offset rule on uint16 samples
-        off = sid % max(1, len(base) - nframes + 1)
-        mode = (sid // 3) % 4
-        out = []
-        for f in range(nframes):
-            Y, U, V = base[off + f]
-            if mode & 1:
-                Y, U, V = Y[:, ::-1], U[:, ::-1], V[:, ::-1]
-            if mode & 2:
-                Y, U, V = Y[::-1], U[::-1], V[::-1]
-            Y = np.clip(Y.astype(np.int32) + (sid % 5), 0, maxv).astype('<u2')
-            out.append(np.concatenate([np.ascontiguousarray(Y).ravel(), np.ascontiguousarray(U).ravel(), np.ascontiguousarray(V).ravel()]))
-        return out
+    def stream_frames(sid):
+        return host_stream_frames(base, sid, nframes, a.bitdepth)
 
     def dev_stream_frame(sid, f):  # the torch restatement of host_stream_frames (checked against it below)
         off = sid % max(1, (nframes + extra) - nframes + 1)
@@ -344,17 +372,34 @@ def main():
     hq = int(p.HQperiod) if not reordered else 0
     if hq > 1 and nv - 1 > 0 and (nv - 1) % hq == 0:   # the baseline frame (coded frame nv - 1) must not be a high-quality frame
         nv = nv + 1 if nv + 1 <= nframes else nv - 1
-    legs = CpuLegs(cfg_path, w, h, qp, ref_extra, nframes, reordered)
+    recorded = None    # --verify recorded: {local stream index: record} of tests/golden/bench_refs.json
+    cw, ch = w, h      # geometry of the live CPU legs
+    if a.verify == 'recorded' and not a.no_verify:
+        refs = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'bench_refs.json')))
+        recorded = {s: refs[ref_key(a.config, w, h, a.bitdepth, qp, nframes, a.sigma, my_ids[s])] for s in sorted({0, S // 2, S - 1})} if rank == 0 else {}
+        nv = nframes
+        if a.cpu_sample:
+            cw, ch = (int(x) for x in a.cpu_sample.lower().split('x'))
+            assert cw <= w and ch <= h and cw % 8 == 0 and ch % 8 == 0
+    legs = CpuLegs(cfg_path, cw, ch, qp, ref_extra, nframes, reordered)
     verify = {}        # local stream index -> [host frames, {coded frame: (display index, md5 of the GPU reconstruction)}]
-    do_verify = rank == 0 and not a.no_verify and legs.available()
+    do_verify = rank == 0 and not a.no_verify and (legs.available() or recorded is not None)
     do_base = rank == 0 and not a.no_cpu_baseline and legs.available()
     n_ref = nframes if reordered else nv   # with frame reordering the coding order depends on the chunk length: run it all
     if rank == 0 and (do_verify or do_base):
         vs = sorted({0, S // 2, S - 1}) if do_verify else [0]
+        def crop(fr):   # top-left cw x ch crop of a flat 4:2:0 frame (the CPU-baseline sample of --cpu-sample)
+            if (cw, ch) == (w, h):
+                return fr
+            Y, U, V = fr[:w * h].reshape(h, w), fr[w * h:w * h + c2].reshape(h // 2, w // 2), fr[w * h + c2:].reshape(h // 2, w // 2)
+            return np.concatenate([np.ascontiguousarray(Y[:ch, :cw]).ravel(), np.ascontiguousarray(U[:ch // 2, :cw // 2]).ravel(), np.ascontiguousarray(V[:ch // 2, :cw // 2]).ravel()])
         for s in vs:
-            fr = host_stream_frames(my_ids[s])
+            fr = stream_frames(my_ids[s])
             verify[s] = [fr, {}]
-            if do_verify or s == vs[0]:
+            if recorded is not None:
+                if do_base and s == vs[0]:
+                    legs.start(f'v{my_ids[s]}', [crop(x).tobytes() for x in fr[:n_ref]], n_ref, False)
+            elif do_verify or s == vs[0]:
                 legs.start(f'v{my_ids[s]}', [x.tobytes() for x in fr[:n_ref]], n_ref, do_verify)
         if do_base:
             s0 = vs[0]
@@ -368,7 +413,7 @@ def main():
             km = min(n_ref, 3)
             for k in range(nm):
                 sid = my_ids[(1 + k) % S]
-                legs.start(f'm{k}', [x.tobytes() for x in host_stream_frames(sid)[:km]], km, False)
+                legs.start(f'm{k}', [x.tobytes() for x in stream_frames(sid)[:km]], km, False)
     if rank == 0 and verify:
         s_chk = sorted(verify)[-1]
         assert np.array_equal(dev_stream_frame(my_ids[s_chk], 0).cpu().numpy().view(np.uint8), verify[s_chk][0][0].view(np.uint8)), \
@@ -449,22 +494,33 @@ def main():
             for s in sorted(verify):
                 fr, recs = verify[s]
                 tag = f'v{my_ids[s]}'
-                rbits = legs.read(tag, n_ref, 'bit')
-                rrec = legs.read(tag, n_ref, 'yuv')
-                gpre, rpre = stream_prefix(local_bits[s], nv), stream_prefix(rbits, nv)
-                same = gpre is not None and rpre is not None and gpre == rpre   # a stream with fewer than nv frames is a failure
                 rec_frames = []
-                for cf in sorted(recs):   # the reference writes its reconstruction in DISPLAY order
-                    di, md5 = recs[cf]
-                    r_ok = len(rrec) >= (di + 1) * fbytes and hashlib.md5(rrec[di * fbytes:(di + 1) * fbytes]).hexdigest() == md5
-                    rec_frames.append(cf)
-                    same = same and r_ok
+                if recorded is not None:   # whole stream + every reconstructed frame against the recorded reference run
+                    rr = recorded[s]
+                    rpre = b'x' * rr['bit_bytes']
+                    same = len(local_bits[s]) == rr['bit_bytes'] and hashlib.md5(local_bits[s]).hexdigest() == rr['bit_md5'] and len(recs) == nframes
+                    for cf in sorted(recs):
+                        di, md5 = recs[cf]
+                        rec_frames.append(cf)
+                        same = same and rr['rec_md5'][di] == md5
+                else:
+                    rbits = legs.read(tag, n_ref, 'bit')
+                    rrec = legs.read(tag, n_ref, 'yuv')
+                    gpre, rpre = stream_prefix(local_bits[s], nv), stream_prefix(rbits, nv)
+                    same = gpre is not None and rpre is not None and gpre == rpre   # a stream with fewer than nv frames is a failure
+                    for cf in sorted(recs):   # the reference writes its reconstruction in DISPLAY order
+                        di, md5 = recs[cf]
+                        r_ok = len(rrec) >= (di + 1) * fbytes and hashlib.md5(rrec[di * fbytes:(di + 1) * fbytes]).hexdigest() == md5
+                        rec_frames.append(cf)
+                        same = same and r_ok
                 res['checked'].append({'stream': my_ids[s], 'frames': nv, 'timed_frames_covered': max(0, nv - a.warmup),
                                        'timed_coded_frames_compared': list(range(a.warmup, nv)),
                                        'bitstream_bytes': len(rpre or b''), 'recon_checked': bool(rec_frames),
                                        'recon_coded_frames_compared': rec_frames, 'ok': bool(same)})
                 ok = ok and same
             res['bit_exact'] = bool(ok)
+            res['bit_exact_source'] = ('reference runs recorded in the build container (scripts/record_bench_refs.py -> tests/golden/bench_refs.json)'
+                                       if recorded is not None else 'live runs of oracle/_ref/Thorenc beside the GPU run')
             res['bit_exact_scope'] = (f'{len(verify)} of {S} streams (first, middle, last), coded frames 0..{nv - 1} of {nframes}: bitstream prefix + reconstruction of '
                                       f'every one of those frames equal the live reference run; timed frames {a.warmup}..{nv - 1} of {a.warmup}..{nframes - 1} are covered')
         if do_base:
@@ -475,15 +531,15 @@ def main():
                 if not (n_lo >= 1 and n_lo < n_ref):
                     raise RuntimeError(f'cpu_baseline needs two reference runs of different length (have {n_ref} frames)')
                 t_hi, t_lo = times[(tag, n_ref)], times[(tag, n_lo)]
-                v1, d_cpu, d_wall = one_frame_baseline(t_hi, t_lo, float(w) * h * (n_ref - n_lo), {'frames_lo': n_lo})
+                v1, d_cpu, d_wall = one_frame_baseline(t_hi, t_lo, float(cw) * ch * (n_ref - n_lo), {'frames_lo': n_lo})
                 # aggregate of all concurrently running reference processes: pixels coded / wall of the slowest
-                agg_px = sum(n for (_, n) in times) * float(w) * h
+                agg_px = sum(n for (_, n) in times) * float(cw) * ch
                 agg = agg_px / max(t[0] for t in times.values()) / 1e6
                 what = (f'coded frame {nv - 1} ({min(int(p.max_num_ref), nv - 1)} references)' if not reordered
                         else f'coded frames 1..{n_ref - 1} of the chunk (everything but the I frame)')
                 res['cpu_baseline'] = {
                     'value': round(v1, 4), 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'reference',
-                    'sample': f'stream {my_ids[sorted(verify)[0]]} of the same workload at the benched geometry {w}x{h}: {what} = CPU time (user + system, '
+                    'sample': f'stream {my_ids[sorted(verify)[0]]} of the same workload, ' + (f'at the benched geometry {w}x{h}' if (cw, ch) == (w, h) else f'top-left {cw}x{ch} crop of the {w}x{h} frames (a bounded sample: the full-size reference run takes many minutes per stream)') + f': {what} = CPU time (user + system, '
                               f'wait4 rusage) of the {n_ref}-frame run - of the {n_lo}-frame run = {t_hi[1]:.1f} s - {t_lo[1]:.1f} s = {d_cpu:.1f} s '
                               f'(wall until exit: {t_hi[0]:.1f} s - {t_lo[0]:.1f} s = {d_wall:.1f} s); Thorenc SIMD build, 1 thread per process, '
                               f'{nproc} reference processes running at the same time beside the GPU job on rank 0 of {world}',
@@ -526,13 +582,13 @@ def main():
             'fps': round(value * 1e6 / (w * h), 3),
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt * 1e3 / max(a.steps, 1), 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u16' if hbd else 'u8', 'data': 'synthetic',
-            'bit_exact': res['bit_exact'], 'bit_exact_scope': res.get('bit_exact_scope'), 'bit_exact_checked': res['checked'],
+            'bit_exact': res['bit_exact'], 'bit_exact_source': res.get('bit_exact_source'), 'bit_exact_scope': res.get('bit_exact_scope'), 'bit_exact_checked': res['checked'],
             'config': {'workload': f'{w}x{h} {a.bitdepth}-bit 4:2:0, {cfg_name[:-4]} (configs/{cfg_name}), qp {qp}, '
                                    f'{S} independent closed streams per GPU in lock step, timed frames = coded frames {a.warmup}..{nframes - 1} of each stream '
                                    f'({R:.2f} references on average), synthetic content sigma {a.sigma:g}',
                        'streams_per_gpu': S, 'frames_timed_per_stream': a.steps, 'parallelism': f'stream-sharded x{world}',
                        'per_stream_fps': round(a.steps / dt, 4), 'per_stream_mpx_s': round(w * h * a.steps / dt / 1e6, 4),
-                       'superblock_queue': os.environ.get('THOR_SCHED', 'fifo'), 'csrc_digest': csrc_digest()},   # thor_amd/csrc/tk_sched.h: fifo | lag
+                       'superblock_queue': 'fifo', 'csrc_digest': csrc_digest()},   # thor_amd/csrc/tk_sched.h
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 4), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 8), 'traffic': traffic, 'traffic_unit': 'bytes per launch', 'traffic_source': traffic_src,
                          'alg_bytes_per_launch': round(alg_bytes_per_launch),

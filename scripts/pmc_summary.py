@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc passes of tools/thorenc_hip (one directory per pass: gpurun_out/<prefix>_<tag>/) for
 k_superblocks: writes a markdown table and a small JSON with the per-pixel figures bench.py reports as roofline.traffic.
-  python scripts/pmc_summary.py gpurun_out/r2c6_pmc 1920 1080 128 3 profiles/r02_pmc  "<workload description>" """
-import collections, csv, glob, json, sys
+  python scripts/pmc_summary.py gpurun_out/r4pmc 3840 2160 128 6 gpurun_out/r04_pmc_bench "<workload description>"   (run on the GPU box, in the tree that was profiled) """
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from bench import csrc_digest   # the summary is stamped with the digest of the engine sources it profiled; bench.py attaches it only to the same sources
 
 prefix, w, h, S, n, out, desc = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], sys.argv[7]
 px = float(w) * h * S * n
@@ -23,7 +25,7 @@ g = lambda k: agg.get(k, float('nan'))
 fetch_b = g('FETCH_SIZE') * 1024 * 2
 write_b = g('WRITE_SIZE') * 1024
 tsum = sum(times.get('sq1', [0]))
-res = {'workload': desc, 'width': w, 'height': h, 'streams': S, 'frames': n, 'config': 'ldb', 'luma_pixels': px, 'kernel_seconds_total': tsum, 'launches': len(times.get('sq1', [])),
+res = {'csrc_digest': csrc_digest(), 'workload': desc, 'width': w, 'height': h, 'streams': S, 'frames': n, 'config': 'ldb', 'luma_pixels': px, 'kernel_seconds_total': tsum, 'launches': len(times.get('sq1', [])),
        'fetch_bytes_per_px': fetch_b / px, 'write_bytes_per_px': write_b / px,
        'valu_insts_per_px': g('SQ_INSTS_VALU') / px, 'salu_insts_per_px': g('SQ_INSTS_SALU') / px, 'lds_insts_per_px': g('SQ_INSTS_LDS') / px,
        'vmem_rd_insts_per_px': g('SQ_INSTS_VMEM_RD') / px, 'vmem_wr_insts_per_px': g('SQ_INSTS_VMEM_WR') / px, 'flat_insts_per_px': g('SQ_INSTS_FLAT') / px,

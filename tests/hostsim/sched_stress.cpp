@@ -2,7 +2,7 @@
 // driven by OS threads instead of workgroups.  Every "workgroup" takes tasks with df_next, checks that the task's dependencies
 // have finished, combines their payloads into its own (plain loads / stores: ThreadSanitizer sees a missing release/acquire),
 // burns a pseudo-random amount of time and releases the successors with df_finish.
-//   sched_stress S ROWS COLS WORKERS fifo|lag SEED   -> exit code 0 and a one-line summary, or a message and exit code 1
+//   sched_stress S ROWS COLS WORKERS SEED   -> exit code 0 and a one-line summary, or a message and exit code 1
 #define THOR_SCHED_HOSTTEST 1
 #include "../../thor_amd/csrc/tk_sched.h"
 #include <stdio.h>
@@ -13,39 +13,27 @@
 using namespace tk;
 
 int main(int argc, char** argv) {
-  if (argc < 7) { fprintf(stderr, "usage: sched_stress S ROWS COLS WORKERS fifo|lag SEED\n"); return 2; }
+  if (argc < 6) { fprintf(stderr, "usage: sched_stress S ROWS COLS WORKERS SEED\n"); return 2; }
   const int S = atoi(argv[1]), rows = atoi(argv[2]), cols = atoi(argv[3]), W = atoi(argv[4]);
-  const int lag = !strcmp(argv[5], "lag");
-  const unsigned seed = (unsigned)atoi(argv[6]);
+  const unsigned seed = (unsigned)atoi(argv[5]);
   const int nsb = rows * cols;
   const unsigned total = (unsigned)S * (unsigned)nsb;
   DfCtl ctl = {0u, (unsigned)S, 0u, 0u};
   std::vector<unsigned> queue(total, kDfEmpty), cnt(total, 0u);
-  const int nb = lag ? df_num_buckets(rows, cols) : 0;
-  std::vector<unsigned> bq(2 * (nb > 0 ? nb : 1), 0u), bbase(nb + 1, 0u);
-  if (nb) {
-    for (int k = 0; k < rows; k++)
-      for (int l = 0; l < cols; l++) bbase[df_bucket(k, l) + 1] += (unsigned)S;
-    for (int b = 0; b < nb; b++) bbase[b + 1] += bbase[b];
-    if (bbase[nb] != total) { fprintf(stderr, "bucket layout does not cover the queue\n"); return 1; }
-    bq[1] = (unsigned)S;
-  }
   for (int s = 0; s < S; s++) queue[s] = (unsigned)s * (unsigned)nsb;
   DfArgs A;
   memset(&A, 0, sizeof(A));
   A.ctl = &ctl; A.queue = queue.data(); A.cnt = cnt.data(); A.S = S; A.nsb = nsb; A.cols = cols; A.rows = rows;
   A.spin_limit = 60ull * 100000000ull;
-  A.nb = nb; A.bq = bq.data(); A.bbase = bbase.data();
   std::vector<unsigned> state(total, 0u);            // 0 not started, 1 running, 2 done (atomic)
   std::vector<unsigned long long> payload(total, 0);  // plain memory: ordered only by the scheduler's release/acquire
-  std::vector<unsigned> order;                        // pop order (single worker only)
   std::vector<int> bad(W, 0);
   std::vector<std::thread> th;
   for (int w = 0; w < W; w++)
     th.emplace_back([&, w]() {
-      unsigned lo = 0, rng = seed * 2654435761u + (unsigned)w * 40503u + 1u;
+      unsigned rng = seed * 2654435761u + (unsigned)w * 40503u + 1u;
       for (;;) {
-        const unsigned task = df_next(A, total, lo);
+        const unsigned task = df_next(A, total);
         if (task == kDfEmpty) break;
         const int s = (int)(task / (unsigned)nsb), sb = (int)(task % (unsigned)nsb), k = sb / cols, l = sb % cols;
         if (__atomic_exchange_n(&state[task], 1u, __ATOMIC_ACQ_REL) != 0u) { bad[w] = 1; break; }   // handed out twice
@@ -62,7 +50,6 @@ int main(int argc, char** argv) {
           if (__atomic_load_n(&state[d], __ATOMIC_ACQUIRE) != 2u) { bad[w] = 2; break; }
           v += payload[d];
         }
-        if (W == 1) order.push_back(task);
         rng = rng * 1664525u + 1013904223u;
         for (volatile unsigned spin = 0; spin < (rng >> 22); spin++) {}
         if ((rng & 7u) == 0) sched_yield();
@@ -75,7 +62,7 @@ int main(int argc, char** argv) {
   for (int w = 0; w < W; w++)
     if (bad[w]) { fprintf(stderr, "worker %d: %s\n", w, bad[w] == 1 ? "task handed out twice" : "task released before a dependency finished"); return 1; }
   if (ctl.error) { fprintf(stderr, "scheduler reported an error\n"); return 1; }
-  const unsigned handed = lag ? ctl.claimed : ctl.tail;
+  const unsigned handed = ctl.tail;
   if (handed != total) { fprintf(stderr, "%u of %u tasks handed out\n", handed, total); return 1; }
   // payload of SB(k,l) = number of dependency paths into it + 1 ... same for every stream: compare against stream 0 computed serially
   std::vector<unsigned long long> ref(nsb, 0);
@@ -90,14 +77,6 @@ int main(int argc, char** argv) {
     if (state[t] != 2u) { fprintf(stderr, "task %u not finished\n", t); return 1; }
     if (payload[t] != ref[t % (unsigned)nsb]) { fprintf(stderr, "task %u: payload %llu, expected %llu\n", t, payload[t], ref[t % (unsigned)nsb]); return 1; }
   }
-  if (W == 1 && lag) {  // one worker, laggards first: successors always land in higher buckets, so the pop order never goes back
-    int prev = -1;
-    for (unsigned t : order) {
-      const int sb = (int)(t % (unsigned)nsb), b = df_bucket(sb / cols, sb % cols);
-      if (b < prev) { fprintf(stderr, "laggards-first order violated (bucket %d after %d)\n", b, prev); return 1; }
-      prev = b;
-    }
-  }
-  printf("ok: %u tasks, %d workers, %s\n", total, W, lag ? "laggards first" : "fifo");
+  printf("ok: %u tasks, %d workers\n", total, W);
   return 0;
 }

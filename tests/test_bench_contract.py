@@ -138,3 +138,42 @@ def test_cpu_baseline_with_frame_reordering_subtracts_the_intra_frame(monkeypatc
     c = d['cpu_baseline']
     assert c.get('error') is None and 0.02 < c['value'] < 5.0, c
     assert 'coded frames 1..8' in c['sample'] and '9-frame run' in c['sample'] and '1-frame run' in c['sample']
+
+
+class _ReconFakeEncoder(_FakeEncoder):
+    def recon(self, stream):
+        import numpy as np
+        return np.zeros(16, dtype=np.uint8)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, 'oracle', '_ref', 'Thorenc')), reason='oracle/_ref/Thorenc not built')
+def test_recorded_verification_rejects_a_wrong_stream(monkeypatch, tmp_path):
+    """--verify recorded: three streams against reference runs recorded by scripts/record_bench_refs.py; an encoder that returns
+    anything else gets bit_exact false, value 0 and exit code 1.  The CPU baseline comes from a cropped live sample."""
+    import subprocess
+    import thor_amd
+    import bench
+    refs = os.path.join(ROOT, 'tests', 'golden', 'bench_refs.json')
+    keep = open(refs).read() if os.path.exists(refs) else None
+    try:
+        subprocess.check_call([sys.executable, os.path.join(ROOT, 'scripts', 'record_bench_refs.py'), '--config', 'ldb', '--frames', '3', '--streams', '3',
+                               '--width', '192', '--height', '128'])
+        rec = json.load(open(refs))
+        assert all(bench.ref_key('ldb', 192, 128, 8, 32, 3, 2.0, s) in rec for s in (0, 1, 2))
+        monkeypatch.setattr(thor_amd, 'Encoder', _ReconFakeEncoder)
+        monkeypatch.setattr(sys, 'argv', ['bench.py', '--streams', '3', '--width', '192', '--height', '128', '--steps', '2', '--warmup', '1', '--verify', 'recorded',
+                                          '--cpu-sample', '128x64'])
+        monkeypatch.delenv('WORLD_SIZE', raising=False)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf), pytest.raises(SystemExit) as ex:
+            bench.main()
+        assert ex.value.code == 1
+        d = json.loads([l for l in buf.getvalue().splitlines() if l.strip()][0])
+        assert d['bit_exact'] is False and d['value'] == 0.0 and 'recorded' in d['bit_exact_source']
+        assert len(d['bit_exact_checked']) == 3 and d['bit_exact_checked'][0]['frames'] == 3
+        assert '128x64 crop' in d['cpu_baseline']['sample'] and d['cpu_baseline'].get('error') is None
+    finally:
+        if keep is None:
+            os.remove(refs)
+        else:
+            open(refs, 'w').write(keep)

@@ -38,7 +38,7 @@ __device__ Tables g_tab;
 // ---------------------------------------------------------------------------------------------
 // Dependency-driven persistent superblock kernel.  A task is (stream, superblock).  SB(k,l) needs its left
 // neighbour (k,l-1) and its up-right neighbour (k-1,l+1) ((k-1,l) in the last column) - SURVEY.md Appendix A.
-// The ready-task queues and their two disciplines (FIFO / laggards first) are in tk_sched.h.
+// The ready-task queue is in tk_sched.h.
 
 // Workgroup = kWaves wavefronts on one superblock: wave 0 walks the quadtree (process_sb), the others are parked on
 // the workgroup barrier and take work items of the block decisions (tk_block.h:mode_decision_par).  3 workgroups of
@@ -65,13 +65,12 @@ template <typename PIX> __global__ __launch_bounds__(kWgThreads, (sizeof(PIX) ==
   WsP<PIX> ws = ldsc(&s_view[wave]);
   const Team t = mk_team(lane, 64, sh.tabs.izz);
   xform_tables_fill(&sh.tabs, (int)threadIdx.x, kWgThreads);  // constant: once per workgroup
-  unsigned sched_lo = 0;   // thread 0: scheduler state of this workgroup (tk_sched.h:df_next)
   for (;;) {
     __syncthreads();
     unsigned long long tpop = 0;
     if (threadIdx.x == 0) {
       if (A.times) tpop = wall_clock64();
-      s_task = df_next(A, total, sched_lo);
+      s_task = df_next(A, total);
     }
     __syncthreads();
     const unsigned task = (unsigned)__builtin_amdgcn_readfirstlane((int)s_task);
@@ -350,9 +349,6 @@ struct DfState {  // per engine (keyed by its device job array)
   unsigned* cnt = nullptr;
   uint8_t* pool = nullptr;
   unsigned long long* times = nullptr;
-  unsigned* bq = nullptr;      // laggards-first discipline: per-bucket claim / push counts, bucket offsets (tk_sched.h)
-  unsigned* bbase = nullptr;
-  int nb = 0;
   int S = 0, nsb = 0, wgs = 0;
   size_t slot = 0;
   int frame = 0;
@@ -362,31 +358,16 @@ static void df_free(DfState& D) {
   if (!D.ctl) return;
   HIPCHECK(hipFree(D.ctl)); HIPCHECK(hipFree(D.queue)); HIPCHECK(hipFree(D.cnt)); HIPCHECK(hipFree(D.pool));
   if (D.times) HIPCHECK(hipFree(D.times));
-  if (D.bq) { HIPCHECK(hipFree(D.bq)); HIPCHECK(hipFree(D.bbase)); }
 }
-// Queue discipline of the superblock scheduler (tk_sched.h): THOR_SCHED=fifo (default) | lag (laggards first).  Read once per
-// process; an unknown value is reported and the default is used (a library does not abort its host over an environment variable).
-static int df_lag_discipline() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = getenv("THOR_SCHED");
-    mode = 0;
-    if (e && !strcmp(e, "lag")) mode = 1;
-    else if (e && strcmp(e, "fifo")) fprintf(stderr, "thor_hip: THOR_SCHED=%s is not a queue discipline (fifo | lag): using fifo\n", e);
-  }
-  return mode;
-}
-
 template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S) {
   const int cols = hjobs[0].sb_cols, rows = hjobs[0].sb_rows, nsb = cols * rows;
   const size_t total = (size_t)S * nsb;
   DfState& D = g_df[jobs];
   const size_t slot = (sizeof(BigWs<PIX>) + 255) & ~(size_t)255;
-  const int nb = df_lag_discipline() ? df_num_buckets(rows, cols) : 0;
-  if (D.S != S || D.nsb != nsb || D.slot != slot || D.nb != nb) {
+  if (D.S != S || D.nsb != nsb || D.slot != slot) {
     df_free(D);
     D = DfState();
-    D.S = S; D.nsb = nsb; D.slot = slot; D.nb = nb;
+    D.S = S; D.nsb = nsb; D.slot = slot;
     int per_cu = 0;
     HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_superblocks<PIX>, kWgThreads, 0));
     hipDeviceProp_t prop;
@@ -401,16 +382,6 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
     HIPCHECK(hipMalloc(&D.cnt, sizeof(unsigned) * total));
     HIPCHECK(hipMalloc(&D.pool, slot * (size_t)D.wgs * kWaves));  // one BigWs slot per wavefront
     if (getenv("THOR_SBTIMES")) { HIPCHECK(hipMalloc(&D.times, sizeof(unsigned long long) * 3 * total)); }
-    if (nb) {
-      // bucket b = anti-diagonal l + 2k holds S * #{(k,l): l + 2k = b} tasks, back to back in `queue`
-      std::vector<unsigned> base(nb + 1, 0u);
-      for (int k = 0; k < rows; k++)
-        for (int l = 0; l < cols; l++) base[df_bucket(k, l) + 1] += (unsigned)S;
-      for (int b = 0; b < nb; b++) base[b + 1] += base[b];
-      HIPCHECK(hipMalloc(&D.bq, sizeof(unsigned) * 2 * nb));
-      HIPCHECK(hipMalloc(&D.bbase, sizeof(unsigned) * (nb + 1)));
-      HIPCHECK(hipMemcpy(D.bbase, base.data(), sizeof(unsigned) * (nb + 1), hipMemcpyHostToDevice));
-    }
   }
   // frame start: only SB(0,0) of every stream is ready
   {
@@ -419,19 +390,13 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
     DfCtl hc0 = {0u, (unsigned)S, 0u, 0u};
     HIPCHECK(hipMemsetAsync(D.queue, 0xff, sizeof(unsigned) * total, g_stream));
     HIPCHECK(hipMemsetAsync(D.cnt, 0, sizeof(unsigned) * total, g_stream));
-    HIPCHECK(hipMemcpyAsync(D.queue, q0.data(), sizeof(unsigned) * S, hipMemcpyHostToDevice, g_stream));   // bucket 0 = SB(0,0) of every stream
+    HIPCHECK(hipMemcpyAsync(D.queue, q0.data(), sizeof(unsigned) * S, hipMemcpyHostToDevice, g_stream));
     HIPCHECK(hipMemcpyAsync(D.ctl, &hc0, sizeof(hc0), hipMemcpyHostToDevice, g_stream));
-    if (nb) {
-      const unsigned pushed0 = (unsigned)S;
-      HIPCHECK(hipMemsetAsync(D.bq, 0, sizeof(unsigned) * 2 * nb, g_stream));
-      HIPCHECK(hipMemcpyAsync(D.bq + 1, &pushed0, sizeof(unsigned), hipMemcpyHostToDevice, g_stream));
-    }
     HIPCHECK(hipStreamSynchronize(g_stream));
   }
   DfArgs A;
   A.ctl = D.ctl; A.queue = D.queue; A.cnt = D.cnt; A.pool = D.pool; A.slot_bytes = slot; A.times = D.times;
   A.S = S; A.nsb = nsb; A.cols = cols; A.rows = rows;
-  A.nb = nb; A.bq = D.bq; A.bbase = D.bbase;
   double lim_s = 300.0;
   if (const char* e = getenv("THOR_HIP_SPIN_TIMEOUT_S")) lim_s = atof(e);
   A.spin_limit = (unsigned long long)(lim_s * 1e8);
@@ -450,7 +415,7 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
             hipGetErrorString(e));
     abort();
   }
-  const unsigned handed_out = nb ? hc.claimed : hc.tail;
+  const unsigned handed_out = hc.tail;
   if (hc.error || handed_out != (unsigned)total) {
     fprintf(stderr, "Run-time error...\nthor_hip: superblock scheduler failed (error %u, %u of %zu tasks released)\n...now exiting to system...\n", hc.error, handed_out, total);
     abort();

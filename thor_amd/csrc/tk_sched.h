@@ -8,13 +8,11 @@
 // dispatch order or residency.  Publication uses agent-scope release (push) / acquire (after the pop), which also orders the
 // data across the 8 XCD L2s.
 //
-// Two queue disciplines over the same `queue` array (one slot per task of the frame, single use, no wrap-around):
-//  * FIFO (nb == 0): pushes take a tail ticket, idle workgroups take a head ticket and wait for that slot to be filled.
-//  * laggards first (nb > 0): one single-use FIFO per anti-diagonal b = l + 2k of the superblock grid (the step of the
-//    62-step dependency chain of a 3840x2160 frame a task belongs to), laid out back to back (bucket b starts at bbase[b] and
-//    holds S * #{(k,l): l + 2k = b} tasks).  An idle workgroup claims from the lowest bucket that has an unclaimed pushed task
-//    (compare-and-swap on the bucket's claim count): streams that have fallen behind are served first, so the frame does
-//    not end with a few slow streams walking their chains alone (profiles/r03_sched_policy_model.md).
+// One queue discipline: ready-order FIFO over the `queue` array (one slot per task of the frame, single use, no wrap-around) - pushes
+// take a tail ticket, idle workgroups take a head ticket and wait for that slot to be filled.  (A second discipline, "laggards
+// first" - one FIFO per anti-diagonal of the superblock grid, lowest first - was built at the end of round 3 and measured in round
+// 4: bit-exact, and no faster at 3840x2160 x 128 streams (114.99 vs 114.84 Mpx/s, 88 % of the workgroup-time busy either way,
+// profiles/r04_call2_ab.md); it was removed again.)
 //
 // The functions below are written against a small set of atomics macros so that tests/hostsim/sched_stress.cpp can run the
 // very same protocol with OS threads (THOR_SCHED_HOSTTEST); the device build maps them to agent-scope HIP atomics.
@@ -26,12 +24,10 @@
 #include <time.h>
 #define DF_FN static inline
 #define DF_HD static inline
-#define DF_FN_NOINLINE static
 // (acquire loads instead of relaxed loads + the fence the kernel executes after the pop: ThreadSanitizer does not model fences)
 #define DF_LOAD(p) __atomic_load_n((p), __ATOMIC_ACQUIRE)
 #define DF_ADD(p, v) __atomic_fetch_add((p), (v), __ATOMIC_RELAXED)
 #define DF_ADD_ACQ_REL(p, v) __atomic_fetch_add((p), (v), __ATOMIC_ACQ_REL)
-#define DF_CAS(p, expected, desired) __atomic_compare_exchange_n((p), &(expected), (desired), false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)
 #define DF_STORE_RELEASE(p, v) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
 #define DF_EXCHANGE(p, v) __atomic_exchange_n((p), (v), __ATOMIC_RELAXED)
 #define DF_BACKOFF() sched_yield()
@@ -43,13 +39,9 @@ static inline unsigned long long df_clock() {  // 100 MHz ticks like the device'
 #else
 #define DF_FN __device__ inline
 #define DF_HD __host__ __device__ inline
-// out of line: the claim loop must not add to the register pressure of the kernel body it is called from (once per superblock)
-#define DF_FN_NOINLINE __device__ __noinline__
 #define DF_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define DF_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define DF_ADD_ACQ_REL(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
-#define DF_CAS(p, expected, desired) \
-  __hip_atomic_compare_exchange_strong((p), &(expected), (desired), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define DF_STORE_RELEASE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
 #define DF_EXCHANGE(p, v) __hip_atomic_exchange((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 // ~14 us between polls: an idle workgroup must not compete with the working ones for the L2
@@ -60,9 +52,9 @@ __device__ inline unsigned long long df_clock() { return wall_clock64(); }
 namespace tk {
 
 struct DfCtl {
-  unsigned head, tail;   // FIFO discipline: pop / push tickets
+  unsigned head, tail;   // pop / push tickets
   unsigned error;
-  unsigned claimed;      // laggards-first discipline: tasks claimed so far (all disciplines end with `total` tasks handed out)
+  unsigned pad;
 };
 struct DfArgs {
   DfCtl* ctl;
@@ -73,16 +65,8 @@ struct DfArgs {
   unsigned long long* times;   // optional [S*nsb][3] pop/start/end wall clock (100 MHz)
   int S, nsb, cols, rows;
   unsigned long long spin_limit;  // wall-clock ticks a workgroup may wait
-  // laggards first: nb buckets (0 = FIFO discipline); bq[2b] = tasks claimed from bucket b, bq[2b+1] = tasks pushed to it
-  int nb;
-  unsigned* bq;
-  const unsigned* bbase;       // [nb+1] first queue slot of every bucket
 };
 static const unsigned kDfEmpty = 0xffffffffu;
-
-// Number of buckets of a rows x cols superblock grid and the bucket of SB(k,l).
-DF_HD int df_num_buckets(int rows, int cols) { return cols + 2 * (rows - 1); }
-DF_HD int df_bucket(int k, int l) { return l + 2 * k; }
 
 // Wait until `slot` holds a task id.  Polls with RELAXED agent-scope loads: an acquire load in the loop would issue a
 // buffer_inv (a whole-L2 invalidate on this XCD) per poll and starve every working wavefront; the single acquire fence the
@@ -101,15 +85,9 @@ DF_FN unsigned df_wait_slot(const DfArgs& A, unsigned slot) {
 }
 
 // Task `id` = SB(k,l) of some stream has become ready.
-DF_FN void df_push(const DfArgs& A, unsigned id, int k, int l) {
-  if (A.nb) {
-    const unsigned b = (unsigned)df_bucket(k, l);
-    const unsigned p = DF_ADD(&A.bq[2 * b + 1], 1u);
-    DF_STORE_RELEASE(&A.queue[A.bbase[b] + p], id);
-  } else {
-    const unsigned p = DF_ADD(&A.ctl->tail, 1u);
-    DF_STORE_RELEASE(&A.queue[p], id);
-  }
+DF_FN void df_push(const DfArgs& A, unsigned id) {
+  const unsigned p = DF_ADD(&A.ctl->tail, 1u);
+  DF_STORE_RELEASE(&A.queue[p], id);
 }
 
 // A dependency of SB(k,l) of the stream whose tasks start at `base` has finished.
@@ -117,7 +95,7 @@ DF_FN void df_done_dep(const DfArgs& A, unsigned base, int k, int l) {
   const unsigned id = base + (unsigned)(k * A.cols + l);
   const unsigned need = (l > 0 ? 1u : 0u) + (k > 0 ? 1u : 0u);
   const unsigned old = DF_ADD_ACQ_REL(&A.cnt[id], 1u);
-  if (old + 1 == need) df_push(A, id, k, l);
+  if (old + 1 == need) df_push(A, id);
 }
 
 // SB(k,l) of the stream whose tasks start at `base` has finished: release its successors.
@@ -129,40 +107,9 @@ DF_FN void df_finish(const DfArgs& A, unsigned base, int k, int l) {
   }
 }
 
-// Laggards-first discipline: claim from the lowest bucket that has an unclaimed pushed task.  `lo`: lowest bucket that may
-// still hold tasks (per-workgroup state, starts at 0).
-DF_FN_NOINLINE unsigned df_next_lag(const DfArgs& A, unsigned total, unsigned& lo) {
-  const unsigned long long t0 = df_clock();
-  unsigned n = 0;
-  for (;;) {
-    if (DF_LOAD(&A.ctl->claimed) >= total) return kDfEmpty;
-    for (unsigned b = lo; b < (unsigned)A.nb; b++) {
-      const unsigned cap = A.bbase[b + 1] - A.bbase[b];
-      unsigned h = DF_LOAD(&A.bq[2 * b]);
-      if (h >= cap) {              // every task of this bucket has been claimed
-        if (b == lo) lo = b + 1;
-        continue;
-      }
-      const unsigned t = DF_LOAD(&A.bq[2 * b + 1]);
-      while (h < t) {              // a pushed task nobody has claimed yet: claim slot h (a failed CAS reloads h)
-        if (DF_CAS(&A.bq[2 * b], h, h + 1u)) {
-          DF_ADD(&A.ctl->claimed, 1u);
-          return df_wait_slot(A, A.bbase[b] + h);   // the pusher took its ticket before it filled the slot: a short wait at most
-        }
-      }
-    }
-    DF_BACKOFF();
-    if ((++n & 63u) == 0) {
-      if (DF_LOAD(&A.ctl->error)) return kDfEmpty;
-      if (df_clock() - t0 > A.spin_limit) { DF_EXCHANGE(&A.ctl->error, 1u); return kDfEmpty; }
-    }
-  }
-}
-
 // Next task for an idle workgroup (called by ONE thread of it), kDfEmpty when every task of the frame has been handed out
-// (or on error).  `lo`: per-workgroup state of the laggards-first discipline (start 0).
-DF_FN unsigned df_next(const DfArgs& A, unsigned total, unsigned& lo) {
-  if (A.nb) return df_next_lag(A, total, lo);
+// (or on error).
+DF_FN unsigned df_next(const DfArgs& A, unsigned total) {
   const unsigned slot = DF_ADD(&A.ctl->head, 1u);
   return slot < total ? df_wait_slot(A, slot) : kDfEmpty;
 }
