@@ -58,4 +58,23 @@ cd $R
 timeout 500 python bench.py --width 1920 --height 1080 --streams 256 --warmup 5 --steps 8 > $O/r04_bench_1080p_ldb.json 2> $O/r04_bench_1080p_ldb.err; line "cfg 2: 1080p LDB s256" $O/r04_bench_1080p_ldb.json
 timeout 600 python bench.py --config ra --streams 96 --warmup 1 --steps 8 --verify recorded --cpu-sample 1920x1080 > $O/r04_bench_4k_ra.json 2> $O/r04_bench_4k_ra.err; line "cfg 3: 4K RA s96" $O/r04_bench_4k_ra.json; tail -2 $O/r04_bench_4k_ra.err
 timeout 800 python bench.py --config hdb16 --bitdepth 10 --streams 96 --warmup 1 --steps 16 --verify recorded --cpu-sample 1920x1080 > $O/r04_bench_4k_hdb16_10bit.json 2> $O/r04_bench_4k_hdb16_10bit.err; line "cfg 5: 4K 10-bit HDB16 s96" $O/r04_bench_4k_hdb16_10bit.json; tail -2 $O/r04_bench_4k_hdb16_10bit.err
-timeout 500 python bench.py --sigma 6 --warmup 5 --steps 2 --verify-frames 7 > $O/r04_bench_sigma6.json 2> $O/r04_bench_sigma6.err; line "hard content (sigma 6)" $O/r04_bench_sigma6.json
+timeout 500 python bench.py --sigma 6 --warmup 5 --steps 2 --verify recorded --cpu-sample 1920x1080 > $O/r04_bench_sigma6.json 2> $O/r04_bench_sigma6.err; line "hard content (sigma 6)" $O/r04_bench_sigma6.json
+# ---- 6. bisection of the instrumentation hang (THOR_PROF_MD build, call 2): which counters make k_superblocks hang, and does a wait trip the trap?
+#      libthor_hip_profmd (all MD counters), _md1 (work-queue items inside md_worker_sp's loop), _md2 (the trial items' wait), _md4 (master
+#      phases), _md9 (= md1 with register accumulators, one store after the loop).  rc 124 = killed by timeout (hang), 134 = aborted (trap / scheduler error).
+python3 -m thor_amd.synth /tmp/w/sd.yuv 640 384 5 2
+python3 -m thor_amd.synth /tmp/w/hd.yuv 1920 1080 5 2
+hang() {  # tag lib clip w h streams
+  gcc -O2 -std=c99 -D_POSIX_C_SOURCE=200809L -o /tmp/w/thorenc_$1 tools/thorenc_hip.c -Lthor_amd -l:libthor_hip_$2.so -Wl,-rpath,$R/thor_amd
+  THOR_PROF=md THOR_HIP_SPIN_TIMEOUT_S=20 timeout 50 /tmp/w/thorenc_$1 -cf $R/configs/ldb_high_efficiency.cfg -if $3 -width $4 -height $5 -qp 32 -f 30 -n 4 -streams $6 -wrap 5 > $O/r4f_hang_$1.log 2>&1
+  rc=$?; echo "$(el) hang test $1: rc=$rc $(grep -E 'thorenc_hip:|aborted|scheduler failed' $O/r4f_hang_$1.log | cut -c1-150)"; return $rc
+}
+if [ $(( $(date +%s) - T0 )) -lt 2300 ]; then
+  hang profmd_small profmd /tmp/w/sd.yuv 640 384 24
+  if [ $? -ne 0 ]; then
+    for v in md1 md2 md4 md9; do hang ${v}_small $v /tmp/w/sd.yuv 640 384 24; done
+  else
+    hang profmd_hd profmd /tmp/w/hd.yuv 1920 1080 64
+    if [ $? -ne 0 ]; then for v in md1 md2 md4 md9; do hang ${v}_hd $v /tmp/w/hd.yuv 1920 1080 64; done; fi
+  fi
+fi

@@ -221,11 +221,19 @@ template <typename PIX> TK_DEV TeamWs<PIX> make_ws(SmallWs<PIX>* s, WgShared* sh
 // 19 trial items incl. their wait for the vectors, 20 wait of the trial items alone, 21 queue set-up (master), 22 block entry
 // (contexts, candidates, original block), 23 early-skip path (check + trial + final encode), 24 final encode of decided blocks: bit emission
 // (one lane), 25 final encode of decided blocks: reconstruction copy + cell state.
+// -DTHOR_PROF_MD_PARTS=mask (default 7) keeps only some of them - 1: the items inside md_worker_sp's loop, 2: the trial items' wait, 4: the
+// master's phases - and mask bit 8 makes the loop counters accumulate in registers and store once after the loop (bisection of the
+// hang of the fully instrumented build, profiles/r04_call2_ab.md).
 #if defined(THOR_PROF_MD) && defined(THOR_PROF) && !TK_HOST
+#ifndef THOR_PROF_MD_PARTS
+#define THOR_PROF_MD_PARTS 7
+#endif
 #define TK_PROFMD_MARK(v) TK_PROF_MARK(v)
 #define TK_PROFMD_ACC(ws, id, v) TK_PROF_ACC(ws, id, v)
 #define TK_PROFMD_CNT(ws, id) TK_PROF_CNT(ws, id)
+#define TK_PROFMD_ON(bit) ((THOR_PROF_MD_PARTS) & (bit))
 #else
+#define TK_PROFMD_ON(bit) 0
 #define TK_PROFMD_MARK(v) do {} while (0)
 #define TK_PROFMD_ACC(ws, id, v) do {} while (0)
 #define TK_PROFMD_CNT(ws, id) do {} while (0)
@@ -1413,7 +1421,7 @@ TK_DEVNI void md_item_trial(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& 
     if ((spins & 1023u) == 0 && tk_uniform64(wg_clock() - w0) > (unsigned long long)kWgWaitLimit) wg_wait_failed();
     wg_pause();
   }
-  TK_PROFMD_ACC(ws, 20, pwt_);
+  if (TK_PROFMD_ON(2)) TK_PROFMD_ACC(ws, 20, pwt_);
   mv_t mv_all[4][4];
   for (int q = 0; q <= part; q++)
     for (int i = 0; i < 4; i++) mv_all[q][i] = lds_ld(&sh_->ref_mv[r][q][i]);
@@ -1546,6 +1554,9 @@ TK_DEVNI void md_worker_sp(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws) 
   const auto& c = J.cfg;
   const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
   const int n_items = sh->n_items;
+#if defined(THOR_PROF_MD) && defined(THOR_PROF) && !TK_HOST
+  long long pmd_acc_[4] = {0, 0, 0, 0};
+#endif
   for (;;) {
     int i = 0;
     if (t.rank == 0) i = wg_fetch_add(&sh_->next_item, 1);
@@ -1584,8 +1595,17 @@ TK_DEVNI void md_worker_sp(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws) 
       wg_wait_at_least(t, ws, &sh_->parts_done[J.interp_ref ? 1 : 0], 1);
       md_bijoint_telescope<PIX, SP>(t, J, ws, M);
     }
-    TK_PROFMD_ACC(ws, (kind == MD_SKIP || kind == MD_MERGE) ? 16 : kind == MD_INTRA ? 17 : (kind == MD_REF || kind == MD_BIJOINT) ? 18 : 19, pk_);
+#if defined(THOR_PROF_MD) && defined(THOR_PROF) && !TK_HOST
+    if (TK_PROFMD_ON(1)) {
+      const int slot_ = (kind == MD_SKIP || kind == MD_MERGE) ? 0 : kind == MD_INTRA ? 1 : (kind == MD_REF || kind == MD_BIJOINT) ? 2 : 3;
+      if (TK_PROFMD_ON(8)) { const long long d_ = TK_CYC() - pk_; pmd_acc_[0] += slot_ == 0 ? d_ : 0; pmd_acc_[1] += slot_ == 1 ? d_ : 0; pmd_acc_[2] += slot_ == 2 ? d_ : 0; pmd_acc_[3] += slot_ == 3 ? d_ : 0; }
+      else TK_PROF_ACC(ws, 16 + slot_, pk_);
+    }
+#endif
   }
+#if defined(THOR_PROF_MD) && defined(THOR_PROF) && !TK_HOST
+  if (TK_PROFMD_ON(8) && t.rank == 0) for (int q_ = 0; q_ < 4; q_++) ws->prof[16 + q_] += pmd_acc_[q_];
+#endif
   if (sh->do_bipred == 2) {  // uniform over the workgroup: every wave takes part (same number of barriers)
     t.sync();
     TK_PROF_MARK(pb_);
@@ -1665,7 +1685,7 @@ TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, JobR<PIX> J, WsP<
     sh->cmd = WG_CMD_MD;
   }
   t.sync();
-  TK_PROFMD_ACC(ws, 21, pqs_);
+  if (TK_PROFMD_ON(4)) TK_PROFMD_ACC(ws, 21, pqs_);
   wg.barrier();   // fork
 #ifdef THOR_PROF
   { TK_PROF_MARK(pw_); md_worker(wg, t, J, ws); TK_PROF_ACC(ws, 5, pw_); t.sync(); wg.barrier(); TK_PROF_ACC(ws, 29, pw_); }
@@ -1818,7 +1838,7 @@ TK_DEVNI int final_encode(const Team t, JobR<PIX> J, WsP<PIX> ws, Node& nd, BitS
     }
     nbits = team_bcast0(t, nbits);
     out.pos += nbits;
-    TK_PROFMD_ACC(ws, 24, pfe0_);
+    if (TK_PROFMD_ON(4)) TK_PROFMD_ACC(ws, 24, pfe0_);
     copy_block<SP_GLOBAL, SP_GLOBAL>(t, J.rec.y + nd.ypos * J.rec.sy + nd.xpos, J.rec.sy, snap->best_y, size, nd.bw, nd.bh);
     copy_block<SP_GLOBAL, SP_GLOBAL>(t, J.rec.u + yc * J.rec.sc + xc, J.rec.sc, snap->best_u, sc, nd.bw >> 1, nd.bh >> 1);
     copy_block<SP_GLOBAL, SP_GLOBAL>(t, J.rec.v + yc * J.rec.sc + xc, J.rec.sc, snap->best_v, sc, nd.bw >> 1, nd.bh >> 1);
@@ -1931,7 +1951,7 @@ TK_DEV void process_sb(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int 
       }
       t.sync();
       org_select(t, J, ws, tk_uniform(size), ypos, xpos, tk_uniform(nd.bw), tk_uniform(nd.bh), 1);
-      TK_PROFMD_ACC(ws, 22, pen_);
+      if (TK_PROFMD_ON(4)) TK_PROFMD_ACC(ws, 22, pen_);
       TK_PROFMD_MARK(pes_);
       // ---- early skip
       const int lds_blk = tk_uniform(size <= kLdsBlk);   // address space of this block's sample buffers (SP_LDS / SP_GLOBAL instances)
@@ -1974,11 +1994,11 @@ TK_DEV void process_sb(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int 
 #endif
           have_ret = 1;
           sp--;
-          TK_PROFMD_ACC(ws, 23, pes_);
+          if (TK_PROFMD_ON(4)) TK_PROFMD_ACC(ws, 23, pes_);
           continue;
         }
       }
-      TK_PROFMD_ACC(ws, 23, pes_);
+      if (TK_PROFMD_ON(4)) TK_PROFMD_ACC(ws, 23, pes_);
       // ---- split signalling + children (bottom-up), unless this is a top-down 16x16 (encode_block.c:2418)
       const int top_down = size == 2 * kMinBlk && nd.encode_this_size && J.frame_type != F_I && c.encoder_speed > 0;
       if (size > kMinBlk && !top_down) {
@@ -2080,7 +2100,7 @@ TK_DEV void process_sb(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int 
           TK_PROFMD_MARK(pfe_);
           if (nd.size <= kLdsBlk) final_encode<PIX, SP_LDS>(t, J, ws, nd, out, snap);
           else final_encode<PIX, SP_GLOBAL>(t, J, ws, nd, out, snap);
-          TK_PROFMD_ACC(ws, 25, pfe_);   // whole call; slot 24 holds the emission part of the snapshot path
+          if (TK_PROFMD_ON(4)) TK_PROFMD_ACC(ws, 25, pfe_);   // whole call; slot 24 holds the emission part of the snapshot path
         }
       }
       ret = cost < nd.cost_small ? cost : nd.cost_small;
