@@ -920,6 +920,36 @@ template <typename PIX> TK_DEV void add_cands4(const Team t, WsP<PIX> ws, int re
   t.sync();
 }
 
+// 2 * org - pred, saturated (the "original" of a bi-prediction search step, encode_block.c:1786-1791), for a size x size block:
+// four samples per lane and step (sample blocks and original rows are aligned to four samples), sample by sample otherwise.
+template <typename PIX, int SP>
+TK_DEV void build_org8(const Team t, PIX* o8_, const PIX* oy_, int osy, const PIX* py_, int size, int bitdepth) {
+#ifndef TK_NOVEC
+  const int S = (int)sizeof(PIX);
+  const unsigned al = (unsigned)(uintptr_t)o8_ | (unsigned)(uintptr_t)oy_ | (unsigned)(uintptr_t)py_ | (unsigned)(osy * S);
+  if (tk_uniform(!(al & (unsigned)(4 * S - 1)))) {
+    const int ppr = size >> 2, lg = ilog2((unsigned)ppr);
+    for (int k = t.rank; k < ppr * size; k += t.size) {
+      const int i = k >> lg, j = (k & (ppr - 1)) << 2;
+      int o[4], p[4];
+      load_samples<SP, PIX, 4>(oy_ + i * osy + j, o);
+      load_samples<SP, PIX, 4>(py_ + i * size + j, p);
+      for (int q = 0; q < 4; q++) o[q] = sat_pix(2 * o[q] - p[q], bitdepth);
+      store_samples<SP, PIX, 4>(o8_ + i * size + j, o);
+    }
+    return;
+  }
+#endif
+  const auto o8 = spc<SP>(o8_);
+  const auto oys = spc<SP>(oy_);
+  const auto pys = spc<SP>(py_);
+  for (int k = t.rank; k < size * size; k += t.size) {
+    int i, j;
+    split2(mk_pow2(size), k, i, j);
+    o8[k] = (PIX)sat_pix(2 * (int)oys[i * osy + j] - (int)pys[k], bitdepth);
+  }
+}
+
 // search_bipred_prediction_params, me_mode 0 (encode_block.c:1739-1832) - P and B frames.
 template <typename PIX, int SP>
 TK_DEVNI void search_bipred(const Team t, JobR<PIX> J, WsP<PIX> ws, const Node& nd_, int part,
@@ -960,16 +990,7 @@ TK_DEVNI void search_bipred(const Team t, JobR<PIX> J, WsP<PIX> ws, const Node& 
       pred_inter_yuv<SP>(t, lds_ld(&J.ref[ref_o]), ws->pred_y, ws->pred_u, ws->pred_v, nd.ypos, nd.xpos, size, nd.bw, nd.bh,
                      list ? min0 : min1, J.sign[ref_o], c.width, c.height, c.enable_bipred, part > 0, c.bitdepth, 1);
       t.sync();
-      {
-        const auto o8 = spc<SP>(ws->org8);
-        const auto oys = spc<SP>(oy);
-        const auto pys = spc<SP>(ws->pred_y);
-        for (int k = t.rank; k < size * size; k += t.size) {
-          int i, j;
-          split2(mk_pow2(size), k, i, j);
-          o8[k] = (PIX)sat_pix(2 * (int)oys[i * osy + j] - (int)pys[k], c.bitdepth);
-        }
-      }
+      build_org8<PIX, SP>(t, ws->org8, oy, osy, ws->pred_y, size, c.bitdepth);
       t.sync();
       int ref_start, ref_end;
       if (J.frame_type == F_P) { ref_start = 0; ref_end = J.num_ref - 1; }
@@ -1492,15 +1513,7 @@ TK_DEVNI void bipred_par(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, Md
           pred_inter_yuv<SP>(t, lds_ld(&J.ref[ref_o]), ws->pred_y, ws->pred_u, ws->pred_v, nd.ypos, nd.xpos, size, nd.bw, nd.bh, mo, J.sign[ref_o], c.width,
                          c.height, c.enable_bipred, 0, c.bitdepth, 1);
           t.sync();
-          const auto oy = spc<SP>(ws->org_y);
-          const auto py = spc<SP>(ws->pred_y);
-          const auto o8 = spc<SP>(ws->org8);
-          const int osy = ws->org_sy;
-          for (int k = t.rank; k < size * size; k += t.size) {
-            int i, j;
-            split2(mk_pow2(size), k, i, j);
-            o8[k] = (PIX)sat_pix(2 * (int)oy[i * osy + j] - (int)py[k], c.bitdepth);
-          }
+          build_org8<PIX, SP>(t, ws->org8, ws->org_y, ws->org_sy, ws->pred_y, size, c.bitdepth);
           if (t.rank == 0) sh->bp_org8 = ws->org8;
         }
         t.sync();
