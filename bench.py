@@ -567,7 +567,8 @@ def main():
             pm = json.load(open(os.path.join(ROOT, 'profiles', PMC_JSON)))
             if pm.get('csrc_digest') != csrc_digest():
                 traffic_src = f'profiles/{PMC_JSON} describes other engine sources (digest {pm.get("csrc_digest")} != {csrc_digest()}): not attached'
-            elif pm.get('width') == w and pm.get('height') == h and pm.get('streams') == S and pm.get('config', 'ldb') == a.config:
+            elif (pm.get('width') == w and pm.get('height') == h and pm.get('streams') == S and pm.get('config', 'ldb') == a.config and
+                  pm.get('sigma', 2.0) == a.sigma and not hbd):   # same geometry, operating point and content as the profiled workload
                 traffic = round((pm['fetch_bytes_per_px'] + pm['write_bytes_per_px']) * w * h * S * a.steps / max(launches, 1))
                 traffic_src = f'profiles/{PMC_JSON[:-5]}.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this geometry and of these sources (%s)' % pm['workload']
                 valu_util = pm.get('valu_util_chip')

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Event-driven model of the persistent superblock kernel's scheduler (thor_amd/csrc/tk_sched.h): W resident workgroups, S
 streams of a rows x cols superblock grid with the codec's dependencies (left, up-right), synthetic superblock durations
-calibrated to the measured distribution of a 4-reference 3840x2160 frame (profiles/r03_sbtimes_4k_s96.log / _s144.log: mean
+calibrated to the measured distribution of a 4-reference 3840x2160 frame (profiles/archive/r03_sbtimes_4k_s96.log / _s144.log: mean
 118-121 ms, median 116-119, p95 156-158, max 224-266; critical path per stream mean 8.1-8.3 s, max 9.1-9.4 s).
 Compares queue disciplines: fifo (ready order, what the kernel has always done), lag (lowest anti-diagonal l + 2k first =
 laggards first), stream / group priorities.   python3 scripts/sched_policy_model.py [seeds]"""
