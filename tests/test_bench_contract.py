@@ -177,3 +177,37 @@ def test_recorded_verification_rejects_a_wrong_stream(monkeypatch, tmp_path):
             os.remove(refs)
         else:
             open(refs, 'w').write(keep)
+
+
+def test_pmc_figures_are_attached_only_to_the_sources_they_describe(monkeypatch):
+    """roofline.traffic comes from a committed PMC summary of the same engine sources (digest), geometry, operating point and content -
+    a summary of other sources is named in traffic_source and NOT attached (round 3 attached counters of an older library)."""
+    import thor_amd
+    import bench
+    name = '_test_pmc_%d.json' % os.getpid()
+    path = os.path.join(ROOT, 'profiles', name)
+    monkeypatch.setattr(thor_amd, 'Encoder', _FakeEncoder)
+    monkeypatch.setattr(bench, 'PMC_JSON', name)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    argv = ['bench.py', '--streams', '3', '--width', '64', '--height', '64', '--steps', '2', '--warmup', '1', '--no-verify', '--no-cpu-baseline']
+
+    def run(extra=()):
+        monkeypatch.setattr(sys, 'argv', argv + list(extra))
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            bench.main()
+        return json.loads([l for l in buf.getvalue().splitlines() if l.strip()][0])['roofline']
+    pm = {'csrc_digest': 'not-these-sources', 'width': 64, 'height': 64, 'streams': 3, 'config': 'ldb', 'workload': 'test', 'fetch_bytes_per_px': 10.0,
+          'write_bytes_per_px': 5.0, 'valu_util_chip': 0.5}
+    try:
+        json.dump(pm, open(path, 'w'))
+        r = run()
+        assert r['traffic'] is None and 'other engine sources' in r['traffic_source']
+        pm['csrc_digest'] = bench.csrc_digest()
+        json.dump(pm, open(path, 'w'))
+        r = run()
+        assert r['traffic'] == round(15.0 * 64 * 64 * 3 * 2 / 2) and r['ops']['valu_util_chip'] == 0.5
+        assert run(['--sigma', '6'])['traffic'] is None       # other content than the profiled workload
+        assert run(['--streams', '4'])['traffic'] is None     # other geometry
+    finally:
+        os.remove(path)
