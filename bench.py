@@ -225,6 +225,7 @@ class CpuLegs:
         it['wall'] = time.perf_counter() - it['t0']
         it['cpu'] = ru.ru_utime + ru.ru_stime
         it['rc'] = os.waitstatus_to_exitcode(status)
+        it['popen'].returncode = it['rc']   # the child has been reaped here: keep subprocess from waiting for it again
 
     def start(self, tag, frames_bytes, n, with_rec):
         import threading
