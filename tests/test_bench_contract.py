@@ -211,3 +211,82 @@ def test_pmc_figures_are_attached_only_to_the_sources_they_describe(monkeypatch)
         assert run(['--streams', '4'])['traffic'] is None     # other geometry
     finally:
         os.remove(path)
+
+
+class _HostsimEncoder(_FakeEncoder):
+    """Stand-in that really encodes: the frames bench.py stages (host tensors on a machine without a GPU) go through the host simulation of
+    the engine (tests/hostsim - test infrastructure, the same engine sources as the library), so bench.py's verification sees streams and
+    reconstructions that ARE bit-exact and its positive path runs on the CPU."""
+    def __init__(self, params, num_streams=1, device=0):
+        super().__init__(params, num_streams, device)
+        self.p = params
+        self.frames = [dict() for _ in range(num_streams)]
+        self.out = None
+        self.coded = 0
+
+    def stage_device(self, stream, slot, ptr):
+        import ctypes
+        n = self.p.width * self.p.height * 3 // 2
+        self.frames[stream][slot] = ctypes.string_at(ptr, n)
+
+    def _run(self):
+        import tempfile, subprocess
+        from util import build_hostsim
+        sim = build_hostsim()
+        self.out = []
+        for s in range(self.S):
+            n = len(self.frames[s])
+            with tempfile.TemporaryDirectory() as d:
+                open(os.path.join(d, 'in.yuv'), 'wb').write(b''.join(self.frames[s][f] for f in range(n)))
+                subprocess.check_call([sim, '-cf', os.path.join(ROOT, 'configs', 'ldb_high_efficiency.cfg'), '-if', os.path.join(d, 'in.yuv'), '-width', str(self.p.width),
+                                       '-height', str(self.p.height), '-qp', str(self.p.qp), '-n', str(n), '-f', '30', '-of', os.path.join(d, 'o.bit'),
+                                       '-rf', os.path.join(d, 'o.yuv')], stdout=subprocess.DEVNULL)
+                self.out.append((open(os.path.join(d, 'o.bit'), 'rb').read(), open(os.path.join(d, 'o.yuv'), 'rb').read()))
+
+    def encode_staged(self, slots):
+        if self.out is None:
+            self._run()
+        self.coded += 1
+        super().encode_staged(slots)
+
+    def recon(self, stream):
+        import numpy as np
+        n = self.p.width * self.p.height * 3 // 2
+        return np.frombuffer(self.out[stream][1][(self.coded - 1) * n:self.coded * n], dtype=np.uint8)
+
+    def bitstream(self, stream):
+        return self.out[stream][0]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, 'oracle', '_ref', 'Thorenc')), reason='oracle/_ref/Thorenc not built')
+def test_verification_passes_on_bit_exact_streams_live_and_recorded(monkeypatch):
+    """The positive path of bench.py's self-verification on the CPU: streams produced by the host simulation of the engine are compared
+    with live reference runs (bitstream prefix + every frame's reconstruction, three streams) and with recorded reference runs."""
+    import subprocess
+    import thor_amd
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    monkeypatch.setattr(thor_amd, 'Encoder', _HostsimEncoder)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    base = ['bench.py', '--streams', '3', '--width', '192', '--height', '128', '--steps', '2', '--warmup', '1']
+
+    def run(extra):
+        monkeypatch.setattr(sys, 'argv', base + extra)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            bench.main()
+        return json.loads([l for l in buf.getvalue().splitlines() if l.strip()][0])
+    d = run([])
+    assert d['bit_exact'] is True and d['value'] > 0 and 'live' in d['bit_exact_source']
+    assert [c['stream'] for c in d['bit_exact_checked']] == [0, 1, 2]
+    assert all(c['ok'] and c['frames'] == 3 and c['recon_coded_frames_compared'] == [0, 1, 2] and c['timed_coded_frames_compared'] == [1, 2] for c in d['bit_exact_checked'])
+    assert d['cpu_baseline'].get('error') is None and 0.02 < d['cpu_baseline']['value'] < 8
+    refs = os.path.join(ROOT, 'tests', 'golden', 'bench_refs.json')
+    keep = open(refs).read()
+    try:
+        subprocess.check_call([sys.executable, os.path.join(ROOT, 'scripts', 'record_bench_refs.py'), '--config', 'ldb', '--frames', '3', '--streams', '3',
+                               '--width', '192', '--height', '128'])
+        d = run(['--verify', 'recorded', '--no-cpu-baseline'])
+        assert d['bit_exact'] is True and d['value'] > 0 and 'recorded' in d['bit_exact_source'] and len(d['bit_exact_checked']) == 3
+    finally:
+        open(refs, 'w').write(keep)
