@@ -24,15 +24,20 @@ def main():
     ap.add_argument('--sigma', type=float, default=2.0)
     ap.add_argument('--qp', type=int, default=None)
     ap.add_argument('-j', type=int, default=3)
+    ap.add_argument('--sids', default=None, help='comma-separated stream ids to record instead of first / middle / last')
+    ap.add_argument('--cpu-only', action='store_true',
+                    help='record only the CPU seconds of the run (key suffix _cpu): the shorter leg of a recorded CPU-baseline difference')
     a = ap.parse_args()
     cfg_name, qp_default = bench.CONFIGS[a.config]
     qp = a.qp if a.qp is not None else qp_default
     w, h, n, S = a.width, a.height, a.frames, a.streams
     base = synth.make_clip(w, h, n + bench.EXTRA_FRAMES, bench.CONTENT_SEED(a.config, w), a.sigma, a.bitdepth)
-    sids = sorted({0, S // 2, S - 1})
+    sids = sorted({0, S // 2, S - 1}) if a.sids is None else sorted({int(x) for x in a.sids.split(',')})
     extra = ['-bitdepth', str(a.bitdepth), '-input_bitdepth', str(a.bitdepth)] if a.bitdepth > 8 else []
     fbytes = w * h * 3 // 2 * (2 if a.bitdepth > 8 else 1)
     path = os.path.join(ROOT, 'tests', 'golden', 'bench_refs.json')
+    model = [l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')]
+    HOST = f'{model[0] if model else "unknown CPU"}, {os.cpu_count()} logical cores (build container)'
     out = json.load(open(path)) if os.path.exists(path) else {}
 
     def job(sid):
@@ -40,14 +45,22 @@ def main():
             with open(os.path.join(d, 'in.yuv'), 'wb') as f:
                 for fr in bench.host_stream_frames(base, sid, n, a.bitdepth):
                     f.write(fr.tobytes())
-            subprocess.run([bench.REF_ENC, '-cf', os.path.join(ROOT, 'configs', cfg_name), '-if', os.path.join(d, 'in.yuv'), '-width', str(w), '-height', str(h),
-                            '-qp', str(qp), '-n', str(n), '-f', '30', '-of', os.path.join(d, 'o.bit'), '-rf', os.path.join(d, 'o.yuv')] + extra,
-                           check=True, stdout=subprocess.DEVNULL)
+            pr = subprocess.Popen([bench.REF_ENC, '-cf', os.path.join(ROOT, 'configs', cfg_name), '-if', os.path.join(d, 'in.yuv'), '-width', str(w), '-height', str(h),
+                                   '-qp', str(qp), '-n', str(n), '-f', '30', '-of', os.path.join(d, 'o.bit'), '-rf', os.path.join(d, 'o.yuv')] + extra,
+                                  stdout=subprocess.DEVNULL)
+            _, status, ru = os.wait4(pr.pid, 0)   # CPU seconds of exactly this process (user + system), as bench.py's legs take them
+            pr.returncode = os.waitstatus_to_exitcode(status)
+            assert pr.returncode == 0
+            cpu = {'cpu_s': round(ru.ru_utime + ru.ru_stime, 2), 'cpu_host': HOST, 'cpu_concurrent_jobs': min(a.j, len(sids))}
+            if a.cpu_only:
+                return sid, cpu
             bits = open(os.path.join(d, 'o.bit'), 'rb').read()
             rec = open(os.path.join(d, 'o.yuv'), 'rb').read()
             assert len(rec) == n * fbytes
-            return sid, {'bit_md5': hashlib.md5(bits).hexdigest(), 'bit_bytes': len(bits),
-                         'rec_md5': [hashlib.md5(rec[i * fbytes:(i + 1) * fbytes]).hexdigest() for i in range(n)]}
+            # md5 of the stream prefix after every coded frame (low-delay configurations: a shorter chunk of the same stream is a prefix)
+            pre = [] if a.config != 'ldb' else [hashlib.md5(bench.stream_prefix(bits, k)).hexdigest() for k in range(1, n + 1)]
+            return sid, dict({'bit_md5': hashlib.md5(bits).hexdigest(), 'bit_bytes': len(bits), 'prefix_md5': pre,
+                              'rec_md5': [hashlib.md5(rec[i * fbytes:(i + 1) * fbytes]).hexdigest() for i in range(n)]}, **cpu)
 
     with ThreadPoolExecutor(a.j) as ex:
         for sid, res in ex.map(job, sids):
@@ -55,7 +68,7 @@ def main():
             with open(path + '.lock', 'w') as lk:   # several recorders may run side by side: merge under a lock
                 fcntl.flock(lk, fcntl.LOCK_EX)
                 out = json.load(open(path)) if os.path.exists(path) else {}
-                out[bench.ref_key(a.config, w, h, a.bitdepth, qp, n, a.sigma, sid)] = res
+                out[bench.ref_key(a.config, w, h, a.bitdepth, qp, n, a.sigma, sid) + ('_cpu' if a.cpu_only else '')] = res
                 json.dump(out, open(path, 'w'), indent=1, sort_keys=True)
             print('recorded', bench.ref_key(a.config, w, h, a.bitdepth, qp, n, a.sigma, sid), flush=True)
 

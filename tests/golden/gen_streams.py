@@ -29,6 +29,10 @@ CASES = {
     '192x128_n5_q34_ldb_low_10bit': ('clip10_192x128_5.yuv.gz', 192, 128, 5, 34, ['-bitdepth', '10', '-input_bitdepth', '10'], 'ldb_low_complexity.cfg'),
     # BASELINE config 1 exactly: 352x288, 30 frames, seed 1, LDB_low_complexity, qp 32 (clip generated, not committed)
     'cfg1_352x288_n30_q32_ldb_low': ('gen:352,288,30,1,2.0', 352, 288, 30, 32, [], 'ldb_low_complexity.cfg'),
+    # round 5: the frame schedule bench.py's timed frames depend on - LDB_high_efficiency past the second high-quality frame (coded frame 24) and
+    # into the second lap of the 13-slot reference ring (enc/mainenc.c:455-500: long-term reference r1 = last HQ frame)
+    '192x128_n27_q32_ldb': ('gen:192,128,27,7,2.0', 192, 128, 27, 32, []),
+    '208x120_n26_q24_ldb': ('gen:208,120,26,8,3.0', 208, 120, 26, 24, []),
 }
 out = {}
 with tempfile.TemporaryDirectory() as d:

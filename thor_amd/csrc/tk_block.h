@@ -206,6 +206,7 @@ template <typename PIX> TK_DEV TeamWs<PIX> make_ws(SmallWs<PIX>* s, WgShared* sh
   static_assert(offsetof(SmallWs<PIX>, win_extra) == offsetof(SmallWs<PIX>, xf) + sizeof(XformWs), "win_extra must directly follow the transform workspace");
   s->me.win = (uint32_t*)s->xf.in;
   s->me.win_cap = (int)(sizeof(XformWs) - offsetof(XformWs, in)) + (int)WinExtra<PIX>::bytes;
+  s->me.cwin_valid = 0;
   w.coef_y = s->coef_y; w.coef_u = s->coef_u; w.coef_v = s->coef_v;
   w.coef_u_small = s->coef_u; w.coef_v_small = s->coef_v; w.coef_u_big = g->coef_u_big; w.coef_v_big = g->coef_v_big;
   w.acc = s->acc; w.stack = sh->stack; w.prof = s->prof;
@@ -1410,11 +1411,20 @@ TK_DEVNI void md_item_ref(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& M,
   if (t.rank == 0) add_mvcand(ws->mep, r, mvp);
   t.sync();
   mv_t mv_center = mvp;
+  if (t.rank == 0) ldsc(ws->mep)->cwin_valid = 0;
+  t.sync();
   for (int part = 0; part < max_pb; part++) {
     mv_t mv_all[4];
     search_inter<PIX, SP>(t, J, ws, nd.ypos, nd.xpos, size, oy, ws->org_sy, r, mv_center, mvp, mv_all, part, J.sign[r]);
     add_cands4(t, ws, r, mv_all);
-    if (part == 0) mv_center = mv_all[0];
+    if (part == 0) {
+      mv_center = mv_all[0];
+      // the eight searches of the HOR / VER / QUAD partitions all start from mv_center: one window for the block
+      if (max_pb > 1) {
+        const Plane3<PIX> rp = lds_ld(&J.ref[r]);
+        me_stage_cb_window<PIX>(t, ws->mep, rp.y + nd.ypos * rp.sy + nd.xpos, rp.sy, nd.xpos, nd.ypos, size, mv_center, J.sign[r], c.width, c.height, r);
+      }
+    }
     if (t.rank == 0) {
       for (int i = 0; i < 4; i++) lds_st(&M.sh->ref_mv[r][part][i], mv_all[i]);
       if (part == max_pb - 1) lds_st(&M.sh->mv_center[r], mv_center);
@@ -1422,6 +1432,8 @@ TK_DEVNI void md_item_ref(const Team t, JobR<PIX> J, WsP<PIX> ws, MdCtx<PIX>& M,
     }
     t.sync();
   }
+  if (t.rank == 0) ldsc(ws->mep)->cwin_valid = 0;   // the transform workspace the window lives in is about to be used again
+  t.sync();
 }
 
 // MD_TRIAL: the RDO trials of one (reference, partition) (encode_block.c:1993-2012): tb_param -1 (no residual), 0 and 1 share one prediction.

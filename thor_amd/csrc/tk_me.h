@@ -29,6 +29,9 @@ struct MeWs {  // per wavefront
   long long* prof;
   uint32_t* win;  // per-wave LDS for the search window (see MeWin below), nullptr: none
   int win_cap;    // its size in bytes
+  // A window staged for a whole coding block (me_stage_cb_window): the searches of a reference's HOR / VER / QUAD partitions all start from
+  // the same centre, so one (CB + 2R)^2 window serves all eight of them.  cwin_ax / cwin_ay: absolute luma position of its first sample.
+  int cwin_valid, cwin_ref, cwin_ax, cwin_ay, cwin_Ww, cwin_Wh, cwin_pitch;
 };
 TK_DEV int mv_len1(int a) {
   a = iabs(a);
@@ -412,6 +415,53 @@ template <int SP, typename PIX> TK_DEV unsigned fast_quarterpel(const Team t, co
   return utop;
 }
 
+// Stage ONE window for the coding block at (cb_x, cb_y) of size cb in reference `ref_idx` (ref_cb = its co-located sample in the padded
+// plane), centred on the rounded search centre mvc: the HOR / VER / QUAD searches of this reference (eight motion_estimate calls) all start
+// from it and find their window in LDS (motion_estimate: use_cb_win).  No window (cwin_valid = 0) when it does not fit the wave's budget
+// with a reach of at least kMeWinRmin or would leave the padded plane.  The caller clears cwin_valid before the transform workspace is
+// used again.
+template <typename PIX>
+TK_DEV void me_stage_cb_window(const Team t, MeWs* w_, const PIX* ref_cb, int rstride, int cb_x, int cb_y, int cb, mv_t mvc, int sign, int fwidth,
+                               int fheight, int ref_idx) {
+  const auto w = ldsc(w_);
+  const int S = (int)sizeof(PIX), s = sign ? -1 : 1;
+  const int cap = TKU(w->win_cap);
+  int R = kMeWinR;
+  while (R >= kMeWinRmin && me_win_bytes(cb, cb, R, S) > cap) R -= 4;
+  const mv_t mv_ref = mk_mv(((mvc.x + 2) >> 2) << 2, ((mvc.y + 2) >> 2) << 2);
+  const int Ww = cb + 2 * R, Wh = cb + 2 * R, pitch = Ww * S + 4;
+  const int ox = s * (mv_ref.x >> 2) - R, oy = s * (mv_ref.y >> 2) - R;
+  const int ok = TKU(w->win != nullptr && R >= kMeWinRmin && cb_x + ox >= -kPadY && cb_x + ox + Ww <= fwidth + kPadY && cb_y + oy >= -kPadY &&
+                     cb_y + oy + Wh <= fheight + kPadY);
+  t.sync();
+  if (ok) {
+    const uint32_t* w32 = lds_ld(&w_->win);
+    const int rowb = Ww * S, spr = (rowb + 15) >> 4, total = spr * Wh;
+    for (int k0 = 0; k0 < total; k0 += t.size) {
+      const int k = k0 + t.rank;
+      if (k < total) {
+        const int row = k / spr, sg = k - row * spr;
+        const Seg16 v = seg_load<SP_GLOBAL, 16>((const char*)(ref_cb + (oy + row) * rstride + ox) + 16 * sg);
+        const int d = (row * pitch + 16 * sg) >> 2;
+        const int nd = tmin(4, (rowb - 16 * sg) >> 2);
+#if TK_HOST
+        for (int q = 0; q < nd; q++) ((uint32_t*)w32)[d + q] = v.d[q];
+#else
+        TK_LDS uint32_t* l = (TK_LDS uint32_t*)(uint32_t)(uintptr_t)w32 + d;
+        l[0] = v.d[0];
+        if (nd > 1) l[1] = v.d[1];
+        if (nd > 2) l[2] = v.d[2];
+        if (nd > 3) l[3] = v.d[3];
+#endif
+      }
+    }
+  }
+  if (t.rank == 0) {
+    w->cwin_valid = ok; w->cwin_ref = ref_idx; w->cwin_ax = cb_x + ox; w->cwin_ay = cb_y + oy; w->cwin_Ww = Ww; w->cwin_Wh = Wh; w->cwin_pitch = pitch;
+  }
+  t.sync();
+}
+
 // SP: address space of the original-sample block `org` (LDS copy for coding blocks up to kLdsBlk and their 2*org-pred
 // blocks, frame plane / global scratch above); w always lives in LDS on the device.
 template <typename PIX, int SP>
@@ -470,7 +520,13 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
   // when the whole window lies inside the padded reference plane (otherwise every pass of this search reads the plane).
   MeWin win;
   win.on = 0; win.w32 = nullptr; win.ox = win.oy = win.Ww = win.Wh = win.pitch = 0;
-  {
+  const int use_cb_win = TKU(w->cwin_valid && w->cwin_ref == ref_idx && a.speed == 0);
+  if (use_cb_win) {   // the block's window is already in LDS (me_stage_cb_window): this PU's view of it
+    win.Ww = TKU(w->cwin_Ww); win.Wh = TKU(w->cwin_Wh); win.pitch = TKU(w->cwin_pitch);
+    win.ox = TKU(w->cwin_ax) - a.pu_x; win.oy = TKU(w->cwin_ay) - a.pu_y;
+    win.w32 = lds_ld(&w_->win);
+    win.on = 1;
+  } else {
     const int S = (int)sizeof(PIX);
     const int cap = TKU(w->win_cap);
     int R = kMeWinR;
