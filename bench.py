@@ -20,14 +20,19 @@ last of its streams; they run on host cores concurrently with the GPU work and c
 max(warmup + 2, 7), more when the reference can be expected to finish inside the GPU run anyway - i.e. they reach INTO the
 timed region (with the driver's flags: I, P1..P4 and the first timed 4-reference frames).  The GPU bitstream prefix of those
 frames and the reconstruction of EVERY one of them must equal the reference's; `bit_exact_scope` says which timed frames that
-covers; "bit_exact": false zeroes the metric and the exit code is 1.  `--verify recorded` (the RA / HDB16 operating points at
-3840x2160, whose reference runs take 5-11 minutes per stream) compares every frame of the three streams with reference runs
-recorded in the build container (scripts/record_bench_refs.py -> tests/golden/bench_refs.json).
-cpu_baseline: CPU seconds (wait4 rusage) of two reference runs that differ by one coded frame (LDB) or by everything but the I
-frame (reordered configs), taken when the processes exit; an implausible value is an error, not a number.
+covers; "bit_exact": false zeroes the metric and the exit code is 1.  On top of the live runs EVERY RANK compares every coded frame -
+the whole bitstream and the reconstruction of each frame, so all the timed frames - of those of its streams for which a reference run
+was recorded in the build container (scripts/record_bench_refs.py -> tests/golden/bench_refs.json: 11 streams of rank 0 of the headline
+workload with the driver's flags and the first stream of each further rank up to 8 GPUs; the reference needs ~11 minutes per 25-frame 3840x2160
+stream on one core, which no default run can wait for).  `--verify recorded` uses the records only (the RA / HDB16 operating points at
+3840x2160), `--verify live` the live runs only.
+cpu_baseline: CPU seconds (wait4 rusage) of reference runs taken when the processes exit; an implausible value is an error, not a number.
+`value` is sampled on EXACTLY the timed frames: two runs of the top-left 1920x1080 crop of stream 0 with warmup + steps and with warmup frames
+(LDB; a bounded sample - the full-size pair would take the GPU run's time several times over); the one-frame figure at the benched geometry
+(the two live runs that differ by one coded frame) and the build container's full-size figure over the timed frames are reported beside it.
 
   python bench.py --gpus N --steps K --warmup W [--streams S] [--width 3840 --height 2160] [--config ldb|ra|hdb16]
-                  [--bitdepth 8|10] [--sigma 2.0] [--verify live|recorded] [--cpu-sample WxH]
+                  [--bitdepth 8|10] [--sigma 2.0] [--verify auto|live|recorded] [--cpu-sample WxH] [--clip-frames F]
 For N > 1 launch with torch.distributed.run (one rank per GPU); streams are sharded across ranks with no data-path
 collective in the timed region ("weak" scaling: S streams per GPU); RCCL carries a consistency broadcast of the input
 before it and the ordered gather of the per-chunk bitstreams + the all-reduce of the bit/frame counts after it.  A launch
@@ -54,7 +59,7 @@ CONFIGS = {  # operating points of BASELINE.json: config file, default qp
 }
 REF_ENC = os.path.join(ROOT, 'oracle', '_ref', 'Thorenc')
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
-PMC_JSON = 'r04_pmc_bench.json'
+PMC_JSON = 'r05_pmc_bench.json'
 # v_sad_u8: 4 sample differences per lane and instruction, 64 lanes, one wave64 VALU instruction per 4 clocks and SIMD,
 # 1024 SIMDs at 2.4 GHz (MI355X_MICROARCH.md) -> pixel-differences per second the chip could accumulate
 SAD_PEAK_PXOPS = 1024 * 2.4e9 / 4 * 64 * 4
@@ -227,7 +232,7 @@ class CpuLegs:
         it['rc'] = os.waitstatus_to_exitcode(status)
         it['popen'].returncode = it['rc']   # the child has been reaped here: keep subprocess from waiting for it again
 
-    def start(self, tag, frames_bytes, n, with_rec):
+    def start(self, tag, frames_bytes, n, with_rec, geom=None):
         import threading
         d = self.dir.name
         path = os.path.join(d, tag + '.yuv')
@@ -235,7 +240,8 @@ class CpuLegs:
             with open(path, 'wb') as f:
                 for fr in frames_bytes:
                     f.write(fr)
-        cmd = [REF_ENC, '-cf', self.cfg, '-if', path, '-width', str(self.w), '-height', str(self.h), '-qp', str(self.qp),
+        gw, gh = geom or (self.w, self.h)
+        cmd = [REF_ENC, '-cf', self.cfg, '-if', path, '-width', str(gw), '-height', str(gh), '-qp', str(self.qp),
                '-n', str(n), '-f', '30', '-of', os.path.join(d, f'{tag}_{n}.bit')] + self.extra
         if with_rec:
             cmd += ['-rf', os.path.join(d, f'{tag}_{n}.yuv')]
@@ -257,6 +263,37 @@ class CpuLegs:
         return open(os.path.join(self.dir.name, f'{tag}_{n}.{what}'), 'rb').read()
 
 
+def est_run_s(nframes, w, h, S):
+    """Rough wall time of the GPU run (input staging + frames), for sizing the CPU legs that should end with it."""
+    return nframes * w * h * S / 90e6 + 30.0
+
+
+def file_md5(path):
+    return hashlib.md5(open(path, 'rb').read()).hexdigest()
+
+
+def load_bench_refs(cfg_path):
+    """tests/golden/bench_refs.json: recorded reference runs {ref_key: record}.  Records carry the md5 of the configuration file and of the
+    reference binary they were made with: a record made with another configuration file is dropped (it describes another workload); another
+    reference binary (a rebuilt oracle/_ref) is reported in '_note'."""
+    path = os.path.join(ROOT, 'tests', 'golden', 'bench_refs.json')
+    if not os.path.exists(path):
+        return {}
+    refs = json.load(open(path))
+    cfg_md5 = file_md5(cfg_path)
+    enc_md5 = file_md5(REF_ENC) if os.path.exists(REF_ENC) else None
+    out, other_bin = {}, 0
+    for k, r in refs.items():
+        if r.get('cfg_md5') not in (None, cfg_md5) and k.split('_')[0] == os.path.basename(cfg_path).split('_')[0]:
+            continue
+        if enc_md5 and r.get('ref_enc_md5') not in (None, enc_md5):
+            other_bin += 1
+        out[k] = r
+    if other_bin:
+        out['_note'] = f'{other_bin} records were made with another build of oracle/_ref/Thorenc than the one in this snapshot'
+    return out
+
+
 def one_frame_baseline(t_hi, t_lo, frame_px, what):
     """1-core figure from two legs that differ by one coded frame: (wall, cpu) of the longer and the shorter run.  CPU seconds
     (rusage) are the measure; the result must be a plausible single-core rate of this encoder - a difference that is not
@@ -271,6 +308,51 @@ def one_frame_baseline(t_hi, t_lo, frame_px, what):
         raise RuntimeError(f'cpu_baseline: {v:.3f} Mpixels/s is not a single-core rate of the reference encoder '
                            f'(t = {t_hi[1]:.2f} s - {t_lo[1]:.2f} s of CPU time)')
     return v, d_cpu, d_wall
+
+
+def cpu_baseline_object(times, base_tag, tf_legs, nv, n_ref, reordered, a, p, w, h, cw, ch, legs, world, my_ids, refs, qp, clipn):
+    """The cpu_baseline object of the line from the (wall, CPU seconds) of the reference legs."""
+    nframes = a.warmup + a.steps
+    n_lo = 1 if reordered else nv - 1
+    nproc = len(legs.procs)
+    if not (n_lo >= 1 and n_lo < n_ref):
+        raise RuntimeError(f'cpu_baseline needs two reference runs of different length (have {n_ref} frames)')
+    t_hi, t_lo = times[(base_tag, n_ref)], times[(base_tag, n_lo)]
+    v1, d_cpu, d_wall = one_frame_baseline(t_hi, t_lo, float(cw) * ch * (n_ref - n_lo), {'frames_lo': n_lo})
+    # aggregate of all concurrently running reference processes of the benched geometry: pixels coded / wall of the slowest
+    same_geom = {k: t for k, t in times.items() if k[0] != 't'}
+    agg = sum(n for (_, n) in same_geom) * float(cw) * ch / max(t[0] for t in same_geom.values()) / 1e6
+    what = (f'coded frame {nv - 1} ({min(int(p.max_num_ref), nv - 1)} references)' if not reordered
+            else f'coded frames 1..{n_ref - 1} of the chunk (everything but the I frame)')
+    geom = (f'at the benched geometry {w}x{h}' if (cw, ch) == (w, h) else
+            f'top-left {cw}x{ch} crop of the {w}x{h} frames (a bounded sample: the full-size reference run takes many minutes per stream)')
+    tail = (f'Thorenc SIMD build, 1 thread per process, {nproc} reference processes running at the same time beside the GPU job on rank 0 of {world} '
+            f'(the other ranks run no reference process)')
+    one = {'value': round(v1, 4), 'unit': 'Mpixels/s',
+           'sample': f'stream {my_ids[0]} of the same workload, {geom}: {what} = CPU time (user + system, wait4 rusage) of the {n_ref}-frame run - of the '
+                     f'{n_lo}-frame run = {t_hi[1]:.1f} s - {t_lo[1]:.1f} s = {d_cpu:.1f} s (wall until exit: {t_hi[0]:.1f} s - {t_lo[0]:.1f} s = {d_wall:.1f} s)'}
+    out = {'value': one['value'], 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'reference', 'sample': one['sample'] + '; ' + tail}
+    if tf_legs is not None:   # the figure over exactly the timed frames (LDB): it is the headline value
+        tw, th = tf_legs
+        t_hi, t_lo = times[('t', nframes)], times[('t', a.warmup)]
+        vt, dt_cpu, dt_wall = one_frame_baseline(t_hi, t_lo, float(tw) * th * a.steps, {'frames_lo': a.warmup})
+        out['value'] = round(vt, 4)
+        out['sample'] = (f'stream {my_ids[0]} of the same workload, the TIMED coded frames {a.warmup}..{nframes - 1} on the top-left {tw}x{th} crop of the {w}x{h} frames (a bounded '
+                         f'sample: the full-size pair of runs takes {nframes * w * h / 0.3e6 / 60:.0f} minutes): CPU time (user + system, wait4 rusage) of the {nframes}-frame run - of the '
+                         f'{a.warmup}-frame run = {t_hi[1]:.1f} s - {t_lo[1]:.1f} s = {dt_cpu:.1f} s (wall until exit: {t_hi[0]:.1f} s - {t_lo[0]:.1f} s); ' + tail)
+        out['one_frame_full_geometry'] = one
+    # the same difference at the full geometry, recorded in the build container (another host: reported, never the value)
+    k_hi = refs.get(ref_key(a.config, w, h, a.bitdepth, qp, nframes, a.sigma, my_ids[0]))
+    k_lo = refs.get(ref_key(a.config, w, h, a.bitdepth, qp, a.warmup, a.sigma, my_ids[0]) + f'_cpu_of_n{nframes}')
+    if not reordered and clipn == nframes and k_hi and k_lo and 'cpu_s' in k_hi and k_hi['cpu_s'] > k_lo['cpu_s']:
+        out['recorded_full_geometry_timed_frames'] = {
+            'value': round(float(w) * h * a.steps / (k_hi['cpu_s'] - k_lo['cpu_s']) / 1e6, 4), 'unit': 'Mpixels/s',
+            'sample': f'coded frames {a.warmup}..{nframes - 1} of stream {my_ids[0]} at {w}x{h}: CPU seconds of the recorded {nframes}-frame reference run - of the {a.warmup}-frame '
+                      f'run = {k_hi["cpu_s"]:.1f} s - {k_lo["cpu_s"]:.1f} s, measured in the build container ({k_hi.get("cpu_host")}; {k_hi.get("cpu_concurrent_jobs")} reference '
+                      f'processes at once), not on the GPU box'}
+    out['n_process'] = {'procs': nproc, 'host_cores': legs.ncores, 'value': round(agg, 4), 'unit': 'Mpixels/s',
+                        'note': f'N = {len(same_geom)} concurrently running reference processes of the benched geometry (verify + baseline + fill-up chunks): pixels coded / wall of the slowest'}
+    return out
 
 
 def main():
@@ -288,9 +370,12 @@ def main():
     ap.add_argument('--verify-frames', type=int, default=None, help='coded frames compared with the live reference (default: min(frames, max(warmup + 2, 7)))')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-verify', action='store_true')
-    ap.add_argument('--verify', choices=('live', 'recorded'), default='live',
-                    help='live: reference processes beside the GPU run (default); recorded: every frame of three streams against reference runs recorded with '
-                         'scripts/record_bench_refs.py (tests/golden/bench_refs.json) - for operating points whose reference runs take many minutes per stream')
+    ap.add_argument('--verify', choices=('auto', 'live', 'recorded'), default='auto',
+                    help='auto (default): live reference processes beside the GPU run on rank 0 (first / middle / last stream, the frames they can finish) AND, on every rank, '
+                         'every frame of the streams that have a reference run recorded with scripts/record_bench_refs.py (tests/golden/bench_refs.json); live / recorded: only that')
+    ap.add_argument('--clip-frames', type=int, default=None,
+                    help='generate the seeded clip as a run of this many coded frames would (the clip depends on its length) and encode its first warmup + steps frames: '
+                         'a shorter low-delay run is then a prefix of the recorded 25-frame reference runs and is verified against them')
     ap.add_argument('--cpu-sample', default=None, metavar='WxH',
                     help='with --verify recorded: geometry of the live CPU-baseline sample (top-left crop of stream 0, all frames); default: the benched geometry')
     a = ap.parse_args()
@@ -325,20 +410,22 @@ def main():
     bps = 2 if hbd else 1
     ref_extra = ['-bitdepth', str(a.bitdepth), '-input_bitdepth', str(a.bitdepth)] if hbd else []
     nframes = a.warmup + a.steps           # coded frames = display frames of every chunk
+    clipn = a.clip_frames if a.clip_frames is not None else nframes   # the length the seeded clip is generated for
+    assert clipn >= nframes and (clipn == nframes or a.config == 'ldb'), '--clip-frames: low-delay configuration, at least warmup + steps'
     fpx = w * h * 3 // 2                   # samples per frame
     extra = EXTRA_FRAMES
     reordered = a.config != 'ldb'
     # ---- input: every rank generates the seeded clip; chunks are cut on the GPU --------------------------------------
     t_in = time.perf_counter()
     seed = CONTENT_SEED(a.config, w)
-    base = synth.make_clip(w, h, nframes + extra, seed, a.sigma, a.bitdepth)
+    base = synth.make_clip(w, h, clipn + extra, seed, a.sigma, a.bitdepth)
     flat = np.concatenate([np.concatenate([p.ravel() for p in fr]) for fr in base])
     my_ids = stream_ids(S * world, world, rank)
     if dist is not None:  # consistency of the inputs across ranks: rank 0's first frame travels over RCCL and is compared
         f0 = broadcast_clip(flat[:fpx].view(np.uint8) if rank == 0 else None, dist)
         assert f0.cpu().numpy().tobytes() == flat[:fpx].tobytes(), 'ranks generated different clips'
     clip_t = torch.from_numpy(flat.view(np.int16) if hbd else flat).to(dev)
-    dev_frames = clip_t.view(nframes + extra, fpx)
+    dev_frames = clip_t.view(clipn + extra, fpx)
     over = {'bitdepth': a.bitdepth, 'input_bitdepth': a.bitdepth} if hbd else {}
     p = thor_amd.load_config(cfg_path, width=w, height=h, qp=qp, f=30, **over)
     enc = thor_amd.Encoder(p, S, device=local_rank)
@@ -346,10 +433,10 @@ def main():
     maxv = (1 << a.bitdepth) - 1
 
     def stream_frames(sid):
-        return host_stream_frames(base, sid, nframes, a.bitdepth)
+        return host_stream_frames(base, sid, clipn, a.bitdepth)[:nframes]
 
     def dev_stream_frame(sid, f):  # the torch restatement of host_stream_frames (checked against it below)
-        off = sid % max(1, (nframes + extra) - nframes + 1)
+        off = sid % (extra + 1)
         mode = (sid // 3) % 4
         fr = dev_frames[off + f]
         Y, U, V = fr[:w * h].view(h, w), fr[w * h:w * h + c2].view(h // 2, w // 2), fr[w * h + c2:].view(h // 2, w // 2)
@@ -360,7 +447,7 @@ def main():
         return torch.cat([Y.reshape(-1), U.reshape(-1), V.reshape(-1)])
 
     # ---- checker / CPU baseline: reference processes start NOW and run beside the GPU ------------------------------
-    # Verified frames: at least I + the frames that fill the reference list + two timed frames (7 with the driver's flags);
+    # Live-verified frames: at least I + the frames that fill the reference list + two timed frames (7 with the driver's flags);
     # more when the reference legs can be expected to finish inside the GPU run anyway (one host core codes a frame of this
     # geometry in ~w*h/0.33e6 s; the GPU run takes ~frames * w*h*S / 90e6 s): they cost no wall time.
     nv = a.verify_frames
@@ -373,51 +460,77 @@ def main():
     hq = int(p.HQperiod) if not reordered else 0
     if hq > 1 and nv - 1 > 0 and (nv - 1) % hq == 0:   # the baseline frame (coded frame nv - 1) must not be a high-quality frame
         nv = nv + 1 if nv + 1 <= nframes else nv - 1
-    recorded = None    # --verify recorded: {local stream index: record} of tests/golden/bench_refs.json
     cw, ch = w, h      # geometry of the live CPU legs
-    if a.verify == 'recorded' and not a.no_verify:
-        refs = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'bench_refs.json')))
-        recorded = {s: refs[ref_key(a.config, w, h, a.bitdepth, qp, nframes, a.sigma, my_ids[s])] for s in sorted({0, S // 2, S - 1})} if rank == 0 else {}
-        nv = nframes
-        if a.cpu_sample:
-            cw, ch = (int(x) for x in a.cpu_sample.lower().split('x'))
-            assert cw <= w and ch <= h and cw % 8 == 0 and ch % 8 == 0
+    if a.cpu_sample:
+        cw, ch = (int(x) for x in a.cpu_sample.lower().split('x'))
+        assert cw <= w and ch <= h and cw % 8 == 0 and ch % 8 == 0
     legs = CpuLegs(cfg_path, cw, ch, qp, ref_extra, nframes, reordered)
-    verify = {}        # local stream index -> [host frames, {coded frame: (display index, md5 of the GPU reconstruction)}]
-    do_verify = rank == 0 and not a.no_verify and (legs.available() or recorded is not None)
+    # Recorded reference runs (every rank, its own streams): {local stream index: record}.  A record of the same stream with more frames
+    # serves a shorter low-delay run through its per-frame prefix hashes (the clip must have been generated for that length: --clip-frames).
+    recorded, refs_note = {}, None
+    if a.verify in ('auto', 'recorded') and not a.no_verify:
+        refs = load_bench_refs(cfg_path)
+        refs_note = refs.pop('_note', None)
+        for s_ in range(S):
+            r_ = refs.get(ref_key(a.config, w, h, a.bitdepth, qp, clipn, a.sigma, my_ids[s_]))
+            if r_ is not None and (clipn == nframes or len(r_.get('prefix_md5', [])) >= nframes):
+                recorded[s_] = r_
+        if a.verify == 'recorded' and rank == 0:
+            missing = [my_ids[s_] for s_ in sorted({0, S // 2, S - 1}) if s_ not in recorded]
+            if missing:
+                raise KeyError(f'--verify recorded: no recorded reference run for streams {missing} of this workload (scripts/record_bench_refs.py)')
+    live = a.verify in ('auto', 'live') and not a.no_verify and rank == 0 and legs.available() and (cw, ch) == (w, h)
+    if a.verify == 'recorded':
+        nv = nframes
+    verify = {}        # local stream index -> [host frames or None, {coded frame: (display index, md5 of the GPU reconstruction)}]
+    do_verify = not a.no_verify and (live or bool(recorded))
     do_base = rank == 0 and not a.no_cpu_baseline and legs.available()
     n_ref = nframes if reordered else nv   # with frame reordering the coding order depends on the chunk length: run it all
-    if rank == 0 and (do_verify or do_base):
-        vs = sorted({0, S // 2, S - 1}) if do_verify else [0]
-        def crop(fr):   # top-left cw x ch crop of a flat 4:2:0 frame (the CPU-baseline sample of --cpu-sample)
-            if (cw, ch) == (w, h):
-                return fr
-            Y, U, V = fr[:w * h].reshape(h, w), fr[w * h:w * h + c2].reshape(h // 2, w // 2), fr[w * h + c2:].reshape(h // 2, w // 2)
-            return np.concatenate([np.ascontiguousarray(Y[:ch, :cw]).ravel(), np.ascontiguousarray(U[:ch // 2, :cw // 2]).ravel(), np.ascontiguousarray(V[:ch // 2, :cw // 2]).ravel()])
-        for s in vs:
-            fr = stream_frames(my_ids[s])
-            verify[s] = [fr, {}]
-            if recorded is not None:
-                if do_base and s == vs[0]:
-                    legs.start(f'v{my_ids[s]}', [crop(x).tobytes() for x in fr[:n_ref]], n_ref, False)
-            elif do_verify or s == vs[0]:
-                legs.start(f'v{my_ids[s]}', [x.tobytes() for x in fr[:n_ref]], n_ref, do_verify)
+    vs_live = sorted({0, S // 2, S - 1}) if live else []
+    for s_ in recorded:
+        verify[s_] = [None, {}]
+
+    def crop(fr, cw_, ch_):   # top-left crop of a flat 4:2:0 frame (CPU-baseline samples)
+        if (cw_, ch_) == (w, h):
+            return fr
+        Y, U, V = fr[:w * h].reshape(h, w), fr[w * h:w * h + c2].reshape(h // 2, w // 2), fr[w * h + c2:].reshape(h // 2, w // 2)
+        return np.concatenate([np.ascontiguousarray(Y[:ch_, :cw_]).ravel(), np.ascontiguousarray(U[:ch_ // 2, :cw_ // 2]).ravel(), np.ascontiguousarray(V[:ch_ // 2, :cw_ // 2]).ravel()])
+    base_tag, tf_legs = None, None
+    if rank == 0 and (live or do_base):
+        for s_ in (vs_live or [0]):
+            fr = stream_frames(my_ids[s_])
+            verify.setdefault(s_, [None, {}])[0] = fr
+            if live or s_ == 0:
+                legs.start(f'v{my_ids[s_]}', [crop(x, cw, ch).tobytes() for x in fr[:n_ref]], n_ref, live and s_ in vs_live)
+        if not live and 0 in verify and 0 not in recorded:
+            del verify[0]     # stream 0 only feeds the CPU-baseline legs
         if do_base:
-            s0 = vs[0]
-            # second leg of the 1-core figure: one frame less (LDB: the difference is coded frame nv - 1 with every reference in
+            base_tag = f'v{my_ids[0]}'
+            # second leg of the one-frame figure: one frame less (LDB: the difference is coded frame nv - 1 with every reference in
             # use); with frame reordering the I frame alone (the difference is every other frame of the chunk)
             n_lo = 1 if reordered else nv - 1
             if n_lo >= 1 and n_lo < n_ref:
-                legs.start(f'v{my_ids[s0]}', None, n_lo, False)
+                legs.start(base_tag, None, n_lo, False)
+            # LDB: the CPU figure over EXACTLY the timed frames - a top-left crop of stream 0 (at most 1920x1080) coded with warmup + steps
+            # and with warmup frames; the difference of the CPU seconds is coded frames warmup .. warmup + steps - 1
+            if not reordered and a.warmup >= 1 and not a.cpu_sample:
+                tw, th = min(w, 1920), min(h, 1080)
+                tw, th = tw - tw % 8, th - th % 8
+                if nframes * tw * th / 0.3e6 < max(60.0, 0.8 * est_run_s(nframes, w, h, S)):   # bounded: it must end with the GPU run
+                    fr0 = stream_frames(my_ids[0])
+                    legs.start('t', [crop(x, tw, th).tobytes() for x in fr0], nframes, False, geom=(tw, th))
+                    legs.start('t', None, a.warmup, False, geom=(tw, th))
+                    tf_legs = (tw, th)
             # N-process figure: fill the remaining host cores (one is left to this process) with further chunks
             nm = max(0, min(legs.ncores - 1, 8) - len(legs.procs))
             km = min(n_ref, 3)
             for k in range(nm):
                 sid = my_ids[(1 + k) % S]
-                legs.start(f'm{k}', [x.tobytes() for x in stream_frames(sid)[:km]], km, False)
-    if rank == 0 and verify:
+                legs.start(f'm{k}', [crop(x, cw, ch).tobytes() for x in stream_frames(sid)[:km]], km, False)
+    if verify:
         s_chk = sorted(verify)[-1]
-        assert np.array_equal(dev_stream_frame(my_ids[s_chk], 0).cpu().numpy().view(np.uint8), verify[s_chk][0][0].view(np.uint8)), \
+        fr_chk = verify[s_chk][0][0] if verify[s_chk][0] is not None else stream_frames(my_ids[s_chk])[0]
+        assert np.array_equal(dev_stream_frame(my_ids[s_chk], 0).cpu().numpy().view(np.uint8), fr_chk.view(np.uint8)), \
             'GPU chunk cutter differs from the host stream generator'
 
     for s in range(S):
@@ -431,6 +544,8 @@ def main():
     t_in = time.perf_counter() - t_in
 
     coded = [0]
+    from concurrent.futures import ThreadPoolExecutor
+    hasher = ThreadPoolExecutor(2)
 
     def step():
         """One lock-step frame of every stream, in coding order."""
@@ -441,9 +556,12 @@ def main():
             idx = [coded[0]] * S
         enc.encode_staged(idx)      # blocks until all streams' bits are on the host
         coded[0] += 1
-        if do_verify and coded[0] <= nv:
-            for s in verify:   # reconstruction of every verified coded frame: (display index, md5)
-                verify[s][1][coded[0] - 1] = (idx[s], hashlib.md5(enc.recon(s).tobytes()).hexdigest())
+        if do_verify:
+            # reconstruction of every verified coded frame: (display index, md5).  The frame is fetched here (D2H); the hash is taken by a
+            # worker thread while the GPU codes the next frame (hashlib releases the GIL)
+            for s in verify:
+                if s in recorded or coded[0] <= nv:
+                    verify[s][1][coded[0] - 1] = (idx[s], hasher.submit(lambda b: hashlib.md5(b).hexdigest(), enc.recon(s).tobytes()))
 
     for _ in range(a.warmup):
         step()
@@ -489,66 +607,79 @@ def main():
         t_w = time.perf_counter()
         times = legs.collect() if legs.procs else {}
         t_w = time.perf_counter() - t_w
-        if do_verify:
-            ok = True
-            fbytes = fpx * bps
-            for s in sorted(verify):
-                fr, recs = verify[s]
-                tag = f'v{my_ids[s]}'
-                rec_frames = []
-                if recorded is not None:   # whole stream + every reconstructed frame against the recorded reference run
-                    rr = recorded[s]
-                    rpre = b'x' * rr['bit_bytes']
-                    same = len(local_bits[s]) == rr['bit_bytes'] and hashlib.md5(local_bits[s]).hexdigest() == rr['bit_md5'] and len(recs) == nframes
-                    for cf in sorted(recs):
-                        di, md5 = recs[cf]
-                        rec_frames.append(cf)
-                        same = same and rr['rec_md5'][di] == md5
-                else:
-                    rbits = legs.read(tag, n_ref, 'bit')
-                    rrec = legs.read(tag, n_ref, 'yuv')
-                    gpre, rpre = stream_prefix(local_bits[s], nv), stream_prefix(rbits, nv)
-                    same = gpre is not None and rpre is not None and gpre == rpre   # a stream with fewer than nv frames is a failure
-                    for cf in sorted(recs):   # the reference writes its reconstruction in DISPLAY order
-                        di, md5 = recs[cf]
-                        r_ok = len(rrec) >= (di + 1) * fbytes and hashlib.md5(rrec[di * fbytes:(di + 1) * fbytes]).hexdigest() == md5
-                        rec_frames.append(cf)
-                        same = same and r_ok
-                res['checked'].append({'stream': my_ids[s], 'frames': nv, 'timed_frames_covered': max(0, nv - a.warmup),
-                                       'timed_coded_frames_compared': list(range(a.warmup, nv)),
-                                       'bitstream_bytes': len(rpre or b''), 'recon_checked': bool(rec_frames),
-                                       'recon_coded_frames_compared': rec_frames, 'ok': bool(same)})
-                ok = ok and same
-            res['bit_exact'] = bool(ok)
-            res['bit_exact_source'] = ('reference runs recorded in the build container (scripts/record_bench_refs.py -> tests/golden/bench_refs.json)'
-                                       if recorded is not None else 'live runs of oracle/_ref/Thorenc beside the GPU run')
-            res['bit_exact_scope'] = (f'{len(verify)} of {S} streams (first, middle, last), coded frames 0..{nv - 1} of {nframes}: bitstream prefix + reconstruction of '
-                                      f'every one of those frames equal the live reference run; timed frames {a.warmup}..{nv - 1} of {a.warmup}..{nframes - 1} are covered')
         if do_base:
-            tag = f'v{my_ids[sorted(verify)[0]]}'
-            n_lo = 1 if reordered else nv - 1
-            nproc = len(legs.procs)
             try:
-                if not (n_lo >= 1 and n_lo < n_ref):
-                    raise RuntimeError(f'cpu_baseline needs two reference runs of different length (have {n_ref} frames)')
-                t_hi, t_lo = times[(tag, n_ref)], times[(tag, n_lo)]
-                v1, d_cpu, d_wall = one_frame_baseline(t_hi, t_lo, float(cw) * ch * (n_ref - n_lo), {'frames_lo': n_lo})
-                # aggregate of all concurrently running reference processes: pixels coded / wall of the slowest
-                agg_px = sum(n for (_, n) in times) * float(cw) * ch
-                agg = agg_px / max(t[0] for t in times.values()) / 1e6
-                what = (f'coded frame {nv - 1} ({min(int(p.max_num_ref), nv - 1)} references)' if not reordered
-                        else f'coded frames 1..{n_ref - 1} of the chunk (everything but the I frame)')
-                res['cpu_baseline'] = {
-                    'value': round(v1, 4), 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'reference',
-                    'sample': f'stream {my_ids[sorted(verify)[0]]} of the same workload, ' + (f'at the benched geometry {w}x{h}' if (cw, ch) == (w, h) else f'top-left {cw}x{ch} crop of the {w}x{h} frames (a bounded sample: the full-size reference run takes many minutes per stream)') + f': {what} = CPU time (user + system, '
-                              f'wait4 rusage) of the {n_ref}-frame run - of the {n_lo}-frame run = {t_hi[1]:.1f} s - {t_lo[1]:.1f} s = {d_cpu:.1f} s '
-                              f'(wall until exit: {t_hi[0]:.1f} s - {t_lo[0]:.1f} s = {d_wall:.1f} s); Thorenc SIMD build, 1 thread per process, '
-                              f'{nproc} reference processes running at the same time beside the GPU job on rank 0 of {world}',
-                    'n_process': {'procs': nproc, 'host_cores': legs.ncores, 'value': round(agg, 4), 'unit': 'Mpixels/s',
-                                  'note': f'N = {nproc} concurrently running reference processes (verify + baseline + fill-up chunks): pixels coded / wall of the slowest'}}
+                res['cpu_baseline'] = cpu_baseline_object(times, base_tag, tf_legs, nv, n_ref, reordered, a, p, w, h, cw, ch, legs, world, my_ids,
+                                                          load_bench_refs(cfg_path) if not a.no_verify else {}, qp, clipn)
             except (RuntimeError, KeyError) as e:
                 print(f'bench.py: {e}', file=sys.stderr)
                 res['cpu_baseline'] = {'value': None, 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'reference', 'sample': None, 'error': str(e)}
+    # ---- verification: every rank checks its own streams, rank 0 collects ------------------------------------------------
+    my_checked, my_ok = [], True
+    if do_verify:
+        fbytes = fpx * bps
+        for s in sorted(verify):
+            fr, recs = verify[s]
+            recs = {cf: (di, fut.result()) for cf, (di, fut) in recs.items()}
+            entry = {'rank': rank, 'stream': my_ids[s], 'ok': True}
+            if s in vs_live:   # bitstream prefix + reconstruction of the first nv coded frames against the live reference run
+                tag = f'v{my_ids[s]}'
+                rbits, rrec = legs.read(tag, n_ref, 'bit'), legs.read(tag, n_ref, 'yuv')
+                gpre, rpre = stream_prefix(local_bits[s], nv), stream_prefix(rbits, nv)
+                same = gpre is not None and rpre is not None and gpre == rpre   # a stream with fewer than nv frames is a failure
+                cmp_frames = []
+                for cf in sorted(recs):   # the reference writes its reconstruction in DISPLAY order
+                    if cf >= nv:
+                        continue
+                    di, md5 = recs[cf]
+                    same = same and len(rrec) >= (di + 1) * fbytes and hashlib.md5(rrec[di * fbytes:(di + 1) * fbytes]).hexdigest() == md5
+                    cmp_frames.append(cf)
+                entry['live'] = {'frames': nv, 'timed_coded_frames_compared': list(range(a.warmup, nv)), 'bitstream_bytes': len(rpre or b''),
+                                 'recon_coded_frames_compared': cmp_frames, 'ok': bool(same)}
+                entry['ok'] = entry['ok'] and bool(same)
+            if s in recorded:  # whole stream (or its prefix) + every reconstructed frame against the recorded reference run
+                rr = recorded[s]
+                if clipn == nframes:
+                    same = len(local_bits[s]) == rr['bit_bytes'] and hashlib.md5(local_bits[s]).hexdigest() == rr['bit_md5']
+                else:
+                    same = hashlib.md5(local_bits[s]).hexdigest() == rr['prefix_md5'][nframes - 1]
+                same = same and len(recs) == nframes
+                for cf in sorted(recs):
+                    di, md5 = recs[cf]
+                    same = same and rr['rec_md5'][di] == md5
+                entry['recorded'] = {'frames': nframes, 'timed_coded_frames_compared': list(range(a.warmup, nframes)), 'bitstream_bytes': len(local_bits[s]),
+                                     'recon_coded_frames_compared': sorted(recs), 'ok': bool(same)}
+                entry['ok'] = entry['ok'] and bool(same)
+            entry['frames'] = nframes if s in recorded else nv
+            entry['timed_frames_covered'] = max(0, entry['frames'] - a.warmup)
+            my_checked.append(entry)
+            my_ok = my_ok and entry['ok']
+    all_checked = [my_checked]
+    if dist is not None:
+        all_checked = [None] * world
+        dist.all_gather_object(all_checked, my_checked)
+    if rank == 0:
+        checked = [e for part in all_checked for e in part]
+        if checked:
+            n_live = sum(1 for e in checked if 'live' in e)
+            n_rec = sum(1 for e in checked if 'recorded' in e)
+            res['checked'] = checked
+            res['bit_exact'] = all(e['ok'] for e in checked)
+            src, scope = [], []
+            if n_live:
+                src.append('live runs of oracle/_ref/Thorenc beside the GPU run')
+                scope.append(f'{n_live} of {S * world} streams (first, middle, last of rank 0) against the live reference run: coded frames 0..{nv - 1} of {nframes} - '
+                             f'bitstream prefix + reconstruction of every one of those frames; timed frames {a.warmup}..{nv - 1} of {a.warmup}..{nframes - 1}')
+            if n_rec:
+                src.append('reference runs recorded in the build container (scripts/record_bench_refs.py -> tests/golden/bench_refs.json)')
+                ranks_rec = sorted({e['rank'] for e in checked if 'recorded' in e})
+                scope.append(f'{n_rec} of {S * world} streams (ranks {ranks_rec}) against recorded reference runs: ALL coded frames 0..{nframes - 1} - the '
+                             f'{"whole bitstream" if clipn == nframes else "bitstream (a prefix of the recorded " + str(clipn) + "-frame run)"} + reconstruction of every frame; '
+                             f'every timed frame {a.warmup}..{nframes - 1} is covered')
+            res['bit_exact_source'] = ' + '.join(src)
+            res['bit_exact_scope'] = '; '.join(scope)
+            if refs_note:
+                res['bit_exact_scope'] += f' ({refs_note})'
         if res['bit_exact'] is False:
             value, rc = 0.0, 1
         # roofline of the dominant kernel (k_superblocks): algorithmic HBM bytes per luma pixel of a P frame with R
@@ -602,7 +733,11 @@ def main():
                          'note': 'one persistent dependency-driven launch per frame; the path is latency/instruction-bound, not HBM-bound (SURVEY.md 0.7); '
                                  'filters+ref kernels took %.1f ms in the timed region' % filt_ms},
             'io': {'input_setup_s': round(t_in, 2), 'gather_s': round(t_g, 3), 'cpu_legs_wait_s': round(t_w, 1),
-                   'stream_bytes_total': int(total_bytes), 'frames_total': int(total_frames)},
+                   'stream_bytes_total': int(total_bytes), 'frames_total': int(total_frames),
+                   'inputs': 'resident in HBM before the timed region (staged device-to-device); host-to-device transfer of the input frames is EXCLUDED from value '
+                             f'(one {fpx * bps / 1e6:.1f} MB frame per stream and step: ~{S * fpx * bps / 50e9 * 1e3:.0f} ms per step at PCIe Gen5 rates); the device-to-host '
+                             'transfer of every stream\'s bits and of the verified reconstructions is inside it',
+                   'rank0_host_load': f'{len(legs.procs)} reference processes (checker + cpu_baseline legs) ran on rank 0\'s host beside its GPU work; the other ranks ran none'},
         }
         if stats:
             out['content'] = stats

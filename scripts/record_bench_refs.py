@@ -25,13 +25,15 @@ def main():
     ap.add_argument('--qp', type=int, default=None)
     ap.add_argument('-j', type=int, default=3)
     ap.add_argument('--sids', default=None, help='comma-separated stream ids to record instead of first / middle / last')
+    ap.add_argument('--clip-frames', type=int, default=None, help='generate the clip as for a run of this many frames (bench.py --clip-frames) and code the first --frames of it')
     ap.add_argument('--cpu-only', action='store_true',
-                    help='record only the CPU seconds of the run (key suffix _cpu): the shorter leg of a recorded CPU-baseline difference')
+                    help='record only the CPU seconds of the run (key suffix _cpu_of_n<clip frames>): the shorter leg of a recorded CPU-baseline difference')
     a = ap.parse_args()
     cfg_name, qp_default = bench.CONFIGS[a.config]
     qp = a.qp if a.qp is not None else qp_default
     w, h, n, S = a.width, a.height, a.frames, a.streams
-    base = synth.make_clip(w, h, n + bench.EXTRA_FRAMES, bench.CONTENT_SEED(a.config, w), a.sigma, a.bitdepth)
+    clipn = a.clip_frames or n
+    base = synth.make_clip(w, h, clipn + bench.EXTRA_FRAMES, bench.CONTENT_SEED(a.config, w), a.sigma, a.bitdepth)
     sids = sorted({0, S // 2, S - 1}) if a.sids is None else sorted({int(x) for x in a.sids.split(',')})
     extra = ['-bitdepth', str(a.bitdepth), '-input_bitdepth', str(a.bitdepth)] if a.bitdepth > 8 else []
     fbytes = w * h * 3 // 2 * (2 if a.bitdepth > 8 else 1)
@@ -43,7 +45,7 @@ def main():
     def job(sid):
         with tempfile.TemporaryDirectory() as d:
             with open(os.path.join(d, 'in.yuv'), 'wb') as f:
-                for fr in bench.host_stream_frames(base, sid, n, a.bitdepth):
+                for fr in bench.host_stream_frames(base, sid, clipn, a.bitdepth)[:n]:
                     f.write(fr.tobytes())
             pr = subprocess.Popen([bench.REF_ENC, '-cf', os.path.join(ROOT, 'configs', cfg_name), '-if', os.path.join(d, 'in.yuv'), '-width', str(w), '-height', str(h),
                                    '-qp', str(qp), '-n', str(n), '-f', '30', '-of', os.path.join(d, 'o.bit'), '-rf', os.path.join(d, 'o.yuv')] + extra,
@@ -51,7 +53,8 @@ def main():
             _, status, ru = os.wait4(pr.pid, 0)   # CPU seconds of exactly this process (user + system), as bench.py's legs take them
             pr.returncode = os.waitstatus_to_exitcode(status)
             assert pr.returncode == 0
-            cpu = {'cpu_s': round(ru.ru_utime + ru.ru_stime, 2), 'cpu_host': HOST, 'cpu_concurrent_jobs': min(a.j, len(sids))}
+            cpu = {'cpu_s': round(ru.ru_utime + ru.ru_stime, 2), 'cpu_host': HOST, 'cpu_concurrent_jobs': min(a.j, len(sids)),
+                   'cfg_md5': bench.file_md5(os.path.join(ROOT, 'configs', cfg_name)), 'ref_enc_md5': bench.file_md5(bench.REF_ENC)}
             if a.cpu_only:
                 return sid, cpu
             bits = open(os.path.join(d, 'o.bit'), 'rb').read()
@@ -68,7 +71,7 @@ def main():
             with open(path + '.lock', 'w') as lk:   # several recorders may run side by side: merge under a lock
                 fcntl.flock(lk, fcntl.LOCK_EX)
                 out = json.load(open(path)) if os.path.exists(path) else {}
-                out[bench.ref_key(a.config, w, h, a.bitdepth, qp, n, a.sigma, sid) + ('_cpu' if a.cpu_only else '')] = res
+                out[bench.ref_key(a.config, w, h, a.bitdepth, qp, n, a.sigma, sid) + (f'_cpu_of_n{clipn}' if a.cpu_only else '')] = res
                 json.dump(out, open(path, 'w'), indent=1, sort_keys=True)
             print('recorded', bench.ref_key(a.config, w, h, a.bitdepth, qp, n, a.sigma, sid), flush=True)
 

@@ -170,7 +170,7 @@ def test_recorded_verification_rejects_a_wrong_stream(monkeypatch, tmp_path):
         assert ex.value.code == 1
         d = json.loads([l for l in buf.getvalue().splitlines() if l.strip()][0])
         assert d['bit_exact'] is False and d['value'] == 0.0 and 'recorded' in d['bit_exact_source']
-        assert len(d['bit_exact_checked']) == 3 and d['bit_exact_checked'][0]['frames'] == 3
+        assert len(d['bit_exact_checked']) == 3 and d['bit_exact_checked'][0]['frames'] == 3 and d['bit_exact_checked'][0]['recorded']['ok'] is False
         assert '128x64 crop' in d['cpu_baseline']['sample'] and d['cpu_baseline'].get('error') is None
     finally:
         if keep is None:
@@ -276,11 +276,17 @@ def test_verification_passes_on_bit_exact_streams_live_and_recorded(monkeypatch)
         with contextlib.redirect_stdout(buf):
             bench.main()
         return json.loads([l for l in buf.getvalue().splitlines() if l.strip()][0])
-    d = run([])
-    assert d['bit_exact'] is True and d['value'] > 0 and 'live' in d['bit_exact_source']
+    d = run(['--verify', 'live'])
+    assert d['bit_exact'] is True and d['value'] > 0 and 'live' in d['bit_exact_source'] and 'recorded' not in d['bit_exact_source']
     assert [c['stream'] for c in d['bit_exact_checked']] == [0, 1, 2]
-    assert all(c['ok'] and c['frames'] == 3 and c['recon_coded_frames_compared'] == [0, 1, 2] and c['timed_coded_frames_compared'] == [1, 2] for c in d['bit_exact_checked'])
-    assert d['cpu_baseline'].get('error') is None and 0.02 < d['cpu_baseline']['value'] < 8
+    assert all(c['ok'] and c['frames'] == 3 and c['live']['recon_coded_frames_compared'] == [0, 1, 2] and c['live']['timed_coded_frames_compared'] == [1, 2]
+               for c in d['bit_exact_checked'])
+    c = d['cpu_baseline']
+    assert c.get('error') is None and 0.02 < c['value'] < 8
+    # LDB: the headline CPU figure is sampled on exactly the timed frames (two runs of a crop: warmup + steps and warmup frames)
+    assert 'TIMED coded frames 1..2' in c['sample'] and '3-frame run' in c['sample'] and '1-frame run' in c['sample']
+    assert 0.02 < c['one_frame_full_geometry']['value'] < 8 and 'coded frame 2' in c['one_frame_full_geometry']['sample']
+    assert 'EXCLUDED' in d['io']['inputs'] and 'rank 0' in d['io']['rank0_host_load']
     refs = os.path.join(ROOT, 'tests', 'golden', 'bench_refs.json')
     keep = open(refs).read()
     try:
@@ -288,5 +294,25 @@ def test_verification_passes_on_bit_exact_streams_live_and_recorded(monkeypatch)
                                '--width', '192', '--height', '128'])
         d = run(['--verify', 'recorded', '--no-cpu-baseline'])
         assert d['bit_exact'] is True and d['value'] > 0 and 'recorded' in d['bit_exact_source'] and len(d['bit_exact_checked']) == 3
+        assert 'live' not in d['bit_exact_source'] and 'equal the live' not in d['bit_exact_scope']
+        # the default: live runs AND the recorded runs of every stream that has one
+        d = run(['--no-cpu-baseline'])
+        assert d['bit_exact'] is True and 'live' in d['bit_exact_source'] and 'recorded' in d['bit_exact_source']
+        assert all('live' in c and 'recorded' in c and c['recorded']['recon_coded_frames_compared'] == [0, 1, 2] for c in d['bit_exact_checked'])
+        assert 'every timed frame 1..2 is covered' in d['bit_exact_scope']
+        # a 5-frame record serves a 3-frame run of the same clip through its prefix hashes (--clip-frames)
+        subprocess.check_call([sys.executable, os.path.join(ROOT, 'scripts', 'record_bench_refs.py'), '--config', 'ldb', '--frames', '5', '--streams', '3',
+                               '--width', '192', '--height', '128', '--sids', '1'])
+        d = run(['--no-cpu-baseline', '--verify', 'recorded', '--clip-frames', '5']) if False else run(['--no-cpu-baseline', '--clip-frames', '5'])
+        rec = [c for c in d['bit_exact_checked'] if 'recorded' in c]
+        assert d['bit_exact'] is True and [c['stream'] for c in rec] == [1] and 'prefix of the recorded 5-frame run' in d['bit_exact_scope']
+        # a record made with another configuration file describes another workload: dropped
+        rj = json.load(open(refs))
+        for k in rj:
+            if k.startswith('ldb_192x128'):
+                rj[k]['cfg_md5'] = 'x'
+        json.dump(rj, open(refs, 'w'))
+        d = run(['--no-cpu-baseline'])
+        assert d['bit_exact'] is True and 'recorded' not in d['bit_exact_source']
     finally:
         open(refs, 'w').write(keep)
