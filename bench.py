@@ -373,6 +373,8 @@ def main():
     ap.add_argument('--verify', choices=('auto', 'live', 'recorded'), default='auto',
                     help='auto (default): live reference processes beside the GPU run on rank 0 (first / middle / last stream, the frames they can finish) AND, on every rank, '
                          'every frame of the streams that have a reference run recorded with scripts/record_bench_refs.py (tests/golden/bench_refs.json); live / recorded: only that')
+    ap.add_argument('--lockstep', action='store_true', help='one lock-step frame of all streams per step (thor_hip_encode_staged, the rounds 1-4 path) instead of '
+                                                            'thor_hip_encode_staged_run (two stream groups half a frame apart)')
     ap.add_argument('--clip-frames', type=int, default=None,
                     help='generate the seeded clip as a run of this many coded frames would (the clip depends on its length) and encode its first warmup + steps frames: '
                          'a shorter low-delay run is then a prefix of the recorded 25-frame reference runs and is verified against them')
@@ -546,9 +548,18 @@ def main():
     coded = [0]
     from concurrent.futures import ThreadPoolExecutor
     hasher = ThreadPoolExecutor(2)
+    done_frames = [0] * S     # coded frames finished per stream
+
+    def take_recon(s, di):
+        """Reconstruction of the frame stream s has just finished: (display index, md5).  The frame is fetched here (D2H); the hash is taken by a
+        worker thread while the GPU codes on (hashlib releases the GIL)."""
+        cf = done_frames[s]
+        if s in verify and (s in recorded or cf < nv):
+            verify[s][1][cf] = (di, hasher.submit(lambda b: hashlib.md5(b).hexdigest(), enc.recon(s).tobytes()))
+        done_frames[s] = cf + 1
 
     def step():
-        """One lock-step frame of every stream, in coding order."""
+        """One lock-step frame of every stream, in coding order (--lockstep)."""
         if reordered:
             idx = [enc.next_frame(s) for s in range(S)]
             assert idx[0] is not None
@@ -556,23 +567,31 @@ def main():
             idx = [coded[0]] * S
         enc.encode_staged(idx)      # blocks until all streams' bits are on the host
         coded[0] += 1
-        if do_verify:
-            # reconstruction of every verified coded frame: (display index, md5).  The frame is fetched here (D2H); the hash is taken by a
-            # worker thread while the GPU codes the next frame (hashlib releases the GIL)
-            for s in verify:
-                if s in recorded or coded[0] <= nv:
-                    verify[s][1][coded[0] - 1] = (idx[s], hasher.submit(lambda b: hashlib.md5(b).hexdigest(), enc.recon(s).tobytes()))
+        for s in range(S):
+            take_recon(s, idx[s]) if do_verify else None
 
-    for _ in range(a.warmup):
-        step()
+    def run(k):
+        """k steps = k frames of every stream.  Default: ONE call of thor_hip_encode_staged_run - the streams in two groups half a frame apart
+        inside the call, which starts and ends on a frame boundary of every stream; --lockstep: k lock-step frames (the rounds 1-4 path)."""
+        if a.lockstep:
+            for _ in range(k):
+                step()
+            return
+
+        def on_done(first, count):
+            if do_verify:
+                for s in range(first, first + count):
+                    take_recon(s, enc.last_display_index(s))
+        enc.encode_run(k, on_done)
+
+    run(a.warmup)
     enc.kernel_time_reset()
     if dist is not None:
         dist.barrier()
     if have_gpu:
         torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    run(a.steps)
     if have_gpu:
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -717,11 +736,12 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u16' if hbd else 'u8', 'data': 'synthetic',
             'bit_exact': res['bit_exact'], 'bit_exact_source': res.get('bit_exact_source'), 'bit_exact_scope': res.get('bit_exact_scope'), 'bit_exact_checked': res['checked'],
             'config': {'workload': f'{w}x{h} {a.bitdepth}-bit 4:2:0, {cfg_name[:-4]} (configs/{cfg_name}), qp {qp}, '
-                                   f'{S} independent closed streams per GPU in lock step, timed frames = coded frames {a.warmup}..{nframes - 1} of each stream '
+                                   f'{S} independent closed streams per GPU ' + ('in lock step' if a.lockstep else 'in two groups half a frame apart (thor_hip_encode_staged_run; the timed '
+                                   'run starts and ends on a frame boundary of every stream)') + f', timed frames = coded frames {a.warmup}..{nframes - 1} of each stream '
                                    f'({R:.2f} references on average), synthetic content sigma {a.sigma:g}',
                        'streams_per_gpu': S, 'frames_timed_per_stream': a.steps, 'parallelism': f'stream-sharded x{world}',
                        'per_stream_fps': round(a.steps / dt, 4), 'per_stream_mpx_s': round(w * h * a.steps / dt / 1e6, 4),
-                       'superblock_queue': 'fifo', 'csrc_digest': csrc_digest()},   # thor_amd/csrc/tk_sched.h
+                       'superblock_queue': 'fifo', 'schedule': 'lockstep' if a.lockstep else 'two groups half a frame apart', 'csrc_digest': csrc_digest()},   # thor_amd/csrc/tk_sched.h
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 4), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 8), 'traffic': traffic, 'traffic_unit': 'bytes per launch', 'traffic_source': traffic_src,
                          'alg_bytes_per_launch': round(alg_bytes_per_launch),

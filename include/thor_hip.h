@@ -98,6 +98,20 @@ int thor_hip_stage_frame_device(thor_hip_encoder* e, int stream, int slot, const
 /* Encode the next frame of every stream from staging slot slots[stream] (inputs already resident
  * in HBM).  Blocks until the bits of all streams are assembled on the host. */
 int thor_hip_encode_staged(thor_hip_encoder* e, const int* slots);
+/* Encode the next `nframes` frames of every stream, each from the staging slot with the frame's chunk-relative DISPLAY index (what
+ * thor_hip_next_frame reports; low-delay streams: the coded index), with the streams in TWO GROUPS HALF A FRAME APART: a launch of the
+ * persistent superblock kernel carries the second half of one group's frame (the narrowing end of its dependency wavefront over the
+ * superblock grid) and the first half of the other group's, so the workgroup slots one group leaves idle are taken by the other - in lock
+ * step (thor_hip_encode_staged frame by frame) every stream ramps up and down at the same time.  The run starts and ends on a frame
+ * boundary of every stream; the bits and reconstructions are those of the frame-by-frame calls (the order in which superblocks are coded
+ * never changes a result: every superblock starts after its dependencies, enc/encode_frame.c:697-835 raster order).
+ * `done` (may be NULL) is called from the calling thread whenever the frames of streams [first_stream, first_stream + num_streams) are
+ * complete: their bits are appended, thor_hip_get_recon returns that frame and thor_hip_last_display_index its display index until the
+ * callback returns.  Returns 0, or non-zero when a stream has no frame left / a slot is not staged. */
+typedef void (*thor_hip_frames_done_fn)(void* user, int first_stream, int num_streams);
+int thor_hip_encode_staged_run(thor_hip_encoder* e, int nframes, thor_hip_frames_done_fn done, void* user);
+/* Chunk-relative display index of the frame stream `stream` coded last (-1: none yet). */
+int thor_hip_last_display_index(const thor_hip_encoder* e, int stream);
 /* Convenience: stage + encode one host frame per stream (PCIe inclusive). */
 int thor_hip_encode_frame(thor_hip_encoder* e, const void* const* yuv_per_stream);
 

@@ -78,12 +78,14 @@ const unsigned long long* exchange_begin(unsigned long long v) {
 void exchange_end() { barrier(); }
 }  // namespace hostlanes
 namespace backend {
-template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>*, int S) {
+template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>*, int S, const SbRange* ranges) {
   const int N = THOR_HOSTSIM_LANES;
   for (int s = 0; s < S; s++) {
+    if (ranges && ranges[s].lo >= ranges[s].hi) continue;   // nothing of this stream in the launch (its job may not be set up yet)
     const FrameJob<PIX>& J = jobs[s];
     for (int k = 0; k < J.sb_rows; k++)
       for (int l = 0; l < J.sb_cols; l++) {
+        if (ranges && !(l + 2 * k >= ranges[s].lo && l + 2 * k < ranges[s].hi)) continue;   // raster order inside a range respects the dependencies
         const int sbi = k * J.sb_cols + l;
         hostlanes::Shared sh;
         sh.n = N;
@@ -133,9 +135,10 @@ void barrier() {
 }
 }  // namespace hostwaves
 namespace backend {
-template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>*, int S) {
+template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>*, int S, const SbRange* ranges) {
   const int NW = kWaves;
   for (int s = 0; s < S; s++) {
+    if (ranges && ranges[s].lo >= ranges[s].hi) continue;
     const FrameJob<PIX>& J = jobs[s];
     hostwaves::Bar bar;
     bar.n = NW;
@@ -149,6 +152,7 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
         const Team t{0, 1, wsv.sh->tabs.izz};
         for (int k = 0; k < J.sb_rows; k++)
           for (int l = 0; l < J.sb_cols; l++) {
+            if (ranges && !(l + 2 * k >= ranges[s].lo && l + 2 * k < ranges[s].hi)) continue;
             const int sbi = k * J.sb_cols + l;
             if (w == 0) {
               BitSink out;
@@ -164,8 +168,9 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
   }
 }
 #else
-template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>*, int S) {
+template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>*, int S, const SbRange* ranges) {
   for (int s = 0; s < S; s++) {
+    if (ranges && ranges[s].lo >= ranges[s].hi) continue;
     const FrameJob<PIX>& J = jobs[s];
     TeamWs<PIX> wsv = wave_ws<PIX>(J.scratch, 0);
     TeamWs<PIX>* ws = &wsv;
@@ -173,6 +178,7 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
     const Team t{0, 1, ws->sh->tabs.izz};
     for (int k = 0; k < J.sb_rows; k++)
       for (int l = 0; l < J.sb_cols; l++) {
+        if (ranges && !(l + 2 * k >= ranges[s].lo && l + 2 * k < ranges[s].hi)) continue;
         const int sbi = k * J.sb_cols + l;
         BitSink out;
         out.buf = J.sb_bits + (size_t)sbi * J.sb_words; out.pos = 0; out.cap = J.sb_words * 32; out.emit = 1; out.ovf = 0;
@@ -290,8 +296,8 @@ template void run_clpf_apply<uint8_t>(const ClpfJob<uint8_t>*, const ClpfJob<uin
 template void run_clpf_apply<uint16_t>(const ClpfJob<uint16_t>*, const ClpfJob<uint16_t>*, int);
 template void run_cdef<uint8_t>(const CdefJob<uint8_t>*, const CdefJob<uint8_t>*, int);
 template void run_cdef<uint16_t>(const CdefJob<uint16_t>*, const CdefJob<uint16_t>*, int);
-template void run_superblocks<uint8_t>(const FrameJob<uint8_t>*, const FrameJob<uint8_t>*, int);
-template void run_superblocks<uint16_t>(const FrameJob<uint16_t>*, const FrameJob<uint16_t>*, int);
+template void run_superblocks<uint8_t>(const FrameJob<uint8_t>*, const FrameJob<uint8_t>*, int, const SbRange*);
+template void run_superblocks<uint16_t>(const FrameJob<uint16_t>*, const FrameJob<uint16_t>*, int, const SbRange*);
 template void run_deblock<uint8_t>(const FrameJob<uint8_t>*, const FrameJob<uint8_t>*, int);
 template void run_deblock<uint16_t>(const FrameJob<uint16_t>*, const FrameJob<uint16_t>*, int);
 template void run_make_ref<uint8_t>(const FrameJob<uint8_t>*, const Plane3<uint8_t>*, int);

@@ -28,6 +28,16 @@ class _FakeEncoder:
     def encode_staged(self, slots):
         assert len(slots) == self.S
         self.calls += 1
+        self.calls_total = getattr(self, 'calls_total', 0) + 1
+
+    def encode_run(self, nframes, on_done=None):
+        for _ in range(nframes):
+            self.encode_staged([self.calls] * self.S)
+            if on_done is not None:
+                on_done(0, self.S)
+
+    def last_display_index(self, stream):
+        return self.calls_total - 1
 
     def kernel_time(self):
         return 12.0, self.calls, 1.0

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 BIG = json.load(open(os.path.join(GOLD, 'streams_big.json')))
 
 
-def _encode(c, clips):
+def _encode(c, clips, staggered=False):
     import thor_amd
     over = {}
     ex = list(c['extra'])
@@ -29,7 +29,7 @@ def _encode(c, clips):
         over[k[1:]] = v
     p = thor_amd.load_config(os.path.join(ROOT, 'configs', c['cfg']), width=c['w'], height=c['h'], qp=c['qp'], f=30, **over)
     with thor_amd.Encoder(p, len(clips)) as enc:
-        bits, recs = enc.encode_clips(clips)
+        bits, recs = enc.encode_clips(clips, staggered=staggered)
         return bits, [b''.join(r.tobytes() for r in rs if r is not None) for rs in recs]
 
 
@@ -67,5 +67,17 @@ def test_64_streams_1080p_each_equals_its_reference_chunk():
     names = ['1080p_stream%02d_n2_q32' % s for s in range(64)]
     c0 = BIG[names[0]]
     bits, rec = _encode(c0, [_frames(BIG[n]) for n in names])
+    bad = [n for i, n in enumerate(names) if md5(bits[i]) != BIG[n]['bit_md5'] or md5(rec[i]) != BIG[n]['rec_md5']]
+    assert not bad, f'{len(bad)} of 64 streams differ from their reference chunk: {bad[:4]}'
+
+
+def test_64_streams_1080p_six_frames_staggered_groups_equal_their_reference_chunks():
+    """thor_hip_encode_staged_run - what bench.py times since round 5: the 64 streams in two groups half a frame apart, every launch of the persistent
+    kernel covering the second half of one group's frame and the first half of the other's (ranges of anti-diagonals of the 15 x 9 superblock
+    grid, tk_sched.h); I + 5 P per stream, each stream hashed against its own reference run."""
+    names = ['1080p_stream%02d_n6_q32' % s for s in range(64)]
+    if names[0] not in BIG:
+        pytest.skip('6-frame chunk goldens not generated')
+    bits, rec = _encode(BIG[names[0]], [_frames(BIG[n]) for n in names], staggered=True)
     bad = [n for i, n in enumerate(names) if md5(bits[i]) != BIG[n]['bit_md5'] or md5(rec[i]) != BIG[n]['rec_md5']]
     assert not bad, f'{len(bad)} of 64 streams differ from their reference chunk: {bad[:4]}'

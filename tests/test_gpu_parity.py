@@ -12,14 +12,14 @@ pytestmark = pytest.mark.gpu
 G = golden_streams()
 
 
-def encode_gpu(clip, w, h, n, qp, streams=1, skip=0, cfg=None, **over):
+def encode_gpu(clip, w, h, n, qp, streams=1, skip=0, cfg=None, staggered=False, **over):
     import thor_amd
     p = thor_amd.load_config(os.path.join(ROOT, 'configs', cfg) if cfg else CFG, width=w, height=h, qp=qp, f=30, **over)
     fsz = w * h * 3 // 2 * (2 if int(over.get('bitdepth', 8)) > 8 else 1)
     a = np.frombuffer(clip, dtype=np.uint8)
     with thor_amd.Encoder(p, streams) as enc:
         clips = [[a[(skip + s * n + f) * fsz:(skip + s * n + f + 1) * fsz] for f in range(n)] for s in range(streams)]
-        bits, recs = enc.encode_clips(clips, skips=[skip + s * n for s in range(streams)], file_frames=len(a) // fsz)
+        bits, recs = enc.encode_clips(clips, skips=[skip + s * n for s in range(streams)], file_frames=len(a) // fsz, staggered=staggered)
         return bits, [b''.join(r.tobytes() for r in rs if r is not None) for rs in recs]
 
 
@@ -47,6 +47,20 @@ def test_two_streams_equal_two_reference_chunks():
     bits, rec = encode_gpu(clip, 192, 128, 3, 32, streams=2)
     assert md5(bits[0]) == G['192x128_n3_q32']['bit_md5'] and md5(rec[0]) == G['192x128_n3_q32']['rec_md5']
     assert md5(bits[1]) == G['192x128_n3_q32_skip3']['bit_md5'] and md5(rec[1]) == G['192x128_n3_q32_skip3']['rec_md5']
+
+
+def test_staggered_stream_groups_equal_reference_chunks():
+    """thor_hip_encode_staged_run (two stream groups half a frame apart; launches over ranges of anti-diagonals of the superblock grid): stream s of a
+    2-stream LDB run == the reference run on its chunk, and the three 3-frame chunks of a 9-frame RA clip (B frames, interpolated references
+    prepared per group; groups of 1 and 2 streams) == the frames a lock-step run of the same encoder produces."""
+    clip = golden_clip('clip_192x128_6.yuv.gz')
+    bits, rec = encode_gpu(clip, 192, 128, 3, 32, streams=2, staggered=True)
+    assert md5(bits[0]) == G['192x128_n3_q32']['bit_md5'] and md5(rec[0]) == G['192x128_n3_q32']['rec_md5']
+    assert md5(bits[1]) == G['192x128_n3_q32_skip3']['bit_md5'] and md5(rec[1]) == G['192x128_n3_q32_skip3']['rec_md5']
+    ra = golden_clip('clip_128x96_9.yuv.gz')
+    a = encode_gpu(ra, 128, 96, 3, 32, streams=3, cfg='ra_high_efficiency.cfg')
+    b = encode_gpu(ra, 128, 96, 3, 32, streams=3, cfg='ra_high_efficiency.cfg', staggered=True)
+    assert a == b
 
 
 @pytest.mark.skipif(not os.path.exists(REF_ENC), reason='oracle/_ref/Thorenc not in the snapshot')

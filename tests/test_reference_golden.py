@@ -130,3 +130,28 @@ def test_host_simulation_two_random_access_streams_equal_reference_chunks():
                            check=True, stdout=subprocess.DEVNULL)
             assert open(os.path.join(d, 'r.bit'), 'rb').read() == open(os.path.join(d, f'm.bit.{s}'), 'rb').read(), s
             assert open(os.path.join(d, 'r.yuv'), 'rb').read() == open(os.path.join(d, f'm.yuv.{s}'), 'rb').read(), s
+
+
+@needs_ref
+@pytest.mark.parametrize('cfg_name,w,h,n,streams', [('ldb_high_efficiency.cfg', 416, 240, 4, 3), ('ra_high_efficiency.cfg', 128, 96, 9, 2)])
+def test_host_simulation_staggered_stream_groups_equal_reference_chunks(cfg_name, w, h, n, streams):
+    """Engine::encode_run - the streams in two groups half a frame apart, every launch of the superblock scheduler covering the second half of
+    one group's frame (a range of anti-diagonals of the superblock grid) and the first half of the other's - against the reference run on each
+    chunk with -skip/-n: 416x240 LDB (4 x 2 superblocks: five anti-diagonals, three streams = groups of 1 and 2) with 1-lane teams and with
+    4-wave workgroups, and an RA chunk pair (B frames, interpolated references prepared per group)."""
+    import subprocess, tempfile
+    from util import ROOT
+    clip = golden_clip('gen:%d,%d,%d,6,2.5' % (w, h, n * streams))
+    cfg = os.path.join(ROOT, 'configs', cfg_name)
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, 'in.yuv'), 'wb').write(clip)
+        base = ['-cf', cfg, '-if', os.path.join(d, 'in.yuv'), '-width', str(w), '-height', str(h), '-qp', '32', '-f', '30', '-n', str(n)]
+        for s in range(streams):
+            subprocess.run([REF_ENC] + base + ['-skip', str(n * s), '-of', os.path.join(d, f'r.bit.{s}'), '-rf', os.path.join(d, f'r.yuv.{s}')],
+                           check=True, stdout=subprocess.DEVNULL)
+        for sim in ((build_hostsim(), build_hostsim(waves=4)) if 'ldb' in cfg_name else (build_hostsim(),)):
+            subprocess.run([sim] + base + ['-streams', str(streams), '-of', os.path.join(d, 'm.bit'), '-rf', os.path.join(d, 'm.yuv')],
+                           check=True, stdout=subprocess.DEVNULL, env=dict(os.environ, THOR_STAGGER='1'))
+            for s in range(streams):
+                assert open(os.path.join(d, f'r.bit.{s}'), 'rb').read() == open(os.path.join(d, f'm.bit.{s}'), 'rb').read(), (sim, s)
+                assert open(os.path.join(d, f'r.yuv.{s}'), 'rb').read() == open(os.path.join(d, f'm.yuv.{s}'), 'rb').read(), (sim, s)

@@ -25,3 +25,13 @@ def test_every_task_once_after_its_dependencies(S, rows, cols, workers):
     for seed in (1, 2, 3):
         r = subprocess.run([_build(), str(S), str(rows), str(cols), str(workers), str(seed)], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.parametrize('S,rows,cols,workers', [(2, 1, 1, 2), (4, 1, 7, 4), (4, 9, 1, 3), (6, 9, 15, 5), (16, 17, 30, 12), (3, 17, 30, 24), (8, 9, 15, 16)])
+def test_staggered_half_frames_every_task_once_after_its_dependencies(S, rows, cols, workers):
+    """The launches of Engine::encode_run (tk_encoder.h) for one frame of two stream groups half a frame apart: {group 0: first half},
+    {group 0: second half, group 1: first half}, {group 1: second half} - ranges of anti-diagonals; dependencies that finished in an earlier
+    launch are not counted, successors beyond the range are left to the next launch."""
+    for seed in (1, 2):
+        r = subprocess.run([_build(), str(S), str(rows), str(cols), str(workers), str(seed), '1'], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr

@@ -47,6 +47,9 @@ class ThorParams(C.Structure):
                 ('mqpB2', C.c_float), ('mqpB3', C.c_float), ('max_clpf_strength', C.c_int)]
 
 
+FRAMES_DONE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int)   # thor_hip_frames_done_fn
+
+
 def lib():
     """Load the HIP library; raises if it has not been built (no fallback)."""
     global _LIB
@@ -64,6 +67,8 @@ def lib():
         L.thor_hip_stage_frame_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.thor_hip_encode_staged.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.thor_hip_encode_frame.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.thor_hip_encode_staged_run.argtypes = [C.c_void_p, C.c_int, FRAMES_DONE_FN, C.c_void_p]
+        L.thor_hip_last_display_index.argtypes = [C.c_void_p, C.c_int]
         L.thor_hip_stream_bytes.restype = C.c_size_t
         L.thor_hip_stream_bytes.argtypes = [C.c_void_p, C.c_int]
         L.thor_hip_stream_data.restype = C.c_void_p
@@ -134,9 +139,31 @@ class Encoder:
         d = C.c_int()
         return d.value if lib().thor_hip_next_frame(self.h, stream, C.byref(d)) else None
 
-    def encode_clips(self, clips, want_recon=True, skips=None, file_frames=None):
-        """Encode clips[s] (equal-length lists of frames in display order) as closed streams in lock step,
-        following the coding-order schedule.  Stream s stands for frames [skips[s], skips[s]+n) of an input
+    def encode_run(self, nframes, on_done=None):
+        """thor_hip_encode_staged_run: the next nframes frames of every stream (inputs staged at their display index), the streams in two
+        groups half a frame apart.  on_done(first_stream, num_streams) is called when the frames of those streams are complete (recon(s) and
+        last_display_index(s) describe that frame inside the callback)."""
+        err = []
+
+        def _cb(_user, first, count):
+            if on_done is not None and not err:
+                try:
+                    on_done(first, count)
+                except BaseException as e:   # an exception must not unwind through the C frames
+                    err.append(e)
+        cb = FRAMES_DONE_FN(_cb)
+        rc = lib().thor_hip_encode_staged_run(self.h, nframes, cb, None)
+        if err:
+            raise err[0]
+        if rc:
+            raise RuntimeError(f'thor_hip_encode_staged_run rc={rc}')
+
+    def last_display_index(self, stream):
+        return lib().thor_hip_last_display_index(self.h, stream)
+
+    def encode_clips(self, clips, want_recon=True, skips=None, file_frames=None, staggered=False):
+        """Encode clips[s] (equal-length lists of frames in display order) as closed streams in lock step - or, staggered=True, in two groups
+        half a frame apart (encode_run) - following the coding-order schedule.  Stream s stands for frames [skips[s], skips[s]+n) of an input
         file holding file_frames frames (defaults: 0 and n).  Returns (bitstreams, recon[s][display index])."""
         n = len(clips[0])
         for s in range(self.S):
@@ -145,6 +172,13 @@ class Encoder:
             sk = skips[s] if skips else 0
             self.begin_sequence(s, sk, n, file_frames if file_frames else sk + n)
         recs = [[None] * n for _ in range(self.S)]
+        if staggered:
+            def done(first, count):
+                if want_recon:
+                    for s in range(first, first + count):
+                        recs[s][self.last_display_index(s)] = self.recon(s)
+            self.encode_run(n, done)
+            return [self.bitstream(s) for s in range(self.S)], recs
         while True:
             idx = [self.next_frame(s) for s in range(self.S)]
             if idx[0] is None:

@@ -53,7 +53,7 @@ template <typename PIX> __global__ __launch_bounds__(kWgThreads, (sizeof(PIX) ==
   __shared__ SmallWs<PIX> sws[kWaves];
   __shared__ unsigned s_task;
   JobR<PIX> J = *ldsc(&sJ);
-  const unsigned total = (unsigned)A.S * (unsigned)A.nsb;
+  const unsigned total = A.total;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
 #ifdef THOR_PROF
   const Wg wg{wave, kWaves, sws[wave].prof};
@@ -110,7 +110,7 @@ template <typename PIX> __global__ __launch_bounds__(kWgThreads, (sizeof(PIX) ==
     __syncthreads();
     if (threadIdx.x == 0) {
       if (A.times) A.times[3 * (size_t)task + 2] = wall_clock64();
-      df_finish(A, (unsigned)sidx * (unsigned)A.nsb, k, l);
+      df_finish(A, sidx, k, l);
     }
   }
 }
@@ -349,6 +349,7 @@ struct DfState {  // per engine (keyed by its device job array)
   unsigned* cnt = nullptr;
   uint8_t* pool = nullptr;
   unsigned long long* times = nullptr;
+  unsigned* range = nullptr;
   int S = 0, nsb = 0, wgs = 0;
   size_t slot = 0;
   int frame = 0;
@@ -356,12 +357,12 @@ struct DfState {  // per engine (keyed by its device job array)
 static std::map<const void*, DfState> g_df;
 static void df_free(DfState& D) {
   if (!D.ctl) return;
-  HIPCHECK(hipFree(D.ctl)); HIPCHECK(hipFree(D.queue)); HIPCHECK(hipFree(D.cnt)); HIPCHECK(hipFree(D.pool));
+  HIPCHECK(hipFree(D.ctl)); HIPCHECK(hipFree(D.queue)); HIPCHECK(hipFree(D.cnt)); HIPCHECK(hipFree(D.pool)); HIPCHECK(hipFree(D.range));
   if (D.times) HIPCHECK(hipFree(D.times));
 }
-template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S) {
+template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S, const SbRange* ranges) {
   const int cols = hjobs[0].sb_cols, rows = hjobs[0].sb_rows, nsb = cols * rows;
-  const size_t total = (size_t)S * nsb;
+  const size_t all = (size_t)S * nsb;
   DfState& D = g_df[jobs];
   const size_t slot = (sizeof(BigWs<PIX>) + 255) & ~(size_t)255;
   if (D.S != S || D.nsb != nsb || D.slot != slot) {
@@ -376,27 +377,44 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
     HIPCHECK(hipGetDeviceProperties(&prop, dev));
     long cap = (long)(per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
     if (const char* e = getenv("THOR_HIP_WGS")) cap = atol(e);
-    D.wgs = (int)(cap < (long)total ? cap : (long)total);
+    D.wgs = (int)(cap < (long)all ? cap : (long)all);
     HIPCHECK(hipMalloc(&D.ctl, sizeof(DfCtl)));
-    HIPCHECK(hipMalloc(&D.queue, sizeof(unsigned) * total));
-    HIPCHECK(hipMalloc(&D.cnt, sizeof(unsigned) * total));
+    HIPCHECK(hipMalloc(&D.queue, sizeof(unsigned) * all));
+    HIPCHECK(hipMalloc(&D.cnt, sizeof(unsigned) * all));
+    HIPCHECK(hipMalloc(&D.range, sizeof(unsigned) * S));
     HIPCHECK(hipMalloc(&D.pool, slot * (size_t)D.wgs * kWaves));  // one BigWs slot per wavefront
-    if (getenv("THOR_SBTIMES")) { HIPCHECK(hipMalloc(&D.times, sizeof(unsigned long long) * 3 * total)); }
+    if (getenv("THOR_SBTIMES")) { HIPCHECK(hipMalloc(&D.times, sizeof(unsigned long long) * 3 * all)); }
   }
-  // frame start: only SB(0,0) of every stream is ready
+  // launch start: the superblocks of every stream's range whose dependencies all lie below the range (whole frames: SB(0,0))
+  size_t total = 0;
   {
-    std::vector<unsigned> q0(S);
-    for (int s2 = 0; s2 < S; s2++) q0[s2] = (unsigned)s2 * (unsigned)nsb;
-    DfCtl hc0 = {0u, (unsigned)S, 0u, 0u};
+    std::vector<unsigned> q0, hr(S);
+    for (int s2 = 0; s2 < S; s2++) {
+      const int lo = ranges ? ranges[s2].lo : 0, hi = ranges ? ranges[s2].hi : 0x7fff;
+      hr[s2] = (unsigned)lo | ((unsigned)hi << 16);
+      if (lo >= hi) continue;
+      for (int k = 0; k < rows; k++)
+        for (int l = 0; l < cols; l++) {
+          const int t = df_diag(k, l);
+          if (t < lo || t >= hi) continue;
+          total++;
+          if (df_need(k, l, cols, lo) == 0) q0.push_back((unsigned)s2 * (unsigned)nsb + (unsigned)(k * cols + l));
+        }
+    }
+    if (!total) return;
+    DfCtl hc0 = {0u, (unsigned)q0.size(), 0u, 0u};
     HIPCHECK(hipMemsetAsync(D.queue, 0xff, sizeof(unsigned) * total, g_stream));
-    HIPCHECK(hipMemsetAsync(D.cnt, 0, sizeof(unsigned) * total, g_stream));
-    HIPCHECK(hipMemcpyAsync(D.queue, q0.data(), sizeof(unsigned) * S, hipMemcpyHostToDevice, g_stream));
+    HIPCHECK(hipMemsetAsync(D.cnt, 0, sizeof(unsigned) * all, g_stream));
+    if (D.times) HIPCHECK(hipMemsetAsync(D.times, 0, sizeof(unsigned long long) * 3 * all, g_stream));
+    HIPCHECK(hipMemcpyAsync(D.queue, q0.data(), sizeof(unsigned) * q0.size(), hipMemcpyHostToDevice, g_stream));
+    HIPCHECK(hipMemcpyAsync(D.range, hr.data(), sizeof(unsigned) * S, hipMemcpyHostToDevice, g_stream));
     HIPCHECK(hipMemcpyAsync(D.ctl, &hc0, sizeof(hc0), hipMemcpyHostToDevice, g_stream));
     HIPCHECK(hipStreamSynchronize(g_stream));
   }
   DfArgs A;
   A.ctl = D.ctl; A.queue = D.queue; A.cnt = D.cnt; A.pool = D.pool; A.slot_bytes = slot; A.times = D.times;
   A.S = S; A.nsb = nsb; A.cols = cols; A.rows = rows;
+  A.range = ranges ? D.range : nullptr; A.total = (unsigned)total;
   double lim_s = 300.0;
   if (const char* e = getenv("THOR_HIP_SPIN_TIMEOUT_S")) lim_s = atof(e);
   A.spin_limit = (unsigned long long)(lim_s * 1e8);
@@ -421,7 +439,7 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
     abort();
   }
   if (D.times) {
-    std::vector<unsigned long long> h(3 * total);
+    std::vector<unsigned long long> h(3 * all);   // superblocks outside this launch's ranges: zeros
     HIPCHECK(hipMemcpy(h.data(), D.times, h.size() * 8, hipMemcpyDeviceToHost));
     FILE* f = fopen(getenv("THOR_SBTIMES"), D.frame == 0 ? "wb" : "ab");
     if (f) { int hdr[4] = {D.frame, S, nsb, cols}; fwrite(hdr, 4, 4, f); fwrite(h.data(), 8, h.size(), f); fclose(f); }
@@ -525,11 +543,11 @@ void run_gather(const GatherItem* d_items, int n, uint32_t* dst) {
   hipLaunchKernelGGL(k_gather_bits, dim3(n), dim3(64), 0, g_stream, d_items, n, dst);
   HIPCHECK(hipGetLastError());
 }
-template void run_superblocks<uint8_t>(const FrameJob<uint8_t>*, const FrameJob<uint8_t>*, int);
+template void run_superblocks<uint8_t>(const FrameJob<uint8_t>*, const FrameJob<uint8_t>*, int, const SbRange*);
 template void run_deblock<uint8_t>(const FrameJob<uint8_t>*, const FrameJob<uint8_t>*, int);
 template void run_make_ref<uint8_t>(const FrameJob<uint8_t>*, const Plane3<uint8_t>*, int);
 template void run_cdef<uint8_t>(const CdefJob<uint8_t>*, const CdefJob<uint8_t>*, int);
-template void run_superblocks<uint16_t>(const FrameJob<uint16_t>*, const FrameJob<uint16_t>*, int);
+template void run_superblocks<uint16_t>(const FrameJob<uint16_t>*, const FrameJob<uint16_t>*, int, const SbRange*);
 template void run_clpf_stats<uint8_t>(const ClpfJob<uint8_t>*, const ClpfJob<uint8_t>*, int);
 template void run_clpf_stats<uint16_t>(const ClpfJob<uint16_t>*, const ClpfJob<uint16_t>*, int);
 template void run_clpf_apply<uint8_t>(const ClpfJob<uint8_t>*, const ClpfJob<uint8_t>*, int);
@@ -756,6 +774,37 @@ int thor_hip_encode_staged(thor_hip_encoder* e, const int* slots) {
     }
   });
   return rc;
+}
+
+int thor_hip_encode_staged_run(thor_hip_encoder* e, int nframes, thor_hip_frames_done_fn done, void* user) {
+  if (!e || nframes < 0) return 1;
+  int rc = 0;
+  ENC_DISPATCH(e, {
+    std::vector<DevFrame<PIXT>> keep(e->S);
+    for (int s = 0; s < e->S; s++) keep[s] = E.eng.st[s].orig;
+    E.eng.encode_run(nframes,
+        [&](int s) -> bool {
+          if (!E.pending[s] && !E.eng.schedule(s)) { rc = 2; return false; }
+          E.pending[s] = 0;
+          const int slot = E.eng.st[s].cur.frame_num;
+          if (slot < 0 || slot >= (int)E.staged[s].size() || !E.staged[s][slot].base_y) {
+            fprintf(stderr, "thor_hip: stream %d: frame %d is not staged\n", s, slot);
+            rc = 3;
+            return false;
+          }
+          E.eng.st[s].orig = E.staged[s][slot];
+          return true;
+        },
+        [&](int first, int count) { if (done) done(user, first, count); });
+    for (int s = 0; s < e->S; s++) E.eng.st[s].orig = keep[s];
+  });
+  return rc;
+}
+int thor_hip_last_display_index(const thor_hip_encoder* e, int stream) {
+  if (!e || stream < 0 || stream >= e->S) return -1;
+  const int n = e->hbd ? e->e16->eng.st[stream].num_encoded : e->e8->eng.st[stream].num_encoded;
+  if (n < 1) return -1;
+  return e->hbd ? e->e16->eng.st[stream].cur.frame_num : e->e8->eng.st[stream].cur.frame_num;
 }
 
 int thor_hip_encode_frame(thor_hip_encoder* e, const void* const* yuv) {

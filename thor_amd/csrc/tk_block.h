@@ -414,7 +414,9 @@ template <int SP, typename PIX>
 TK_DEV typename SsdT<PIX>::type ssd_part(const Team t, const PIX* a_, int as, const PIX* b_, int bs, int w, int h) {
   a_ = tk_uniform_ptr(a_); b_ = tk_uniform_ptr(b_); as = tk_uniform(as); bs = tk_uniform(bs); w = tk_uniform(w); h = tk_uniform(h);
 #ifndef TK_NOVEC
-  {
+  // (host simulation with teams smaller than a wavefront: a lane's share of a large block of 16-bit samples can exceed the 256 samples for
+  // which the modular 32-bit sums of ssd_rows are exact - such blocks take the 64-bit sample loop below)
+  if (!(TK_HOST && sizeof(PIX) == 2 && (w * h) / t.size > 256)) {
     const int S = (int)sizeof(PIX);
     const unsigned al = (unsigned)(uintptr_t)a_ | (unsigned)(uintptr_t)b_ | (unsigned)(as * S) | (unsigned)(bs * S) | (unsigned)(w * S);
     if (!(al & 15u)) return ssd_rows<SP, PIX, 4>(t, a_, as, b_, bs, w, h);
@@ -1631,7 +1633,8 @@ TK_DEVNI void md_worker_sp(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws) 
 #if defined(THOR_PROF_MD) && defined(THOR_PROF) && !TK_HOST
   if (TK_PROFMD_ON(8) && t.rank == 0) for (int q_ = 0; q_ < 4; q_++) ws->prof[16 + q_] += pmd_acc_[q_];
 #endif
-  if (sh->do_bipred == 2) {  // uniform over the workgroup: every wave takes part (same number of barriers)
+  if (tk_uniform(sh->do_bipred) == 2) {  // uniform over the workgroup: every wave takes part (same number of barriers); a scalar branch - no
+                                         // workgroup barrier behind an exec-masked one (scripts/check_barrier_hazard.py)
     t.sync();
     TK_PROF_MARK(pb_);
     wg.barrier();            // every reference search has finished: mv_center[] and the candidate lists are final

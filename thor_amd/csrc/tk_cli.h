@@ -152,6 +152,23 @@ template <typename PIX> int cli_run(const CliArgs& a) {
   const int file_frames = (int)(ftell(fi) / (long)(fsz * sizeof(PIX)));
   for (int s = 0; s < a.streams; s++) eng.begin_sequence(s, a.skip + s * a.num_frames, a.num_frames, file_frames);
   std::vector<std::vector<PIX>> recs((size_t)a.streams * a.num_frames);  // recon in display order
+  // THOR_STAGGER=1 (tests): the streams in two groups half a frame apart (Engine::encode_run) instead of lock step
+  if (getenv("THOR_STAGGER") && atoi(getenv("THOR_STAGGER")) && a.streams > 1) {
+    int rc = 0;
+    eng.encode_run(a.num_frames,
+        [&](int s) -> bool {
+          if (!eng.schedule(s)) return false;
+          const size_t idx = (size_t)eng.st[s].cur_abs;
+          if (fseek(fi, (long)(idx * fsz * sizeof(PIX)), SEEK_SET) || fread(frame.data(), sizeof(PIX), fsz, fi) != fsz) { fprintf(stderr, "short read at frame %zu\n", idx); rc = 3; return false; }
+          eng.upload_orig(s, frame.data());
+          return true;
+        },
+        [&](int first, int count) {
+          for (int s = first; s < first + count; s++)
+            if (fr[s]) { eng.download_rec(s, rec.data()); recs[(size_t)s * a.num_frames + eng.st[s].cur.frame_num] = rec; }
+        });
+    if (rc) return rc;
+  } else
   for (;;) {
     std::vector<FrameParams> fp(a.streams);
     int active = 0;

@@ -202,7 +202,19 @@ TK_DEV void wg_pause() {
 #include <time.h>
 namespace tk {
 #endif
+// Limit of a wait on another wave of the workgroup, in 100 MHz ticks: 8 s on the device (a search item takes milliseconds).  The host
+// simulation runs waves as OS threads - a sanitizer build or an oversubscribed machine can need far longer for one item without any protocol
+// error - so its limit is 120 s, or THOR_HOSTSIM_WAIT_S seconds.
+#if TK_HOST
+static inline unsigned long long wg_wait_limit() {
+  static unsigned long long lim = 0;
+  if (!lim) { const char* e = getenv("THOR_HOSTSIM_WAIT_S"); lim = (unsigned long long)((e && atof(e) > 0 ? atof(e) : 120.0) * 1e8); }
+  return lim;
+}
+#define kWgWaitLimit wg_wait_limit()
+#else
 enum { kWgWaitLimit = 800000000 };   // 8 s
+#endif
 TK_DEV unsigned long long wg_clock() {
 #if TK_HOST
   struct timespec ts;

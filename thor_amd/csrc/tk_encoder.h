@@ -30,8 +30,10 @@ void d2h(void* h, const void* d, size_t n);
 void dev_memset(void* d, int v, size_t n);
 void dev_sync();
 size_t team_ws_bytes(int pix_bytes);
-// jobs: device array of S FrameJob; hjobs: the same on the host.
-template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S);
+// jobs: device array of S FrameJob; hjobs: the same on the host.  ranges (host array of S, or nullptr = whole frames): the anti-diagonals
+// t = l + 2k of the superblock grid, [lo, hi), that this launch codes of every stream (tk_sched.h; lo == hi: nothing).
+struct SbRange { unsigned short lo, hi; };
+template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S, const SbRange* ranges);
 template <typename PIX> void run_clpf_stats(const ClpfJob<PIX>* jobs, const ClpfJob<PIX>* hjobs, int S);
 template <typename PIX> void run_clpf_apply(const ClpfJob<PIX>* jobs, const ClpfJob<PIX>* hjobs, int S);  // copies rec -> src first
 template <typename PIX> void run_deblock(const FrameJob<PIX>* jobs, const FrameJob<PIX>* hjobs, int S);
@@ -544,9 +546,9 @@ template <typename PIX> class Engine {
 
   // Temporally interpolated reference (enc/mainenc.c:350-355, common/temporal_interp.c:909): built on the device from
   // the two window frames of every stream whose frame uses it (tk_interp_dev.h) - no frame leaves HBM.
-  void make_interp_frames(const std::vector<FrameParams>& fp) {
+  void make_interp_frames(const std::vector<FrameParams>& fp, int first, int count) {
     int n = 0;
-    for (int s = 0; s < S; s++) {
+    for (int s = first; s < first + count; s++) {
       if (!fp[s].interp_ref) continue;
       Stream<PIX>& q = st[s];
       const FrameParams& f = fp[s];
@@ -588,8 +590,67 @@ template <typename PIX> class Engine {
 
   // Encode one frame per stream (origs already uploaded). Appends to st[s].out.
   void encode_frames(const std::vector<FrameParams>& fp) {
-    if (!external_interp) make_interp_frames(fp);
-    for (int s = 0; s < S; s++) {
+    prepare_jobs(fp, 0, S);
+    backend::run_superblocks<PIX>(d_jobs, h_jobs.data(), S, nullptr);
+    finish_frames(fp, 0, S);
+  }
+
+  // Anti-diagonals of the superblock grid (t = l + 2k): their number, and where a frame is cut in two for encode_run.
+  int num_diags() const { return (sb_cols - 1) + 2 * (sb_rows - 1) + 1; }
+
+  // Code the next `nframes` frames of every stream, the streams in TWO GROUPS HALF A FRAME APART (the first half of the streams leads):
+  // one launch of the persistent superblock kernel carries the second half (anti-diagonals [Th, T)) of one group's frame - the narrowing end
+  // of its dependency wavefront - together with the first half of the other group's frame, its widening start, so the workgroup slots one
+  // group leaves idle are taken by the other (in lock step every stream ramps up and down at the same time: 13 % of the workgroup-time idle
+  // at 3840x2160 x 128 streams, profiles/r04_sbtimes_4k_s128_final.log).  The run starts and ends on frame boundaries for every stream: the
+  // first launch holds only the leading group's first half, the last one only the trailing group's second half.  Every superblock still
+  // starts after its two dependencies and sees the same reference frames: results do not depend on the schedule.
+  //   next(s): make stream s ready for its next frame - schedule() it and point st[s].orig at its input; false: no frame left (an error here)
+  //   done(first, count): the frames of streams [first, first + count) are complete (bits appended, st[s].rec = the reconstruction,
+  //                       st[s].cur = the frame) - called before any later launch touches those streams again
+  template <class NextF, class DoneF> void encode_run(int nframes, NextF next, DoneF done) {
+    std::vector<FrameParams> fp(S);
+    auto prep = [&](int first, int count) {
+      for (int s = first; s < first + count; s++) {
+        if (!next(s)) { fprintf(stderr, "thor_hip: stream %d has no frame left to code\n", s); abort(); }
+        fp[s] = st[s].cur;
+      }
+      prepare_jobs(fp, first, count);
+    };
+    if (S < 2 || num_diags() < 2) {   // nothing to stagger: frame by frame
+      for (int f = 0; f < nframes; f++) {
+        prep(0, S);
+        backend::run_superblocks<PIX>(d_jobs, h_jobs.data(), S, nullptr);
+        finish_frames(fp, 0, S);
+        done(0, S);
+      }
+      return;
+    }
+    const int T = num_diags(), Th = (T + 1) / 2, S0 = S / 2, S1 = S - S0;
+    std::vector<backend::SbRange> rg(S);
+    auto set = [&](int first, int count, int lo, int hi) { for (int s = first; s < first + count; s++) { rg[s].lo = (unsigned short)lo; rg[s].hi = (unsigned short)hi; } };
+    if (nframes < 1) return;
+    prep(0, S0);
+    set(0, S0, 0, Th); set(S0, S1, 0, 0);
+    backend::run_superblocks<PIX>(d_jobs, h_jobs.data(), S, rg.data());
+    for (int f = 0; f < nframes; f++) {
+      prep(S0, S1);
+      set(0, S0, Th, T); set(S0, S1, 0, Th);
+      backend::run_superblocks<PIX>(d_jobs, h_jobs.data(), S, rg.data());
+      finish_frames(fp, 0, S0);
+      done(0, S0);
+      if (f + 1 < nframes) { prep(0, S0); set(0, S0, 0, Th); } else set(0, S0, 0, 0);
+      set(S0, S1, Th, T);
+      backend::run_superblocks<PIX>(d_jobs, h_jobs.data(), S, rg.data());
+      finish_frames(fp, S0, S1);
+      done(S0, S1);
+    }
+  }
+
+  // Frame jobs of streams [first, first + count) for the frames fp[s] (origs in place): interpolated references, FrameJob set-up, upload.
+  void prepare_jobs(const std::vector<FrameParams>& fp, int first, int count) {
+    if (!external_interp) make_interp_frames(fp, first, count);
+    for (int s = first; s < first + count; s++) {
       Stream<PIX>& q = st[s];
       const FrameParams& f = fp[s];
       FrameJob<PIX>& J = h_jobs[s];
@@ -619,12 +680,16 @@ template <typename PIX> class Engine {
       J.stats = d_stats;
       if (f.frame_type == F_I) backend::dev_memset(q.cells, 0, (size_t)(sp.width / 4) * (sp.height / 4) * sizeof(DbCell));
     }
-    backend::h2d(d_jobs, h_jobs.data(), sizeof(FrameJob<PIX>) * S);
-    backend::run_superblocks<PIX>(d_jobs, h_jobs.data(), S);
-    if (sp.deblocking) backend::run_deblock<PIX>(d_jobs, h_jobs.data(), S);
+    backend::h2d(d_jobs + first, h_jobs.data() + first, sizeof(FrameJob<PIX>) * count);
+  }
+
+  // Everything after the superblocks of streams [first, first + count): in-loop filters, reference creation, bitstream assembly.
+  void finish_frames(const std::vector<FrameParams>& fp, int first, int count) {
+    const int end = first + count;
+    if (sp.deblocking) backend::run_deblock<PIX>(d_jobs + first, h_jobs.data() + first, count);
     // CDEF (encode_frame.c:685-689 frame-level guesses, :768-783 search + filter)
     if (sp.cdef) {
-      for (int s = 0; s < S; s++) {
+      for (int s = first; s < end; s++) {
         Stream<PIX>& q = st[s];
         CdefJob<PIX>& C = h_cjobs[s];
         C.rec = q.rec.p; C.src = q.tmp.p; C.org = q.orig.p;
@@ -637,14 +702,14 @@ template <typename PIX> class Engine {
         C.dir = q.cdef_dir; C.var = q.cdef_var; C.fb_compact = q.cdef_fbc; C.mse = q.cdef_mse; C.sel = q.cdef_sel;
         C.fb_sel = q.cdef_fbsel; C.res = q.cdef_res; C.tot = q.cdef_tot;
       }
-      backend::h2d(d_cjobs, h_cjobs.data(), sizeof(CdefJob<PIX>) * S);
-      backend::run_cdef<PIX>(d_cjobs, h_cjobs.data(), S);
+      backend::h2d(d_cjobs + first, h_cjobs.data() + first, sizeof(CdefJob<PIX>) * count);
+      backend::run_cdef<PIX>(d_cjobs + first, h_cjobs.data() + first, count);
     }
     // CLPF (encode_frame.c:785-817): statistics on the device, frame-level plan on the host, filter on the device
     std::vector<ClpfPlan> lplan(sp.clpf ? S : 0);
     if (sp.clpf) {
       bool any = false;
-      for (int s = 0; s < S; s++) {
+      for (int s = first; s < end; s++) {
         Stream<PIX>& q = st[s];
         ClpfJob<PIX>& L = h_ljobs[s];
         L.rec = q.rec.p; L.src = q.tmp.p; L.org = q.orig.p;
@@ -654,12 +719,12 @@ template <typename PIX> class Engine {
         any = any || fp[s].qp > 16;
       }
       if (any) {
-        backend::h2d(d_ljobs, h_ljobs.data(), sizeof(ClpfJob<PIX>) * S);
-        backend::run_clpf_stats<PIX>(d_ljobs, h_ljobs.data(), S);
+        backend::h2d(d_ljobs + first, h_ljobs.data() + first, sizeof(ClpfJob<PIX>) * count);
+        backend::run_clpf_stats<PIX>(d_ljobs + first, h_ljobs.data() + first, count);
         backend::dev_sync();
         std::vector<uint32_t> hst(clpf_stat_words());
         bool filt = false;
-        for (int s = 0; s < S; s++) {
+        for (int s = first; s < end; s++) {
           if (fp[s].qp > 16) backend::d2h(hst.data(), st[s].clpf_stats, hst.size() * 4);
           lplan[s] = clpf_plan(hst.data(), sp.width, sp.height, fp[s].qp, h_jobs[s].lambda, sp.max_clpf_strength);
           ClpfJob<PIX>& L = h_ljobs[s];
@@ -668,15 +733,15 @@ template <typename PIX> class Engine {
           if (!lplan[s].fb_on.empty()) backend::h2d(st[s].clpf_fb_on, lplan[s].fb_on.data(), lplan[s].fb_on.size());
         }
         if (filt) {
-          backend::h2d(d_ljobs, h_ljobs.data(), sizeof(ClpfJob<PIX>) * S);
-          backend::run_clpf_apply<PIX>(d_ljobs, h_ljobs.data(), S);
+          backend::h2d(d_ljobs + first, h_ljobs.data() + first, sizeof(ClpfJob<PIX>) * count);
+          backend::run_clpf_apply<PIX>(d_ljobs + first, h_ljobs.data() + first, count);
         }
       } else
-        for (int s = 0; s < S; s++) lplan[s] = clpf_plan(nullptr, sp.width, sp.height, fp[s].qp, h_jobs[s].lambda, sp.max_clpf_strength);
+        for (int s = first; s < end; s++) lplan[s] = clpf_plan(nullptr, sp.width, sp.height, fp[s].qp, h_jobs[s].lambda, sp.max_clpf_strength);
     }
     // sliding window: the slot shifted out becomes ref[0] (encode_frame.c:826-835)
     std::vector<Plane3<PIX>> dst(S);
-    for (int s = 0; s < S; s++) {
+    for (int s = first; s < end; s++) {
       Stream<PIX>& q = st[s];
       DevFrame<PIX> last = q.ring.back();
       for (int r = ring_size - 1; r > 0; r--) q.ring[r] = q.ring[r - 1];
@@ -684,18 +749,19 @@ template <typename PIX> class Engine {
       q.ring[0].frame_num = fp[s].frame_num;
       dst[s] = q.ring[0].p;
     }
-    backend::run_make_ref<PIX>(h_jobs.data(), dst.data(), S);
+    backend::run_make_ref<PIX>(h_jobs.data() + first, dst.data() + first, count);
     backend::dev_sync();
     // bitstream assembly: one D2H of all bit counts, a device-side bit-level gather of the per-SB
     // strings into one compact buffer, one D2H of that buffer.
+    // (arrays indexed by stream: only the entries of [first, end) are filled and used)
     std::vector<int> nb((size_t)S * nsb), stt((size_t)S * nsb);
-    backend::d2h(nb.data(), d_nbits_all, nb.size() * sizeof(int));
-    backend::d2h(stt.data(), d_status_all, stt.size() * sizeof(int));
+    backend::d2h(nb.data() + (size_t)first * nsb, d_nbits_all + (size_t)first * nsb, (size_t)count * nsb * sizeof(int));
+    backend::d2h(stt.data() + (size_t)first * nsb, d_status_all + (size_t)first * nsb, (size_t)count * nsb * sizeof(int));
     std::vector<backend::GatherItem> items((size_t)S * nsb);
     std::vector<long long> stream_off(S + 1, 0);
     {
       long long pos = 0;
-      for (int s = 0; s < S; s++) {
+      for (int s = first; s < end; s++) {
         stream_off[s] = pos;
         for (int i = 0; i < nsb; i++) {
           if (stt[(size_t)s * nsb + i]) { fprintf(stderr, "Run-time error...\nthor_hip: superblock %d bit buffer overflow\n...now exiting to system...\n", i); abort(); }
@@ -705,20 +771,20 @@ template <typename PIX> class Engine {
         }
         pos = (pos + 31) & ~31ll;  // streams start word aligned
       }
-      stream_off[S] = pos;
+      stream_off[end] = pos;
     }
-    const size_t need_words = (size_t)(stream_off[S] >> 5) + 2;
+    const size_t need_words = (size_t)(stream_off[end] >> 5) + 2;
     if (need_words > payload_words) {
       backend::dev_free(d_payload);
       payload_words = need_words + need_words / 2;
       d_payload = (uint32_t*)backend::dev_alloc(payload_words * 4);
     }
     backend::dev_memset(d_payload, 0, need_words * 4);
-    backend::h2d(d_items, items.data(), items.size() * sizeof(backend::GatherItem));
-    backend::run_gather(d_items, (int)items.size(), d_payload);
+    backend::h2d(d_items + (size_t)first * nsb, items.data() + (size_t)first * nsb, (size_t)count * nsb * sizeof(backend::GatherItem));
+    backend::run_gather(d_items + (size_t)first * nsb, count * nsb, d_payload);
     std::vector<uint32_t> words(need_words);
     backend::d2h(words.data(), d_payload, need_words * 4);
-    for (int s = 0; s < S; s++) {
+    for (int s = first; s < end; s++) {
       Stream<PIX>& q = st[s];
       const FrameParams& f = fp[s];
       HostBits& b = q.bits;

@@ -1065,8 +1065,9 @@ TK_DEVNI unsigned motion_estimate_bi(const Team t, MeWs* w_, const PIX* org_, co
       // frame-edge clamp of luma_setup interferes) predicts by copying: the SAD against the truncating average of the two displaced
       // blocks runs on the row-segment evaluator of the uni-directional search (16 bytes of each reference per lane and memory
       // instruction) instead of one sample per lane and step.
-      int all_int = 1;
-      for (int c = 0; c < n; c++) { const BI x = cand(c); all_int = all_int && !(x.s0.ver_frac | x.s0.hor_frac | x.s1.ver_frac | x.s1.hor_frac); }
+      // (the steps of 2 and 1 quarter-pels move off the integer grid: no need to build their candidates twice to find that out)
+      int all_int = step >= 4;
+      for (int c = 0; c < n && all_int; c++) { const BI x = cand(c); all_int = all_int && !(x.s0.ver_frac | x.s0.hor_frac | x.s1.ver_frac | x.s1.hor_frac); }
       unsigned long long k;
       if (TKU(all_int)) {
         struct FB { mv_t mv; const PIX* p; const PIX* p2; int dx, dy; };

@@ -16,6 +16,13 @@
 //
 // The functions below are written against a small set of atomics macros so that tests/hostsim/sched_stress.cpp can run the
 // very same protocol with OS threads (THOR_SCHED_HOSTTEST); the device build maps them to agent-scope HIP atomics.
+//
+// Partial frames (round 5): a launch may cover, per stream, only the superblocks of a range [lo, hi) of anti-diagonals t = l + 2k (both
+// dependencies of a superblock lie on smaller anti-diagonals, so every prefix of the order is closed under the dependencies).  The host
+// codes the streams in two groups half a frame apart (tk_encoder.h:encode_run): one launch carries the second half of one group's frame -
+// its narrowing end - and the first half of the other group's, so the ramp-up of one group fills the slots the ramp-down of the other
+// leaves idle.  A dependency below `lo` finished in an earlier launch and is not counted; a successor at or beyond `hi` is left to a
+// later launch, which starts with every superblock whose dependencies all lie below its `lo`.
 #pragma once
 #include <stdint.h>
 
@@ -65,7 +72,15 @@ struct DfArgs {
   unsigned long long* times;   // optional [S*nsb][3] pop/start/end wall clock (100 MHz)
   int S, nsb, cols, rows;
   unsigned long long spin_limit;  // wall-clock ticks a workgroup may wait
+  const unsigned* range;          // [S] anti-diagonals [lo, hi) of every stream in this launch, lo | hi << 16; nullptr: whole frames
+  unsigned total;                 // tasks of this launch
 };
+// anti-diagonal of SB(k,l) and of its two dependencies: left (k,l-1) and up-right (k-1,l+1) - (k-1,l) in the last column
+DF_HD int df_diag(int k, int l) { return l + 2 * k; }
+DF_HD int df_need(int k, int l, int cols, int lo) {
+  const int t = l + 2 * k;
+  return (l > 0 && t - 1 >= lo ? 1 : 0) + (k > 0 && (l == cols - 1 ? t - 2 : t - 1) >= lo ? 1 : 0);
+}
 static const unsigned kDfEmpty = 0xffffffffu;
 
 // Wait until `slot` holds a task id.  Polls with RELAXED agent-scope loads: an acquire load in the loop would issue a
@@ -90,20 +105,24 @@ DF_FN void df_push(const DfArgs& A, unsigned id) {
   DF_STORE_RELEASE(&A.queue[p], id);
 }
 
-// A dependency of SB(k,l) of the stream whose tasks start at `base` has finished.
-DF_FN void df_done_dep(const DfArgs& A, unsigned base, int k, int l) {
+// A dependency of SB(k,l) of the stream whose tasks start at `base` has finished (lo, hi: the stream's range in this launch).
+DF_FN void df_done_dep(const DfArgs& A, unsigned base, int k, int l, int lo, int hi) {
+  if (df_diag(k, l) >= hi) return;   // not part of this launch: a later one starts it
   const unsigned id = base + (unsigned)(k * A.cols + l);
-  const unsigned need = (l > 0 ? 1u : 0u) + (k > 0 ? 1u : 0u);
+  const unsigned need = (unsigned)df_need(k, l, A.cols, lo);
   const unsigned old = DF_ADD_ACQ_REL(&A.cnt[id], 1u);
   if (old + 1 == need) df_push(A, id);
 }
 
-// SB(k,l) of the stream whose tasks start at `base` has finished: release its successors.
-DF_FN void df_finish(const DfArgs& A, unsigned base, int k, int l) {
-  if (l + 1 < A.cols) df_done_dep(A, base, k, l + 1);               // right neighbour: its left dependency
+// SB(k,l) of stream `sidx` has finished: release its successors.
+DF_FN void df_finish(const DfArgs& A, int sidx, int k, int l) {
+  const unsigned base = (unsigned)sidx * (unsigned)A.nsb;
+  int lo = 0, hi = 0x7fff;
+  if (A.range) { const unsigned r = A.range[sidx]; lo = (int)(r & 0xffffu); hi = (int)(r >> 16); }
+  if (l + 1 < A.cols) df_done_dep(A, base, k, l + 1, lo, hi);               // right neighbour: its left dependency
   if (k + 1 < A.rows) {
-    if (l >= 1) df_done_dep(A, base, k + 1, l - 1);                 // down-left: its up-right dependency
-    if (l == A.cols - 1) df_done_dep(A, base, k + 1, l);            // last column: the SB below uses (k,l) as "up-right"
+    if (l >= 1) df_done_dep(A, base, k + 1, l - 1, lo, hi);                 // down-left: its up-right dependency
+    if (l == A.cols - 1) df_done_dep(A, base, k + 1, l, lo, hi);            // last column: the SB below uses (k,l) as "up-right"
   }
 }
 
