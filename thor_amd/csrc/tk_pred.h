@@ -8,20 +8,32 @@
 
 namespace tk {
 
-// luma taps, [bipred set][frac][6]  (common_kernels.c:1905-1917)
-TK_DEV int luma_tap(int bipred, int frac, int m) {
+// Filter taps as IMMEDIATES: a table indexed at run time is a constant-memory array - every luma_setup of the sub-pel search and of the
+// trial predictions paid a global-memory round trip for its twelve taps (round 5: 4 global_load + 12 readfirstlane per set-up).  Packed into one
+// 64-bit literal per fraction (tap m = int8 lane m) the look-up is three selects on the fraction.
+TK_DEV constexpr unsigned long long pack_taps6(int a, int b, int c, int d, int e, int f) {
+  return (unsigned long long)(unsigned)(a & 0xff) | ((unsigned long long)(unsigned)(b & 0xff) << 8) | ((unsigned long long)(unsigned)(c & 0xff) << 16) |
+         ((unsigned long long)(unsigned)(d & 0xff) << 24) | ((unsigned long long)(unsigned)(e & 0xff) << 32) | ((unsigned long long)(unsigned)(f & 0xff) << 40);
+}
+// luma taps, [bipred set][frac][6]  (common_kernels.c:1905-1917), tap m in bits [8m, 8m + 8) as int8
+TK_DEV unsigned long long luma_taps8(int bipred, int frac) {
   // standard: {0,0,64,0,0,0},{1,-7,55,19,-5,1},{1,-7,38,38,-7,1},{1,-5,19,55,-7,1}
   // bipred  : {0,0,64,0,0,0},{2,-10,59,17,-5,1},{1,-8,39,39,-8,1},{1,-5,17,59,-10,2}
-  const int8_t s[4][6] = {{0, 0, 64, 0, 0, 0}, {1, -7, 55, 19, -5, 1}, {1, -7, 38, 38, -7, 1}, {1, -5, 19, 55, -7, 1}};
-  const int8_t b[4][6] = {{0, 0, 64, 0, 0, 0}, {2, -10, 59, 17, -5, 1}, {1, -8, 39, 39, -8, 1}, {1, -5, 17, 59, -10, 2}};
-  return bipred ? b[frac][m] : s[frac][m];
+  const unsigned long long z = pack_taps6(0, 0, 64, 0, 0, 0);
+  const unsigned long long s1 = pack_taps6(1, -7, 55, 19, -5, 1), s2 = pack_taps6(1, -7, 38, 38, -7, 1), s3 = pack_taps6(1, -5, 19, 55, -7, 1);
+  const unsigned long long b1 = pack_taps6(2, -10, 59, 17, -5, 1), b2 = pack_taps6(1, -8, 39, 39, -8, 1), b3 = pack_taps6(1, -5, 17, 59, -10, 2);
+  const unsigned long long s = frac == 1 ? s1 : frac == 2 ? s2 : s3, b = frac == 1 ? b1 : frac == 2 ? b2 : b3;
+  return frac == 0 ? z : (bipred ? b : s);
 }
-// chroma taps [frac][4] (common_kernels.c:1919-1928)
-TK_DEV int chroma_tap(int frac, int m) {
-  const int8_t c[8][4] = {{0, 64, 0, 0},   {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-4, 44, 28, -4},
-                          {-4, 36, 36, -4}, {-4, 28, 44, -4}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
-  return c[frac][m];
+TK_DEV int luma_tap(int bipred, int frac, int m) { return (int)(int8_t)(luma_taps8(bipred, frac) >> (8 * m)); }
+// chroma taps [frac][4] (common_kernels.c:1919-1928), tap m in bits [8m, 8m + 8) as int8
+TK_DEV unsigned chroma_taps8(int frac) {
+  auto pk = [](int a, int b, int c, int d) -> unsigned { return (unsigned)(a & 0xff) | ((unsigned)(b & 0xff) << 8) | ((unsigned)(c & 0xff) << 16) | ((unsigned)(d & 0xff) << 24); };
+  const unsigned lo = frac == 0 ? pk(0, 64, 0, 0) : frac == 1 ? pk(-2, 58, 10, -2) : frac == 2 ? pk(-4, 54, 16, -2) : pk(-4, 44, 28, -4);
+  const unsigned hi = frac == 4 ? pk(-4, 36, 36, -4) : frac == 5 ? pk(-4, 28, 44, -4) : frac == 6 ? pk(-2, 16, 54, -4) : pk(-2, 10, 58, -2);
+  return frac < 4 ? lo : hi;
 }
+TK_DEV int chroma_tap(int frac, int m) { return (int)(int8_t)(chroma_taps8(frac) >> (8 * m)); }
 
 // clip_mv (inter_prediction.c:51-63)
 TK_DEV mv_t clip_mv(mv_t mv, int ypos, int xpos, int fwidth, int fheight, int bwidth, int bheight, int sign) {
@@ -40,6 +52,7 @@ TK_DEV mv_t clip_mv(mv_t mv, int ypos, int xpos, int fwidth, int fheight, int bw
 struct SubPel {
   int hor_int, ver_int, hor_frac, ver_frac;
   int th[6], tv[6];
+  unsigned long long ph, pv;   // the same taps packed (int8 lane m = tap m): what the 8-bit dot-product forms consume
 };
 TK_DEV SubPel luma_setup(mv_t mv, int sign, int width, int height, int pic_w, int pic_h, int xpos, int ypos, int bipred = 0) {
   int mx = sign ? -mv.x : mv.x, my = sign ? -mv.y : mv.y;
@@ -53,9 +66,11 @@ TK_DEV SubPel luma_setup(mv_t mv, int sign, int width, int height, int pic_w, in
   hi = tmax(hi, -xpos - width);
   s.ver_int = vi;
   s.hor_int = hi;
+  const unsigned long long ph = luma_taps8(bipred, s.hor_frac), pv = luma_taps8(bipred, s.ver_frac);
+  s.ph = ph; s.pv = pv;
   for (int m = 0; m < 6; m++) {
-    s.th[m] = luma_tap(bipred, s.hor_frac, m);
-    s.tv[m] = luma_tap(bipred, s.ver_frac, m);
+    s.th[m] = (int)(int8_t)(ph >> (8 * m));
+    s.tv[m] = (int)(int8_t)(pv >> (8 * m));
   }
   return s;
 }
@@ -200,10 +215,8 @@ struct SubK8 {
 };
 TK_DEV SubK8 subk8_make(const SubPel& s, int dy, int dx, int bipred) {
   SubK8 k;
-  unsigned long long th = 0;
-  for (int n = 0; n < 6; n++) th |= (unsigned long long)(unsigned)(s.th[n] & 0xff) << (8 * n);
-  k.th8 = th << (8 * dx);
-  for (int m = 0; m < 6; m++) k.tv[m] = s.tv[m];
+  k.th8 = s.ph << (8 * dx);
+  for (int m = 0; m < 6; m++) k.tv[m] = (int)(int8_t)(s.pv >> (8 * m));
   k.centre = s.ver_frac == 2 && s.hor_frac == 2 && bipred < 2;
   k.dy = dy; k.dx = dx;
   return k;
