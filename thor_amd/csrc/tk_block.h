@@ -60,6 +60,8 @@ struct WgShared {
   const void* bp_org8;           // 2*org - pred of the current step (leader's buffer)
   unsigned bp_sad[kMaxRefs];
   mv_t bp_mv[kMaxRefs][4];
+  unsigned bp_sad2[2][kMaxRefs];   // results of a lock-step search step, double-buffered (bipred_par)
+  mv_t bp_mv2[2][kMaxRefs][4];
   unsigned bp_min_sad;
   int bp_skip[4];                // per step: its inputs equal those of the previous step of the same list (see bipred_par)
   int bp_ref0, bp_ref1;
@@ -1499,69 +1501,89 @@ TK_DEVNI void bipred_par(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, Md
   const int num_iter = c.encoder_speed == 0 ? 2 : 1;
   const int max_tb = c.enable_tb_split == 1 ? 2 : 1;
   const mv_t mvp = lds_ld(&sh_->mvp);
+  // Round 5: NO leader phase.  Every wave keeps the state of the search (the two lists' best vectors / references, the running minimum) in its
+  // own registers - the reduction after a step reads the four waves' results and is the same deterministic scan in every wave - and every wave
+  // builds ITS QUARTER of the rows of 2*org - pred straight into the shared buffer (the leader used to predict and subtract the whole block while
+  // three waves waited: a third of a step).  Two workgroup barriers per step as before: after the build, after the searches.
   // A step whose inputs - reference and vector of the other list, hence 2*org - pred; and the candidate list of every
   // reference - equal those of the previous step of the same list finds the same SADs again, none of which is below
   // min_sad any more (the earlier step left min_sad <= all of them): it changes nothing and is skipped (about a third of
   // all steps on typical content).  Exact, not a heuristic.
   int prev_ref[2] = {-1, -1}, prev_cnt[2][kMaxRefs];
   mv_t prev_mv[2][4];
+  mv_t min0[4], min1[4];
+  for (int i = 0; i < 4; i++) { min0[i] = mvp; min1[i] = mvp; }
+  int ref0 = 0, ref1 = 0;
+  unsigned min_sad = 1u << 30;
+  if (wg.wave == 0 && t.rank == 0) sh->bp_org8 = ws->org8;   // the shared 2*org - pred block: wave 0's buffer (visible after the fork barrier? no: published below)
+  t.sync();
+  wg.barrier();
+  PIX* const org8 = (PIX*)sh->bp_org8;   // same address space as this wave's buffers (same block size)
+  const int whole = nd.bw == size && nd.bh == size;
   for (int n = 0; n < num_iter; n++)
     for (int list = 1; list >= 0; list--) {
-      const int step = 2 * n + (1 - list);
-      if (wg.wave == 0) {
-        mv_t mo[4];
-        for (int i = 0; i < 4; i++) mo[i] = lds_ld(list ? &sh_->bp_min0[i] : &sh_->bp_min1[i]);
-        const int ref_o = list ? sh->bp_ref0 : sh->bp_ref1;
-        int same = n > 0 && prev_ref[list] == ref_o;
-        for (int i = 0; i < 4; i++) same = same && prev_mv[list][i].x == mo[i].x && prev_mv[list][i].y == mo[i].y;
-        for (int r = 0; r < J.num_ref; r++) {
-          const int cnt = lists->mvcand_num[r];
-          same = same && prev_cnt[list][r] == cnt;
-          prev_cnt[list][r] = cnt;
-        }
-        prev_ref[list] = ref_o;
-        for (int i = 0; i < 4; i++) prev_mv[list][i] = mo[i];
-        same = tk_uniform(same);
-        if (t.rank == 0) sh->bp_skip[step] = same;
-        if (!same) {
-          pred_inter_yuv<SP>(t, lds_ld(&J.ref[ref_o]), ws->pred_y, ws->pred_u, ws->pred_v, nd.ypos, nd.xpos, size, nd.bw, nd.bh, mo, J.sign[ref_o], c.width,
-                         c.height, c.enable_bipred, 0, c.bitdepth, 1);
-          t.sync();
-          build_org8<PIX, SP>(t, ws->org8, ws->org_y, ws->org_sy, ws->pred_y, size, c.bitdepth);
-          if (t.rank == 0) sh->bp_org8 = ws->org8;
-        }
-        t.sync();
+      const int buf = (2 * n + (1 - list)) & 1;   // result slots alternate: a fast wave's next step never overwrites what a slow one still reads
+      const mv_t* mo = list ? min0 : min1;
+      const int ref_o = list ? ref0 : ref1;
+      int same = n > 0 && prev_ref[list] == ref_o;
+      for (int i = 0; i < 4; i++) same = same && prev_mv[list][i].x == mo[i].x && prev_mv[list][i].y == mo[i].y;
+      for (int r = 0; r < J.num_ref; r++) {
+        const int cnt = lists->mvcand_num[r];
+        same = same && prev_cnt[list][r] == cnt;
+        prev_cnt[list][r] = cnt;
       }
-      wg.barrier();
-      if (team_bcast0(t, sh->bp_skip[step])) continue;  // uniform over the workgroup
-      const PIX* org8 = (const PIX*)sh->bp_org8;   // the leader's buffer: same address space as this wave's (same block size)
+      prev_ref[list] = ref_o;
+      for (int i = 0; i < 4; i++) prev_mv[list][i] = mo[i];
+      if (tk_uniform(same)) continue;   // the same decision in every wave: all of them read the same counts and hold the same state
+      if (whole) {
+        // this wave's rows of 2*org - pred (get_inter_prediction_luma of the other list's vector, inter_prediction.c:93-183; encode_block.c:1786-1791)
+        const Plane3<PIX> rp = lds_ld(&J.ref[ref_o]);
+        const int sgn = J.sign[ref_o];
+        const mv_t mvc_ = clip_mv(mo[0], nd.ypos, nd.xpos, c.width, c.height, size, size, sgn);
+        const SubPel sp = luma_setup(mvc_, sgn, size, size, c.width, c.height, nd.xpos, nd.ypos, c.enable_bipred);
+        const PIX* ry = rp.y + nd.ypos * rp.sy + nd.xpos;
+        const int rows = size / wg.nwaves > 0 ? size / wg.nwaves : size, r0 = wg.wave * rows, r1 = size / wg.nwaves > 0 ? r0 + rows : (wg.wave == 0 ? size : 0);
+        const auto o8 = spc<SP>(org8);
+        const auto oys = spc<SP>(ws->org_y);
+        const int osy = ws->org_sy;
+        const Pow2 pw = mk_pow2(size);
+        for (int k = r0 * size + t.rank; k < r1 * size; k += t.size) {
+          int i, j;
+          split2(pw, k, i, j);
+          o8[k] = (PIX)sat_pix(2 * (int)oys[i * osy + j] - luma_sample(ry, rp.sy, i, j, sp, c.enable_bipred, c.bitdepth), c.bitdepth);
+        }
+      } else if (wg.wave == 0) {   // blocks cut by the frame edge: the whole-block path on one wave
+        pred_inter_yuv<SP>(t, lds_ld(&J.ref[ref_o]), ws->pred_y, ws->pred_u, ws->pred_v, nd.ypos, nd.xpos, size, nd.bw, nd.bh, mo, J.sign[ref_o], c.width,
+                           c.height, c.enable_bipred, 0, c.bitdepth, 1);
+        t.sync();
+        build_org8<PIX, SP>(t, org8, ws->org_y, ws->org_sy, ws->pred_y, size, c.bitdepth);
+      }
+      t.sync();
+      wg.barrier();   // 2*org - pred is complete
       for (int r = wg.wave; r < J.num_ref; r += wg.nwaves) {
         mv_t mv_all[4];
         const unsigned sad = search_inter<PIX, SP>(t, J, ws, nd.ypos, nd.xpos, size, org8, size, r, lds_ld(&sh_->mv_center[r]), mvp, mv_all, 0, J.sign[r]);
         add_cands4(t, ws, r, mv_all);
-        if (t.rank == 0) { sh->bp_sad[r] = sad; for (int i = 0; i < 4; i++) lds_st(&sh_->bp_mv[r][i], mv_all[i]); }
+        if (t.rank == 0) { sh->bp_sad2[buf][r] = sad; for (int i = 0; i < 4; i++) lds_st(&sh_->bp_mv2[buf][r][i], mv_all[i]); }
       }
       t.sync();
-      wg.barrier();
-      if (wg.wave == 0) {
-        if (t.rank == 0)
-          for (int r = 0; r < J.num_ref; r++)
-            if (sh->bp_sad[r] < sh->bp_min_sad) {
-              sh->bp_min_sad = sh->bp_sad[r];
-              if (list) { sh->bp_ref1 = r; for (int i = 0; i < 4; i++) lds_st(&sh_->bp_min1[i], lds_ld(&sh_->bp_mv[r][i])); }
-              else { sh->bp_ref0 = r; for (int i = 0; i < 4; i++) lds_st(&sh_->bp_min0[i], lds_ld(&sh_->bp_mv[r][i])); }
-            }
-        t.sync();
+      wg.barrier();   // every reference's result is there
+      for (int r = 0; r < J.num_ref; r++) {   // the reference's scan (encode_block.c:1770-1816), in every wave
+        const unsigned sd = (unsigned)tk_uniform((int)sh->bp_sad2[buf][r]);
+        if (sd < min_sad) {
+          min_sad = sd;
+          if (list) { ref1 = r; for (int i = 0; i < 4; i++) min1[i] = lds_ld(&sh_->bp_mv2[buf][r][i]); }
+          else { ref0 = r; for (int i = 0; i < 4; i++) min0[i] = lds_ld(&sh_->bp_mv2[buf][r][i]); }
+        }
       }
     }
-  wg.barrier();
   // trials: tb 0 on wave 0, tb 1 on the next wave (each builds its own prediction)
   for (int tb = 0; tb <= max_tb - 1; tb++)
     if (wg.wave == tb % wg.nwaves) {
       BlkParam p = blank_param();
       p.mode = M_BIPRED; p.pb_part = P_NONE;
-      p.ref0 = (int8_t)sh->bp_ref0; p.ref1 = (int8_t)sh->bp_ref1;
-      for (int i = 0; i < 4; i++) { p.mv0[i] = lds_ld(&sh_->bp_min0[i]); p.mv1[i] = lds_ld(&sh_->bp_min1[i]); }
+      p.ref0 = (int8_t)ref0; p.ref1 = (int8_t)ref1;
+      for (int i = 0; i < 4; i++) { p.mv0[i] = min0[i]; p.mv1[i] = min1[i]; }
       p.tb_param = (int8_t)tb;
       par_trial<PIX, SP>(t, J, ws, M, p, 54u + (unsigned)tb, 0);
     }

@@ -207,8 +207,7 @@ namespace tk {
 // error - so its limit is 120 s, or THOR_HOSTSIM_WAIT_S seconds.
 #if TK_HOST
 static inline unsigned long long wg_wait_limit() {
-  static unsigned long long lim = 0;
-  if (!lim) { const char* e = getenv("THOR_HOSTSIM_WAIT_S"); lim = (unsigned long long)((e && atof(e) > 0 ? atof(e) : 120.0) * 1e8); }
+  static const unsigned long long lim = [] { const char* e = getenv("THOR_HOSTSIM_WAIT_S"); return (unsigned long long)((e && atof(e) > 0 ? atof(e) : 120.0) * 1e8); }();   // thread-safe initialisation
   return lim;
 }
 #define kWgWaitLimit wg_wait_limit()
@@ -392,6 +391,21 @@ TK_DEV int team_group_sum(const Team t, int v, int G) {
 #else
   for (int d = G >> 1; d >= 1; d >>= 1) v += team_shfl_xor(t, v, d);
   return v;
+#endif
+}
+// value of lane `lane` (wave-uniform index) in every lane of the team
+TK_DEV int team_read_lane(const Team t, int v, int lane) {
+#if TK_LANES
+  const unsigned long long* g = hostlanes::exchange_begin((unsigned long long)(long long)v);
+  const int r = (int)(long long)g[lane < t.size ? lane : 0];
+  hostlanes::exchange_end();
+  return r;
+#elif TK_HOST
+  (void)t; (void)lane;
+  return v;
+#else
+  (void)t;
+  return __builtin_amdgcn_readlane(v, lane);
 #endif
 }
 // minimum over the team, wave-uniform result

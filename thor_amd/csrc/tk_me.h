@@ -381,17 +381,17 @@ TK_DEVNI unsigned long long me_cand8_fullpel(const Team t, MeWs* w_, const uint8
   // multiples of four); window / plane and one / two segments per row are decided outside the loop (straight-line bodies: all eight or
   // sixteen reads of an iteration are issued before the first SAD waits for them)
   auto rows_sad = [&](auto win_tag, auto spr_tag, int dx, int dy, int off) -> unsigned {
-    constexpr int WIN = decltype(win_tag)::value, SPR = decltype(spr_tag)::value;
+    constexpr int WIN = decltype(win_tag)::value, SPR = decltype(spr_tag)::value, ROWS = 4 / SPR;   // four segments in flight
     unsigned sad = 0;
     int wb = mul24(dy - win.oy, win.pitch) + (dx + off - win.ox);
     const uint8_t* gb = ref + mul24(dy, rstride) + (dx + off);
     const uint8_t* ob = org_;
-    for (int i = 0; i < height; i += 4) {
-      Seg16 o[4 * SPR], r[4 * SPR];
+    for (int i = 0; i < height; i += ROWS) {
+      Seg16 o[ROWS * SPR], r[ROWS * SPR];
 #if !TK_HOST
 #pragma unroll
 #endif
-      for (int k = 0; k < 4; k++)
+      for (int k = 0; k < ROWS; k++)
 #if !TK_HOST
 #pragma unroll
 #endif
@@ -403,8 +403,8 @@ TK_DEVNI unsigned long long me_cand8_fullpel(const Team t, MeWs* w_, const uint8
 #if !TK_HOST
 #pragma unroll
 #endif
-      for (int q = 0; q < 4 * SPR; q++) sad = (unsigned)seg_sad<uint8_t, NB>(o[q], r[q], (int)sad);
-      wb += 4 * win.pitch; gb += 4 * rstride; ob += 4 * ostride;
+      for (int q = 0; q < ROWS * SPR; q++) sad = (unsigned)seg_sad<uint8_t, NB>(o[q], r[q], (int)sad);
+      wb += ROWS * win.pitch; gb += ROWS * rstride; ob += ROWS * ostride;
     }
     return sad;
   };
@@ -412,22 +412,23 @@ TK_DEVNI unsigned long long me_cand8_fullpel(const Team t, MeWs* w_, const uint8
   struct T1 { enum { value = 1 }; };
   struct T2 { enum { value = 2 }; };
   auto block_sad = [&](int use_win, int dx, int dy, int off) -> unsigned {
-    if (NB == 16 && spr == 2) return use_win ? rows_sad(T1(), T2(), dx, dy, off) : rows_sad(T0(), T2(), dx, dy, off);
+    if constexpr (NB == 16) {
+      if (spr == 2) return use_win ? rows_sad(T1(), T2(), dx, dy, off) : rows_sad(T0(), T2(), dx, dy, off);
+    }
     return use_win ? rows_sad(T1(), T1(), dx, dy, off) : rows_sad(T0(), T1(), dx, dy, off);
   };
-  // One pass: lane c evaluates candidate c < n (n <= 64), mv_of(c) = its (unclipped) vector.  Returns min over (cost << 8 | c).
-  // WIDE: the cost of a candidate is that of its best x offset of {-3, -1, 0, 1, 3} (first minimum) with the vector moved there
-  // (encode_block.c:430-453); key = cost << 9 | c << 3 | offset index.
-  auto pass = [&](int n, auto mv_of, int do_clip, auto wide_tag) -> unsigned {
+  // Cost of THIS LANE's candidate (vector m, not yet clipped; `valid` lanes only - the others return ~0u).  Every vector is clipped with clip_mv,
+  // which leaves a vector inside the clip-free area alone: the same vectors motion_estimate evaluates with or without its `noclip` short cut.
+  // WIDE (16x16 coding blocks, candidate list): the cost is that of the best x offset of {-3, -1, 0, 1, 3} (first minimum) with the vector moved
+  // there (encode_block.c:430-453); *osel = that offset's index.
+  auto lane_cost = [&](mv_t m, int valid, auto wide_tag, unsigned* osel) -> unsigned {
     constexpr int WIDE = decltype(wide_tag)::value;
-    const int c = t.rank, valid = c < n;
-    mv_t m = mv_of(valid ? c : 0);
-    if (do_clip) m = clip_mv(m, ypos, xpos, fw, fh, cb, cb, sign);
+    m = clip_mv(m, ypos, xpos, fw, fh, cb, cb, sign);
     const int dx = s * (m.x >> 2), dy = s * (m.y >> 2);
     const int x0 = dx - (WIDE ? 3 : 0), x1 = dx + (WIDE ? 3 : 0);
     const int outside = valid && !(x0 >= win.ox && x1 + width <= win.ox + win.Ww && dy >= win.oy && dy + height <= win.oy + win.Wh);
     const int use_win = win.on && team_ballot(t, outside) == 0ull;
-    unsigned sad, osel = 0;
+    unsigned sad;
     int mx = m.x;
     if constexpr (WIDE) {
       sad = 1u << 31;
@@ -435,91 +436,148 @@ TK_DEVNI unsigned long long me_cand8_fullpel(const Team t, MeWs* w_, const uint8
       for (int q = 0; q < 5; q++) {
         const int off = q == 0 ? -3 : q == 1 ? -1 : q == 2 ? 0 : q == 3 ? 1 : 3;
         const unsigned v = block_sad(use_win, dx, dy, off);
-        if (v < sad) { sad = v; bx = off; osel = (unsigned)q; }
+        if (v < sad) { sad = v; bx = off; *osel = (unsigned)q; }
       }
       mx = (int16_t)(m.x + ((s * bx) << 2));
     } else
       sad = block_sad(use_win, dx, dy, 0);
     const unsigned cost = sad + mv_cost(lam, m.y - mvp.y, mx - mvp.x);
-    unsigned k = WIDE ? ((cost << 9) | ((unsigned)c << 3) | osel) : ((cost << 8) | (unsigned)c);
-    if (!valid) k = ~0u;
+    return valid ? cost : ~0u;
+  };
+  // min over the lanes [lo, lo + n) of (cost << 8 | lane - lo): the first candidate in evaluation order among the cheapest; ~0u for n == 0
+  auto range_min = [&](unsigned cost, int lo, int n) -> unsigned {
+    const int c = t.rank - lo;
+    unsigned k = (cost << 8) | (unsigned)(c & 0xff);
+    if (c < 0 || c >= n || cost == ~0u) k = ~0u;
     return team_min32(t, k);
   };
   struct NoWide { enum { value = 0 }; };
   struct Wide { enum { value = 1 }; };
-  // --- telescope (encode_block.c:529-561)
-  for (int step = 32; step >= 4; step >>= 1) {
-    const int n = step < 32 ? 24 : 25;
+  auto grid_mv = [&](mv_t centre, int step, int c) -> mv_t {   // point c of the 5x5 grid of spacing `step` around centre; the centre is skipped after the first step
+    const int idx = (step < 32 && c >= 12) ? c + 1 : c;
+    const int q = mul24(idx, 13) >> 6;   // idx / 5
+    return mk_mv(centre.x + mul24(idx - q - (q << 2) - 2, step), centre.y + mul24(q - 2, step));
+  };
+  auto take = [&](mv_t m) {   // new optimum (clipped the way its candidate was), wave-uniform
+    m = clip_mv(m, ypos, xpos, fw, fh, cb, cb, sign);
+    mv_opt = mk_mv(tk_uniform(m.x), tk_uniform(m.y));
+  };
+  // --- telescope (encode_block.c:529-561): steps of 32, 16, 8, 4 quarter-pels.  A step is evaluated TOGETHER with the next one around the same
+  // centre (25 + 24 or 24 + 24 lanes): when the step leaves the optimum on its centre - the usual case with a good predictor - the next step's grid is
+  // exactly that one and its costs are already there; otherwise they are dropped and the next step runs from its real centre.
+  for (int step = 32; step >= 4;) {
+#ifdef TK_ME_NOSPEC   // tools/ubench_me.cpp: every step / round a pass of its own
+    const int n1 = step < 32 ? 24 : 25, n2 = 0;
+#else
+    const int n1 = step < 32 ? 24 : 25, n2 = step > 4 ? 24 : 0;
+#endif
     const mv_t centre = mv_ref;
-    const int noclip = TKU(clip_free(centre, 2 * step));
-    auto tele_mv = [&](int c) -> mv_t {
-      const int idx = (step < 32 && c >= 12) ? c + 1 : c;   // centre skipped after the first step
-      const int q = mul24(idx, 13) >> 6;                    // idx / 5
-      return mk_mv(centre.x + mul24(idx - q - (q << 2) - 2, step), centre.y + mul24(q - 2, step));
-    };
-    const unsigned k = pass(n, tele_mv, !noclip, NoWide());
-    if (k != ~0u && (k >> 8) < min_sad) {
-      min_sad = k >> 8;
-      mv_t m = tele_mv((int)(k & 0xffu));
-      if (!noclip) m = clip_mv(m, ypos, xpos, fw, fh, cb, cb, sign);
-      mv_opt = mk_mv(tk_uniform(m.x), tk_uniform(m.y));
-    }
+    const int c1 = t.rank, c2 = t.rank - n1;
+    const int v1 = c1 < n1, v2 = c2 >= 0 && c2 < n2;
+    const mv_t m = v2 ? grid_mv(centre, step >> 1, c2) : grid_mv(centre, step, v1 ? c1 : 0);
+    const unsigned cost = lane_cost(m, v1 || v2, NoWide(), nullptr);
+    const unsigned k1 = range_min(cost, 0, n1);
+    if (k1 != ~0u && (k1 >> 8) < min_sad) { min_sad = k1 >> 8; take(grid_mv(centre, step, (int)(k1 & 0xffu))); }
     mv_ref = mv_opt;
+    step >>= 1;
+    if (n2 && mv_ref.x == centre.x && mv_ref.y == centre.y) {   // the next step's centre is this one's: its costs are in lanes n1 .. n1 + 23
+      const unsigned k2 = range_min(cost, n1, n2);
+      if (k2 != ~0u && (k2 >> 8) < min_sad) { min_sad = k2 >> 8; take(grid_mv(centre, step, (int)(k2 & 0xffu))); }
+      mv_ref = mv_opt;
+      step >>= 1;
+    }
   }
   // --- candidate list (encode_block.c:564-581)
   {
     const int n = TKU(lists->mvcand_num[ref_idx]);
     if (n > 0) {
       auto list_mv = [&](int c) -> mv_t { return mk_mv((int16_t)(lists->mvcand[ref_idx][c].x << 2), (int16_t)(lists->mvcand[ref_idx][c].y << 2)); };
+      const int valid = t.rank < n;
+      const mv_t m = list_mv(valid ? t.rank : 0);
       if (cb == 16) {
-        const unsigned k = pass(n, list_mv, 1, Wide());
-        if (k != ~0u && (k >> 9) < min_sad) {
-          min_sad = k >> 9;
-          const int c = (int)((k >> 3) & 0x3fu), q = (int)(k & 7u);
-          mv_t m = clip_mv(list_mv(c), ypos, xpos, fw, fh, cb, cb, sign);
-          const int bx = q == 0 ? -3 : q == 1 ? -1 : q == 2 ? 0 : q == 3 ? 1 : 3;
-          m.x = (int16_t)(m.x + ((s * bx) << 2));
-          mv_opt = mk_mv(tk_uniform(m.x), tk_uniform(m.y));
-        }
-      } else {
-        const unsigned k = pass(n, list_mv, 1, NoWide());
+        unsigned osel = 0;
+        const unsigned cost = lane_cost(m, valid, Wide(), &osel);
+        const unsigned k = range_min(cost, 0, n);
         if (k != ~0u && (k >> 8) < min_sad) {
           min_sad = k >> 8;
-          const mv_t m = clip_mv(list_mv((int)(k & 0xffu)), ypos, xpos, fw, fh, cb, cb, sign);
-          mv_opt = mk_mv(tk_uniform(m.x), tk_uniform(m.y));
+          const int c = (int)(k & 0xffu);
+          const int q = team_read_lane(t, (int)osel, c);   // the winner's offset
+          mv_t mm = clip_mv(list_mv(c), ypos, xpos, fw, fh, cb, cb, sign);
+          const int bx = q == 0 ? -3 : q == 1 ? -1 : q == 2 ? 0 : q == 3 ? 1 : 3;
+          mm.x = (int16_t)(mm.x + ((s * bx) << 2));
+          mv_opt = mk_mv(tk_uniform(mm.x), tk_uniform(mm.y));   // (the moved vector is not clipped again: encode_block.c:447-451)
         }
+      } else {
+        const unsigned cost = lane_cost(m, valid, NoWide(), nullptr);
+        const unsigned k = range_min(cost, 0, n);
+        if (k != ~0u && (k >> 8) < min_sad) { min_sad = k >> 8; take(list_mv((int)(k & 0xffu))); }
       }
     }
     mv_ref = mv_opt;
   }
-  // --- hexagon refinement (encode_block.c:583-616): up to 5 rounds
+  // --- hexagon refinement (encode_block.c:583-616): up to 5 rounds of 6, then 3 points.  A round is evaluated together with the next round of
+  // every direction it can move in (6 + 6 x 3 or 3 + 3 x 3 lanes): the usual search ends after one or two rounds = one pass.
   {
+    auto hex_off = [&](int dir, int* ox, int* oy) {
+      *ox = dir == 0 ? 1 : dir == 1 ? 2 : dir == 2 ? 1 : dir == 3 ? -1 : dir == 4 ? -2 : -1;
+      *oy = dir == 0 ? -1 : dir == 1 ? 0 : dir == 2 ? 1 : dir == 3 ? 1 : dir == 4 ? 0 : -1;
+    };
     int start = 0, end = 5;
-    for (int round = 1; round < 6; round++) {
+    for (int round = 1; round < 6;) {
       const int n = (end - start + 6) % 6 + 1;   // 6 in the first round, 3 afterwards
       const mv_t centre = mv_ref;
-      const int noclip = TKU(clip_free(centre, 8));
-      auto hex_mv = [&](int c) -> mv_t {
-        const int dir = (start + c) % 6;
-        const int ox = dir == 0 ? 1 : dir == 1 ? 2 : dir == 2 ? 1 : dir == 3 ? -1 : dir == 4 ? -2 : -1;
-        const int oy = dir == 0 ? -1 : dir == 1 ? 0 : dir == 2 ? 1 : dir == 3 ? 1 : dir == 4 ? 0 : -1;
-        return mk_mv(centre.x + ox * 4, centre.y + oy * 4);
-      };
-      int which = -1;
-      const unsigned k = pass(n, hex_mv, !noclip, NoWide());
-      if (k != ~0u && (k >> 8) < min_sad) {
-        min_sad = k >> 8;
-        which = (int)(k & 0xffu);
-        mv_t m = hex_mv(which);
-        if (!noclip) m = clip_mv(m, ypos, xpos, fw, fh, cb, cb, sign);
-        mv_opt = mk_mv(tk_uniform(m.x), tk_uniform(m.y));
+      // lanes [0, n): this round; lanes [n + 3 j, n + 3 j + 3): the next round if this one moves to its point j (new start = that direction - 1)
+      const int L = t.rank;
+      int ox, oy, valid = L < n * 4;
+      mv_t m;
+      {
+        const int j = L < n ? L : mul24(L - n, 11) >> 5;   // (L - n) / 3 for L - n < 32
+        const int dir1 = (start + (j < n ? j : 0)) % 6;
+        hex_off(dir1, &ox, &oy);
+        m = mk_mv(centre.x + ox * 4, centre.y + oy * 4);
+        if (L >= n) {
+          const int st2 = dir1 ? dir1 - 1 : 5;
+          const int dir2 = (st2 + (L - n - mul24(j, 3))) % 6;
+          hex_off(dir2, &ox, &oy);
+          m = mk_mv(m.x + ox * 4, m.y + oy * 4);
+        }
       }
-      const int best_dir = which < 0 ? -1 : (start + which) % 6;
+#ifdef TK_ME_NOSPEC
+      const int speculate = 0;
+#else
+      const int speculate = round < 5;
+#endif
+      if (!speculate) valid = L < n;
+      const unsigned cost = lane_cost(m, valid, NoWide(), nullptr);
+      int which = -1;
+      const unsigned k = range_min(cost, 0, n);
+      auto hex_mv = [&](mv_t ctr, int st, int c) -> mv_t { int x, y; hex_off((st + c) % 6, &x, &y); return mk_mv(ctr.x + x * 4, ctr.y + y * 4); };
+      if (k != ~0u && (k >> 8) < min_sad) { min_sad = k >> 8; which = (int)(k & 0xffu); take(hex_mv(centre, start, which)); }
+      int best_dir = which < 0 ? -1 : (start + which) % 6;
+      // (the next round's centre is the point as this round evaluated it; a clipped point is not the speculated centre: fall back to a fresh pass)
+      const mv_t raw = which < 0 ? centre : hex_mv(centre, start, which);
       mv_ref = mv_opt;
+      const int start0 = start;
       start = best_dir ? best_dir - 1 : 5;
       end = start + 2;
       end -= (end >= 6) * 6;
+      round++;
       if (best_dir < 0) break;
+      if (speculate && round < 6 && raw.x == mv_ref.x && raw.y == mv_ref.y) {
+        // the next round around the new centre: its three points are lanes n + 3 * which ..
+        (void)start0;
+        const mv_t centre2 = mv_ref;
+        const unsigned k2 = range_min(cost, n + 3 * which, 3);
+        int which2 = -1;
+        if (k2 != ~0u && (k2 >> 8) < min_sad) { min_sad = k2 >> 8; which2 = (int)(k2 & 0xffu); take(hex_mv(centre2, start, which2)); }
+        best_dir = which2 < 0 ? -1 : (start + which2) % 6;
+        mv_ref = mv_opt;
+        start = best_dir ? best_dir - 1 : 5;
+        end = start + 2;
+        end -= (end >= 6) * 6;
+        round++;
+        if (best_dir < 0) break;
+      }
     }
   }
   return ((unsigned long long)min_sad << 32) | ((unsigned long long)(uint16_t)mv_opt.x << 16) | (unsigned long long)(uint16_t)mv_opt.y;
@@ -940,7 +998,8 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
   // 8-bit PUs of up to 32x32 samples, encoder_speed 0: the one-lane-per-candidate full-pel search (me_cand8_fullpel) - same passes, same result
   int small_done = 0;
   if constexpr (sizeof(PIX) == 1) {
-    if (TKU(a.speed == 0 && a.width <= 32 && a.height <= 32 && t.size == 64)) {
+    // (rows of 64 and 128 samples keep the 64-lane evaluator: a lane walking 256+ row segments of the plane by itself measured 2x slower, profiles/r05_ubench_me.md)
+    if (TKU(a.speed == 0 && t.size == 64 && a.width <= 32 && a.height <= 32)) {
 #ifndef TK_ME_NO_SMALL
       unsigned long long fr;
 #define TK_ME_FP_ARGS t, w_, org, ref, a.cb_size, a.ostride, a.width, a.height, a.rstride, a.sign, a.fwidth, a.fheight, a.xpos, a.ypos, a.lam, win.w32, win.ox, win.oy, win.Ww, win.Wh, win.pitch, win.on, mvc, mvp, ref_idx

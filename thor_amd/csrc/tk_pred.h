@@ -467,6 +467,12 @@ TK_DEV void pred_chroma(const Team t, PIX* dst_, int dstride, const PIX* ref, in
   vi = tmax(vi, -xpos - height);  // sic (inter_prediction.c:78)
   hi = tmin(hi, pic_w2 - xpos);
   hi = tmax(hi, -xpos - width);
+  // the eight taps once per PU (they are selects on the fractions, not table reads: keep them out of the sample loop)
+  int th[4], tv[4];
+  {
+    const unsigned ph = chroma_taps8(hf), pv = chroma_taps8(vf);
+    for (int n = 0; n < 4; n++) { th[n] = (int)(int8_t)(ph >> (8 * n)); tv[n] = (int)(int8_t)(pv >> (8 * n)); }
+  }
   for (int k = t.rank; k < width * height; k += t.size) {
     int i, j;
     split2(mk_div(width), k, i, j);
@@ -478,8 +484,8 @@ TK_DEV void pred_chroma(const Team t, PIX* dst_, int dstride, const PIX* ref, in
       int sum = 0;
       for (int n = 0; n < 4; n++) {
         const TK_GLOBAL PIX* q = p + (n - 1) * rstride;
-        int row = chroma_tap(hf, 0) * q[-1] + chroma_tap(hf, 1) * q[0] + chroma_tap(hf, 2) * q[1] + chroma_tap(hf, 3) * q[2];
-        sum += chroma_tap(vf, n) * row;
+        int row = th[0] * q[-1] + th[1] * q[0] + th[2] * q[1] + th[3] * q[2];
+        sum += tv[n] * row;
       }
       v = sat_pix((sum + 2048) >> 12, bitdepth);
     }

@@ -10,7 +10,7 @@ using namespace tk;
 
 enum { W = 1024, H = 512, PITCH = W + 2 * kPadY };
 
-template <int PW, int PH, int CB> __global__ __launch_bounds__(256, 3) void k_me(const uint8_t* cur, const uint8_t* ref, int iters, long long* cyc, int* sink, long long* prof_out) {
+template <int PW, int PH, int CB, int SPACE = SP_LDS> __global__ __launch_bounds__(256, 3) void k_me(const uint8_t* cur, const uint8_t* ref, int iters, long long* cyc, int* sink, long long* prof_out) {
   extern __shared__ uint8_t pad_[];   // dynamic LDS: pads the workgroup to the product's footprint so that at most three fit a CU
   __shared__ MeWs ws[4];
   __shared__ MeLists lists[4];
@@ -37,14 +37,16 @@ template <int PW, int PH, int CB> __global__ __launch_bounds__(256, 3) void k_me
   for (int it = 0; it < iters; it++) {
     // the wave's next block: walks over the plane, 16-aligned positions away from the frame edge
     const int bx = 64 + 16 * ((gw * 7 + it * 3) % ((W - 160) / 16)), by = 64 + 16 * ((gw * 5 + it) % ((H - 160) / 16));
-    for (int k = lane; k < PW * PH; k += 64) org[wave][k] = cur0[(by + k / PW) * PITCH + bx + k % PW];
+    if (SPACE == SP_LDS) for (int k = lane; k < PW * PH; k += 64) org[wave][k & 1023] = cur0[(by + k / PW) * PITCH + bx + k % PW];
     if (lane == 0 && (it & 7) == 0) { lists[wave].mvcand_num[0] = 0; lists[wave].mvcand_mask[0] = 0; }   // a new "superblock": empty candidate list
     t.sync();
     a.xpos = bx; a.ypos = by; a.pu_x = bx; a.pu_y = by;
     mv_t mv;
-    const mv_t mvp = mk_mv(8, -4);   // predictor 2 px / 1 px off the true motion (20, -12 quarter-pels)
+    // predictor: the true motion (20, -12 quarter-pels) in three searches of four, 3 px / 2 px off in the fourth
+    const mv_t mvp = (it & 3) ? mk_mv(20, -12) : mk_mv(8, -4);
     const long long t0 = (long long)__builtin_readcyclecounter();
-    acc += (int)motion_estimate<uint8_t, SP_LDS>(t, &ws[wave], org[wave], ref0 + by * PITCH + bx, a, mvp, mvp, 0, &mv);
+    if (SPACE == SP_LDS) acc += (int)motion_estimate<uint8_t, SP_LDS>(t, &ws[wave], org[wave], ref0 + by * PITCH + bx, a, mvp, mvp, 0, &mv);
+    else { a.ostride = PITCH; acc += (int)motion_estimate<uint8_t, SP_GLOBAL>(t, &ws[wave], cur0 + by * PITCH + bx, ref0 + by * PITCH + bx, a, mvp, mvp, 0, &mv); }
     total += (long long)__builtin_readcyclecounter() - t0;
     if (lane == 0) add_mvcand(&ws[wave], 0, mv);
     t.sync();
@@ -56,13 +58,13 @@ template <int PW, int PH, int CB> __global__ __launch_bounds__(256, 3) void k_me
 }
 
 static long long* d_prof = nullptr;
-template <int PW, int PH, int CB> static void run(const uint8_t* d_cur, const uint8_t* d_ref, long long* d_cyc, int* d_sink) {
-  const int iters = 400;
+template <int PW, int PH, int CB, int SPACE = SP_LDS> static void run(const uint8_t* d_cur, const uint8_t* d_ref, long long* d_cyc, int* d_sink) {
+  const int iters = PW >= 64 ? 100 : 400;
   for (int per_cu = 1; per_cu <= 3; per_cu++) {
     const int blocks = 256 * per_cu;
     const size_t dyn = 36 * 1024;   // + ~17 KB static: 53 KB per workgroup, three per CU at most
     for (int rep = 0; rep < 2; rep++) {
-      hipLaunchKernelGGL((k_me<PW, PH, CB>), dim3(blocks), dim3(256), dyn, 0, d_cur, d_ref, iters, d_cyc, d_sink, d_prof);
+      hipLaunchKernelGGL((k_me<PW, PH, CB, SPACE>), dim3(blocks), dim3(256), dyn, 0, d_cur, d_ref, iters, d_cyc, d_sink, d_prof);
       if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return; }
     }
     std::vector<long long> c(blocks * 4);
@@ -104,5 +106,6 @@ int main() {
   run<8, 8, 8>(d_cur, d_ref, d_cyc, d_sink);
   run<16, 16, 16>(d_cur, d_ref, d_cyc, d_sink);
   run<32, 32, 32>(d_cur, d_ref, d_cyc, d_sink);
+  run<64, 64, 64, SP_GLOBAL>(d_cur, d_ref, d_cyc, d_sink);
   return 0;
 }
