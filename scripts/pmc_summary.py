@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc passes of tools/thorenc_hip (one directory per pass: gpurun_out/<prefix>_<tag>/) for
 k_superblocks: writes a markdown table and a small JSON with the per-pixel figures bench.py reports as roofline.traffic.
-  python scripts/pmc_summary.py gpurun_out/r4pmc 3840 2160 128 6 gpurun_out/r04_pmc_bench "<workload description>"   (run on the GPU box, in the tree that was profiled) """
+  python scripts/pmc_summary.py gpurun_out/r4pmc 3840 2160 128 6 gpurun_out/r04_pmc_bench "<workload description>" [SKIP]   (run on the GPU box, in the tree that was profiled)
+SKIP (round 5): number of leading k_superblocks launches to leave out - the warm-up frames of a bench.py run - so that the counters are those of the TIMED
+frames only; `frames` is then the number of timed frames (steps). """
 import collections, csv, glob, json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from bench import csrc_digest   # the summary is stamped with the digest of the engine sources it profiled; bench.py attaches it only to the same sources
 
 prefix, w, h, S, n, out, desc = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], sys.argv[7]
+skip = int(sys.argv[8]) if len(sys.argv) > 8 else 0
 px = float(w) * h * S * n
 agg = collections.OrderedDict()
 times = {}
-for tag in ('sq1', 'sq2', 'fetch', 'write'):
+for tag in ('sq1', 'sq2', 'fetch', 'write'):   # one rocprofv3 --pmc pass each (a missing pass is skipped)
     fs = glob.glob(f'{prefix}_{tag}/*/*_counter_collection.csv')
     if not fs:
         continue
-    for r in csv.DictReader(open(fs[0])):
-        if 'k_superblocks' in r['Kernel_Name']:
+    rows = [r for r in csv.DictReader(open(fs[0])) if 'k_superblocks' in r['Kernel_Name']]
+    ids = sorted({int(r['Dispatch_Id']) for r in rows})
+    keep = set(ids[skip:])   # the launches of the timed frames
+    for r in rows:
+        if int(r['Dispatch_Id']) in keep:
             agg[r['Counter_Name']] = agg.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
     kt = glob.glob(f'{prefix}_{tag}/*/*_kernel_trace.csv')[0]
-    times[tag] = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e9 for r in csv.DictReader(open(kt)) if 'k_superblocks' in r['Kernel_Name']]
+    times[tag] = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e9 for r in sorted((r for r in csv.DictReader(open(kt)) if 'k_superblocks' in r['Kernel_Name']),
+                                                                                                   key=lambda r: int(r['Start_Timestamp']))][skip:]
 g = lambda k: agg.get(k, float('nan'))
 # gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE tallies 128-B requests at
 # 64 B -> doubled; WRITE_SIZE is uncalibrated on gfx950 and is reported as is.

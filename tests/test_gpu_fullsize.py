@@ -81,3 +81,17 @@ def test_64_streams_1080p_six_frames_staggered_groups_equal_their_reference_chun
     bits, rec = _encode(BIG[names[0]], [_frames(BIG[n]) for n in names], staggered=True)
     bad = [n for i, n in enumerate(names) if md5(bits[i]) != BIG[n]['bit_md5'] or md5(rec[i]) != BIG[n]['rec_md5']]
     assert not bad, f'{len(bad)} of 64 streams differ from their reference chunk: {bad[:4]}'
+
+
+def test_nine_1080p_streams_27_frames_across_both_high_quality_frames_equal_their_reference_runs():
+    """Round 5: the frame schedule of every frame bench.py times with the driver's flags (coded frames 5..24) and two more - LDB_high_efficiency past the
+    second high-quality frame (coded frame 24), the long-term reference r1 = last HQ frame up to 12 frames back, the second lap of the 13-slot reference
+    ring (enc/mainenc.c:455-500): the 27-frame 1080p clip and eight streams of bench.py's 1080p workload with 27 frames each, nine closed streams in
+    one staggered run (thor_hip_encode_staged_run), each hashed against its own reference run."""
+    names = ['1080p_ldb_n27_q32'] + ['1080p_stream%02d_n27_q32' % s for s in (0, 5, 10, 15, 21, 26, 31, 36)]
+    names = [n for n in names if n in BIG]
+    if len(names) < 2:
+        pytest.skip('27-frame goldens not generated')
+    bits, rec = _encode(BIG[names[0]], [_frames(BIG[n]) for n in names], staggered=True)
+    bad = [n for i, n in enumerate(names) if md5(bits[i]) != BIG[n]['bit_md5'] or md5(rec[i]) != BIG[n]['rec_md5']]
+    assert not bad, f'{len(bad)} of {len(names)} streams differ from their reference run: {bad}'
