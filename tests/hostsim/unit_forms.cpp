@@ -24,6 +24,7 @@ template <typename PIX> static void test_subpel(int bitdepth, unsigned seed) {
               SubPel s;
               s.ver_int = dy - 1; s.hor_int = dx - 1; s.ver_frac = fy; s.hor_frac = fx;
               for (int m = 0; m < 6; m++) { s.th[m] = luma_tap(bip, fx, m); s.tv[m] = luma_tap(bip, fy, m); }
+              s.ph = luma_taps8(bip, fx); s.pv = luma_taps8(bip, fy);   // the packed form of the same taps (what subk8_make reads since round 5)
               const int ci = 20, cj = 24;   // centre position (integer displacement 0) of the sample under test
               const PIX* ref = plane.data() + ci * W + cj;
               const int want = luma_sample<PIX>(ref, W, 0, 0, s, bip, bitdepth);
@@ -67,10 +68,9 @@ template <typename PIX> static void test_blocks(int bitdepth, unsigned seed) {
       for (int k = 0; k < size * size; k++) { long long e = (long long)a[k] - (long long)b[k]; want += (unsigned long long)(e * e); }
       const unsigned long long got = ssd_total(t, ssd_part<SP_GLOBAL, PIX>(t, a, size, b, size, size, size));
       // The modular form is exact while ONE LANE's share stays below 2^32: on the device a lane holds at most 128*128/64 = 256 samples
-      // (256 x 4095^2 < 2^32, always exact); this 1-lane team sums the whole block in one lane, so only cases that fit are compared
-      // (8-bit: every size; 16-bit: up to the sizes / contents whose total stays below 2^32).
-      if (want < (1ull << 32)) CHECK(got == want, "ssd size %d bd %d mode %d: %llu != %llu", size, bitdepth, mode, got, want);
-      else CHECK(got == (want & 0xffffffffull), "ssd (mod 2^32) size %d bd %d mode %d: %llu != %llu", size, bitdepth, mode, got, want & 0xffffffffull);
+      // (256 x 4095^2 < 2^32, always exact).  A team smaller than a wavefront (this 1-lane team sums the whole block in one lane) takes the
+      // 64-bit sample loop for blocks of 16-bit samples whose share can exceed that (round 5, tk_block.h:ssd_part): exact for every case.
+      CHECK(got == want, "ssd size %d bd %d mode %d: %llu != %llu", size, bitdepth, mode, got, want);
       // truncating average
       average_yuv<SP_GLOBAL, PIX>(t, d, d + size * size, d + size * size * 5 / 4, a, a, a, b, b, b, size, size, size);   // chroma views overlap on purpose: only luma is checked
       int bad = 0;

@@ -27,7 +27,7 @@ def test_reference_reproduces_golden_and_roundtrips(name):
                                   '128x96_n9_q32_ra', '192x128_n6_q30_ra_gop4', '192x128_n6_q36_ra_gop4_nointerp',
                                   '192x128_n5_q32_hdb16_gop4_10bit',
                                   '192x128_n6_q32_ldb_low', '208x120_n4_q30_ldb_medium', '208x120_n4_q38_ldb_medium_clpf',
-                                  '192x128_n5_q34_ldb_low_10bit', 'cfg1_352x288_n30_q32_ldb_low', '192x128_n27_q32_ldb'])
+                                  '192x128_n5_q34_ldb_low_10bit', 'cfg1_352x288_n30_q32_ldb_low'])   # (the 26 / 27-frame LDB goldens: 4-wave simulation below and the GPU suite)
 def test_engine_host_simulation_matches_golden(name):
     c = G[name]
     bits, rec = run_encoder(build_hostsim(), golden_clip(c['clip']), c['w'], c['h'], c['n'], c['qp'], c['extra'], cfg=c.get('cfg'))
@@ -133,11 +133,11 @@ def test_host_simulation_two_random_access_streams_equal_reference_chunks():
 
 
 @needs_ref
-@pytest.mark.parametrize('cfg_name,w,h,n,streams', [('ldb_high_efficiency.cfg', 416, 240, 4, 3), ('ra_high_efficiency.cfg', 128, 96, 9, 2)])
+@pytest.mark.parametrize('cfg_name,w,h,n,streams', [('ldb_high_efficiency.cfg', 384, 136, 3, 3), ('ra_high_efficiency.cfg', 128, 96, 9, 2)])
 def test_host_simulation_staggered_stream_groups_equal_reference_chunks(cfg_name, w, h, n, streams):
     """Engine::encode_run - the streams in two groups half a frame apart, every launch of the superblock scheduler covering the second half of
     one group's frame (a range of anti-diagonals of the superblock grid) and the first half of the other's - against the reference run on each
-    chunk with -skip/-n: 416x240 LDB (4 x 2 superblocks: five anti-diagonals, three streams = groups of 1 and 2) with 1-lane teams and with
+    chunk with -skip/-n: 384x136 LDB (3 x 2 superblocks: five anti-diagonals, three streams = groups of 1 and 2) with 1-lane teams and with
     4-wave workgroups, and an RA chunk pair (B frames, interpolated references prepared per group)."""
     import subprocess, tempfile
     from util import ROOT
