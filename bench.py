@@ -550,12 +550,33 @@ def main():
     hasher = ThreadPoolExecutor(2)
     done_frames = [0] * S     # coded frames finished per stream
 
+    # Host buffers of the verified reconstructions: a small pool of PINNED frames that is reused (a fresh pageable array per frame costs page faults and
+    # a staged copy: ~8 ms per 3840x2160 frame; 14 verified streams per step).  A buffer goes back to the pool when its hash has been taken.
+    import queue
+    fbytes_host = enc.frame_bytes
+    pool = queue.SimpleQueue()
+    n_pool = min(2 * max(len(verify), 1), 32) if do_verify else 0
+    pool_bufs = [torch.empty(fbytes_host, dtype=torch.uint8, pin_memory=have_gpu) for _ in range(n_pool)]
+    for b_ in pool_bufs:
+        pool.put(b_)
+    verify_host_s = [0.0]
+
+    def hash_and_release(buf):
+        try:
+            return hashlib.md5(memoryview(buf.numpy())).hexdigest()
+        finally:
+            pool.put(buf)
+
     def take_recon(s, di):
-        """Reconstruction of the frame stream s has just finished: (display index, md5).  The frame is fetched here (D2H); the hash is taken by a
-        worker thread while the GPU codes on (hashlib releases the GIL)."""
+        """Reconstruction of the frame stream s has just finished: (display index, md5).  The frame is fetched here (D2H into a pinned buffer of the
+        pool); the hash is taken by a worker thread while the GPU codes on (hashlib releases the GIL)."""
         cf = done_frames[s]
         if s in verify and (s in recorded or cf < nv):
-            verify[s][1][cf] = (di, hasher.submit(lambda b: hashlib.md5(b).hexdigest(), enc.recon(s).tobytes()))
+            t_ = time.perf_counter()
+            buf = pool.get()     # blocks only if every buffer is still being hashed
+            enc.recon_into(s, buf.data_ptr())
+            verify[s][1][cf] = (di, hasher.submit(hash_and_release, buf))
+            verify_host_s[0] += time.perf_counter() - t_
         done_frames[s] = cf + 1
 
     def step():
@@ -586,6 +607,7 @@ def main():
 
     run(a.warmup)
     enc.kernel_time_reset()
+    verify_host_s[0] = 0.0
     if dist is not None:
         dist.barrier()
     if have_gpu:
@@ -757,6 +779,10 @@ def main():
                    'inputs': 'resident in HBM before the timed region (staged device-to-device); host-to-device transfer of the input frames is EXCLUDED from value '
                              f'(one {fpx * bps / 1e6:.1f} MB frame per stream and step: ~{S * fpx * bps / 50e9 * 1e3:.0f} ms per step at PCIe Gen5 rates); the device-to-host '
                              'transfer of every stream\'s bits and of the verified reconstructions is inside it',
+                   'timed_region_ms_per_step': {'k_superblocks': round(sb_ms / max(a.steps, 1), 1), 'filters_reference_creation_bit_gather_kernels': round(filt_ms / max(a.steps, 1), 1),
+                                                'verified_reconstructions_d2h': round(verify_host_s[0] * 1e3 / max(a.steps, 1), 1),
+                                                'other_host_work_and_launch_gaps': round((dt * 1e3 - sb_ms - filt_ms - verify_host_s[0] * 1e3) / max(a.steps, 1), 1),
+                                                'note': 'rank-local figures of this rank; the kernels of a step do not overlap (a launch, then the filters of the stream group whose frame it completed)'},
                    'rank0_host_load': f'{len(legs.procs)} reference processes (checker + cpu_baseline legs) ran on rank 0\'s host beside its GPU work; the other ranks ran none'},
         }
         if stats:

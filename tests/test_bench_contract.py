@@ -15,6 +15,13 @@ class _FakeEncoder:
     def __init__(self, params, num_streams=1, device=0):
         self.S = num_streams
         self.calls = 0
+        self.frame_bytes = params.width * params.height * 3 // 2 * (2 if getattr(params, 'bitdepth', 8) > 8 else 1)
+
+    def recon_into(self, stream, ptr):   # the product binding downloads into a caller-owned (pinned) buffer; the fakes go through their recon()
+        import ctypes
+        b = self.recon(stream).tobytes()
+        ctypes.memset(ptr, 0, self.frame_bytes)
+        ctypes.memmove(ptr, b, min(len(b), self.frame_bytes))
 
     def stage_device(self, stream, slot, ptr):
         assert ptr != 0 and 0 <= stream < self.S

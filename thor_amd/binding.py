@@ -206,6 +206,12 @@ class Encoder:
             raise RuntimeError(f'thor_hip_get_recon rc={rc}')
         return out
 
+    def recon_into(self, stream, ptr):
+        """Reconstruction of the stream's last frame into a caller-owned host buffer of frame_bytes bytes (e.g. pinned memory that is reused)."""
+        rc = lib().thor_hip_get_recon(self.h, stream, C.c_void_p(ptr))
+        if rc:
+            raise RuntimeError(f'thor_hip_get_recon rc={rc}')
+
     def kernel_time(self):
         a, b, c = C.c_double(), C.c_long(), C.c_double()
         lib().thor_hip_kernel_time(self.h, C.byref(a), C.byref(b), C.byref(c))
