@@ -36,5 +36,5 @@ python3 scripts/pmc_summary.py gpurun_out/r5pmc 3840 2160 128 20 gpurun_out/r05_
 cp gpurun_out/r05_pmc_bench.json gpurun_out/r05_pmc_bench.md profiles/
 find $O -name "*_kernel_trace.csv" -path "*r5pmc*" -size +2M -delete
 find $O -name "*_counter_collection.csv" -path "*r5pmc*" -size +8M -delete
-timeout 600 python bench.py --warmup 5 --steps 20 --verify recorded --no-cpu-baseline > $O/r05_bench_driver_regime_traffic.json 2> $O/r05_bench_driver_regime_traffic.err
+timeout 700 python bench.py --steps 20 --warmup 5 > $O/r05_bench_driver_regime_traffic.json 2> $O/r05_bench_driver_regime_traffic.err
 echo "$(el) bench with traffic: $(grep -o '"value": [0-9.]*' $O/r05_bench_driver_regime_traffic.json | head -1) $(grep -o '"traffic": [0-9a-z]*' $O/r05_bench_driver_regime_traffic.json) $(grep -o '"bit_exact": [a-z]*' $O/r05_bench_driver_regime_traffic.json)"
