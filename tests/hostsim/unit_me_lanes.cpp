@@ -45,11 +45,11 @@ struct Case { int pw, ph, cb; };
 struct Result { unsigned cost; mv_t mv; };
 
 // One sequence of searches (the per-"superblock" candidate list evolves along it) with a team of `lanes` lanes.
-static std::vector<Result> run_sequence(int lanes, const Case& c, int iters, const uint8_t* cur0, const uint8_t* ref0, int bipred, int sign, unsigned seed) {
+static std::vector<Result> run_sequence(int lanes, const Case& c, int iters, const uint8_t* cur0, const uint8_t* ref0, int bipred, int sign, int window, unsigned seed) {
   std::vector<Result> out(iters);
   static MeWs ws; static MeLists lists; static uint32_t win[1200]; static uint8_t org[32 * 32]; static long long prof[32];
   memset(&ws, 0, sizeof(ws)); memset(&lists, 0, sizeof(lists));
-  ws.lists = &lists; ws.prof = prof; ws.win = win; ws.win_cap = 4500; ws.cwin_valid = 0;
+  ws.lists = &lists; ws.prof = prof; ws.win = window ? win : nullptr; ws.win_cap = window ? 4500 : 0; ws.cwin_valid = 0;   // no window: every candidate is read from the plane
   hostlanes::Shared sh;
   sh.n = lanes;
   std::vector<std::thread> th;
@@ -114,10 +114,12 @@ int main(int argc, char** argv) {
   for (const Case& c : cases) {
     ci++;
     if (ci < first || ci >= first + count) continue;
-    for (int variant = 0; variant < 2; variant++) {   // plain search / the second search of a bi-prediction step (enable_bipred filters), reference "in the future"
-      const int iters = c.pw * c.ph >= 512 ? 12 : 24;
-      const std::vector<Result> a = run_sequence(64, c, iters, cur0, ref0, 1, variant, 777u + (unsigned)c.pw * 31u + (unsigned)c.ph);
-      const std::vector<Result> b = run_sequence(1, c, iters, cur0, ref0, 1, variant, 777u + (unsigned)c.pw * 31u + (unsigned)c.ph);
+    for (int variant = 0; variant < 4; variant++) {   // 0 plain / 1 reference "in the future" (vector signs) / 2 the other filter set (enable_bipred 0) / 3 no staged window
+      const int iters = c.pw * c.ph >= 512 ? 24 : 48;
+      const int sign = variant == 1, bipred = variant != 2, window = variant != 3;
+      const unsigned seed = 777u + (unsigned)c.pw * 31u + (unsigned)c.ph + 1000u * (unsigned)variant;
+      const std::vector<Result> a = run_sequence(64, c, iters, cur0, ref0, bipred, sign, window, seed);
+      const std::vector<Result> b = run_sequence(1, c, iters, cur0, ref0, bipred, sign, window, seed);
       for (int it = 0; it < iters; it++) {
         total++;
         if (a[it].cost != b[it].cost || a[it].mv.x != b[it].mv.x || a[it].mv.y != b[it].mv.y) {
