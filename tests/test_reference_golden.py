@@ -72,6 +72,19 @@ def test_sixteen_lane_teams_search_window_and_row_segments_vs_live_reference():
 
 
 @needs_ref
+def test_sixty_four_lane_teams_run_the_lane_per_candidate_search_vs_live_reference():
+    """64-lane teams (the device's team size) on a 64x64 clip (I + 2 P; the second P frame searches two references and their bi-prediction): with 64 lanes the 8-bit PUs of up to
+    32x32 samples take the lane-per-candidate search (tk_me.h: me_cand8_fullpel / me_cand8_subpel) - the code the MI355X runs - inside a complete
+    encode, on the CPU; stream and reconstruction must equal the live reference run.  (A whole small golden, 192x128 x 3 frames, was run this way once
+    in round 5: profiles/r05_hostsim_l64.log - 64 OS threads per team make it too slow for the suite.)"""
+    from thor_amd import synth
+    clip = b''.join(p.tobytes() for fr in synth.make_clip(64, 64, 3, 13, 4.0) for p in fr)
+    rb, rr = run_encoder(REF_ENC, clip, 64, 64, 3, 32)
+    bits, rec = run_encoder(build_hostsim(lanes=64), clip, 64, 64, 3, 32)
+    assert bits == rb and rec == rr
+
+
+@needs_ref
 def test_multi_wave_host_simulation_416x240_four_references_vs_live_reference():
     """416x240 LDB_high_efficiency, I + 5 P (the last two P frames search 4 references): the regime bench.py times - lock-step
     bi-prediction search over 4 references with skipped repeat steps, duplicate-partition skipping, key-based pruning - in the
