@@ -733,7 +733,7 @@ def main():
         avg_launch_s = (sb_ms / 1e3) / max(launches, 1)
         achieved = alg_bytes_per_launch / max(avg_launch_s, 1e-12) / 1e9
         # HBM traffic and SQ figures: only from a committed PMC pass of THIS workload geometry AND of this very library
-        # (profiles/r04_pmc_bench.json, written by scripts/pmc_summary.py from rocprofv3 --pmc passes of the same bench geometry; it
+        # (profiles/r05_pmc_bench.json, written by scripts/pmc_summary.py from rocprofv3 --pmc passes of the same bench geometry; it
         # carries csrc_digest() of the sources it profiled); otherwise null - a counter of other code is not attached to this line.
         traffic, traffic_src, valu_util = None, None, None
         try:
@@ -772,8 +772,11 @@ def main():
                          'ops': {'model': 'SAD pixel-differences per luma pixel (SURVEY 8d): %.3g' % sad_ops_px,
                                  'achieved_pxops_per_s': round(value * 1e6 * sad_ops_px, 0), 'peak_pxops_per_s': SAD_PEAK_PXOPS,
                                  'unit': 'v_sad_u8 pixel-differences/s', 'frac': round(sad_frac, 6), 'valu_util_chip': valu_util},
-                         'note': 'one persistent dependency-driven launch per frame; the path is latency/instruction-bound, not HBM-bound (SURVEY.md 0.7); '
-                                 'filters+ref kernels took %.1f ms in the timed region' % filt_ms},
+                         'traffic_frac_of_peak': (round(traffic / max(avg_launch_s, 1e-12) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+                         'note': ('one persistent dependency-driven launch per frame' if a.lockstep else
+                                  'persistent dependency-driven launches over ranges of anti-diagonals of the superblock grid: two per frame + one per run (two stream groups half a frame apart)') +
+                                 '; by algorithmic bytes the path is latency/instruction-bound, not HBM-bound (SURVEY.md 0.7) - `traffic` (L2 misses of the resident working set, '
+                                 'DESIGN.md 8a) is what loads the memory system; filters+ref kernels took %.1f ms in the timed region' % filt_ms},
             'io': {'input_setup_s': round(t_in, 2), 'gather_s': round(t_g, 3), 'cpu_legs_wait_s': round(t_w, 1),
                    'stream_bytes_total': int(total_bytes), 'frames_total': int(total_frames),
                    'inputs': 'resident in HBM before the timed region (staged device-to-device); host-to-device transfer of the input frames is EXCLUDED from value '

@@ -94,7 +94,7 @@ class _SlowFakeEncoder(_FakeEncoder):
     (the situation of the driver's 25-frame run, where round 3's poll-time stamps produced 73 Mpixels/s)."""
     def encode_staged(self, slots):
         import time
-        time.sleep(0.4)
+        time.sleep(0.8)   # (0.4 s was not enough on a loaded host: the legs must have exited before the timed region ends)
         super().encode_staged(slots)
 
 
