@@ -45,7 +45,7 @@ struct Case { int pw, ph, cb; };
 struct Result { unsigned cost; mv_t mv; };
 
 // One sequence of searches (the per-"superblock" candidate list evolves along it) with a team of `lanes` lanes.
-static std::vector<Result> run_sequence(int lanes, const Case& c, int iters, const uint8_t* cur0, const uint8_t* ref0, int bipred, int sign, int window, unsigned seed) {
+static std::vector<Result> run_sequence(int lanes, const Case& c, int iters, const uint8_t* cur0, const uint8_t* ref0, int bipred, int sign, int window, unsigned seed, double lam = 9.5, int list_period = 8) {
   std::vector<Result> out(iters);
   static MeWs ws; static MeLists lists; static uint32_t win[1200]; static uint8_t org[32 * 32]; static long long prof[32];
   memset(&ws, 0, sizeof(ws)); memset(&lists, 0, sizeof(lists));
@@ -59,7 +59,7 @@ static std::vector<Result> run_sequence(int lanes, const Case& c, int iters, con
       const Team t = mk_team(r, lanes);
       MeArgs a;
       a.cb_size = c.cb; a.ostride = c.pw; a.width = c.pw; a.height = c.ph; a.rstride = PITCH; a.sign = sign; a.fwidth = W; a.fheight = H;
-      a.enable_bipred = bipred; a.bitdepth = 8; a.speed = 0; a.lam = 9.5;
+      a.enable_bipred = bipred; a.bitdepth = 8; a.speed = 0; a.lam = lam;
       unsigned rng = seed;
       for (int it = 0; it < iters; it++) {
         // positions all over the frame, its corners and edges included (clipped vectors, windows cut by the padding)
@@ -67,7 +67,7 @@ static std::vector<Result> run_sequence(int lanes, const Case& c, int iters, con
         int bx = (int)((rng >> 8) % (unsigned)((W - c.pw) / 4 + 1)) * 4, by = (int)((rng >> 20) % (unsigned)((H - c.ph) / 4 + 1)) * 4;
         if (it % 7 == 0) { bx = it % 14 ? 0 : W - c.pw; by = it % 21 ? 0 : H - c.ph; }
         for (int k = r; k < c.pw * c.ph; k += lanes) org[k] = cur0[(by + k / c.pw) * PITCH + bx + k % c.pw];
-        if (r == 0 && (it & 7) == 0) { lists.mvcand_num[0] = 0; lists.mvcand_mask[0] = 0; }
+        if (r == 0 && it % list_period == 0) { lists.mvcand_num[0] = 0; lists.mvcand_mask[0] = 0; }   // a new "superblock": empty candidate list
         t.sync();
         a.xpos = bx & ~(c.cb - 1); a.ypos = by & ~(c.cb - 1); a.pu_x = bx; a.pu_y = by;
         rng = rng * 1664525u + 1013904223u;
@@ -114,12 +114,16 @@ int main(int argc, char** argv) {
   for (const Case& c : cases) {
     ci++;
     if (ci < first || ci >= first + count) continue;
-    for (int variant = 0; variant < 4; variant++) {   // 0 plain / 1 reference "in the future" (vector signs) / 2 the other filter set (enable_bipred 0) / 3 no staged window
+    // 0 plain / 1 reference "in the future" (vector signs) / 2 the other filter set (enable_bipred 0) / 3 no staged window /
+    // 4 one long candidate list (never reset: up to 48 entries), large lambda / 5 small lambda, future reference, the other filter set
+    for (int variant = 0; variant < 6; variant++) {
       const int iters = c.pw * c.ph >= 512 ? 24 : 48;
-      const int sign = variant == 1, bipred = variant != 2, window = variant != 3;
+      const int sign = variant == 1 || variant == 5, bipred = variant != 2 && variant != 5, window = variant != 3;
+      const double lam = variant == 4 ? 28.3 : variant == 5 ? 2.1 : 9.5;
+      const int period = variant == 4 ? 1000 : 8;
       const unsigned seed = 777u + (unsigned)c.pw * 31u + (unsigned)c.ph + 1000u * (unsigned)variant;
-      const std::vector<Result> a = run_sequence(64, c, iters, cur0, ref0, bipred, sign, window, seed);
-      const std::vector<Result> b = run_sequence(1, c, iters, cur0, ref0, bipred, sign, window, seed);
+      const std::vector<Result> a = run_sequence(64, c, iters, cur0, ref0, bipred, sign, window, seed, lam, period);
+      const std::vector<Result> b = run_sequence(1, c, iters, cur0, ref0, bipred, sign, window, seed, lam, period);
       for (int it = 0; it < iters; it++) {
         total++;
         if (a[it].cost != b[it].cost || a[it].mv.x != b[it].mv.x || a[it].mv.y != b[it].mv.y) {

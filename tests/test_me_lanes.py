@@ -1,10 +1,10 @@
 """The motion search with one lane per candidate (tk_me.h: me_cand8_fullpel / me_cand8_subpel - what 64-lane teams run for 8-bit PUs of up to 32x32
 samples, i.e. what the MI355X runs) against the generic search on the CPU: tests/hostsim/unit_me_lanes.cpp runs the product's motion_estimate over the
 same sequences of searches with a team of 64 lanes (64 OS threads) and with a 1-lane team; vector and cost of every search must be equal (twelve PU
-shapes x four variants - plain, reference "in the future", the other filter set, no staged window - 2016 searches; frame corners and edges, predictors on
-and far off the true motion, evolving candidate lists).  The CPU twin of the -DTK_ME_CROSSCHECK builds that make the same comparison inside the kernel
-on the GPU.  (Sensitivity checked once by hand: a reversed tie-break or a rate term off by one quarter-pel in the lane-per-candidate code fails
-2016 / 587 of the searches.)"""
+shapes x six variants - plain, reference "in the future", the other filter set, no staged window, one long candidate list with a large lambda, a small
+lambda - 3024 searches; frame corners and edges, predictors on and far off the true motion, evolving candidate lists).  The CPU twin of the -DTK_ME_CROSSCHECK builds that make the same comparison inside the kernel
+on the GPU.  (Sensitivity checked once by hand: a reversed tie-break or a rate term off by one quarter-pel in the lane-per-candidate code fails every search /
+a third of the searches.)"""
 import os
 import subprocess
 
@@ -16,4 +16,4 @@ def test_lane_per_candidate_search_equals_the_generic_search(tmp_path):
     subprocess.check_call(['g++', '-std=c++17', '-O2', '-DTHOR_HOSTSIM', '-DTHOR_HOSTSIM_LANES=64', '-ffp-contract=off', '-pthread', '-o', exe,
                            os.path.join(ROOT, 'tests', 'hostsim', 'unit_me_lanes.cpp')])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0 and r.stdout.startswith('ok: 2016 searches'), r.stdout + r.stderr
+    assert r.returncode == 0 and r.stdout.startswith('ok: 3024 searches'), r.stdout + r.stderr
