@@ -3,7 +3,7 @@
 // motion_estimate runs the same sequence of searches twice - once with a team of 64 lanes (64 OS threads, the cross-lane primitives go through the
 // exchange below) and once with a 1-lane team - and vector and cost of every search must be equal.  On the MI355X the same comparison is made inside
 // the kernel by -DTK_ME_CROSSCHECK builds (scripts/gpu_r5_call6.sh); this is its CPU twin, so that the lane-per-candidate code is not gated by GPU runs alone.
-//   g++ -std=c++17 -O2 -DTHOR_HOSTSIM -DTHOR_HOSTSIM_LANES=64 -ffp-contract=off -pthread -o unit_me_lanes tests/hostsim/unit_me_lanes.cpp
+//   g++ -std=c++17 -O2 -fno-strict-aliasing -DTHOR_HOSTSIM -DTHOR_HOSTSIM_LANES=64 -ffp-contract=off -pthread -o unit_me_lanes tests/hostsim/unit_me_lanes.cpp
 #include "../../thor_amd/csrc/tk_me.h"
 #include "../../thor_amd/csrc/tk_tables.h"
 #include <atomic>

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_lane_per_candidate_search_equals_the_generic_search(tmp_path):
     exe = str(tmp_path / 'unit_me_lanes')
-    subprocess.check_call(['g++', '-std=c++17', '-O2', '-DTHOR_HOSTSIM', '-DTHOR_HOSTSIM_LANES=64', '-ffp-contract=off', '-pthread', '-o', exe,
+    subprocess.check_call(['g++', '-std=c++17', '-O2', '-fno-strict-aliasing', '-DTHOR_HOSTSIM', '-DTHOR_HOSTSIM_LANES=64', '-ffp-contract=off', '-pthread', '-o', exe,
                            os.path.join(ROOT, 'tests', 'hostsim', 'unit_me_lanes.cpp')])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and r.stdout.startswith('ok: 3024 searches'), r.stdout + r.stderr

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_packed_forms_equal_the_per_sample_definitions(tmp_path):
     exe = str(tmp_path / 'unit_forms')
-    subprocess.check_call(['g++', '-std=c++17', '-O1', '-DTHOR_HOSTSIM', '-ffp-contract=off', '-I', ROOT, '-include', os.path.join(ROOT, 'thor_amd', 'csrc', 'tk_tables.h'),
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-fno-strict-aliasing', '-DTHOR_HOSTSIM', '-ffp-contract=off', '-I', ROOT, '-include', os.path.join(ROOT, 'thor_amd', 'csrc', 'tk_tables.h'),
                            '-o', exe, os.path.join(ROOT, 'tests', 'hostsim', 'unit_forms.cpp')])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip() == 'ok', r.stderr

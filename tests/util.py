@@ -75,7 +75,10 @@ def build_hostsim(lanes=1, waves=1):
     newest = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc)])
     if not os.path.exists(out) or os.path.getmtime(out) < newest:
         extra = ['-pthread'] + ([] if lanes == 1 else [f'-DTHOR_HOSTSIM_LANES={lanes}']) + ([] if waves == 1 else [f'-DTHOR_HOSTSIM_WAVES={waves}'])
-        subprocess.check_call(['g++', '-std=c++17', '-O2', '-DTHOR_HOSTSIM', '-ffp-contract=off'] + extra + ['-o', out, src])
+        # -fno-strict-aliasing: the host branches of the engine headers read row segments (uint32_t[4]) through sample-typed pointers (tk_me.h:seg_sad);
+        # with 16-bit samples that is undefined under strict aliasing, and g++ -O2 miscompiled one instantiation in builds with 32+ lanes (round 5:
+        # the 10-bit HDB16 golden differed with 32 / 64-lane teams, bit-exact with this flag; the device code works on the dwords - v_sad_u16)
+        subprocess.check_call(['g++', '-std=c++17', '-O2', '-fno-strict-aliasing', '-DTHOR_HOSTSIM', '-ffp-contract=off'] + extra + ['-o', out, src])
     return out
 
 
