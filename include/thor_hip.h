@@ -107,7 +107,8 @@ int thor_hip_encode_staged(thor_hip_encoder* e, const int* slots);
  * never changes a result: every superblock starts after its dependencies, enc/encode_frame.c:697-835 raster order).
  * `done` (may be NULL) is called from the calling thread whenever the frames of streams [first_stream, first_stream + num_streams) are
  * complete: their bits are appended, thor_hip_get_recon returns that frame and thor_hip_last_display_index its display index until the
- * callback returns.  Returns 0, or non-zero when a stream has no frame left / a slot is not staged. */
+ * callback returns.  Returns 0; 2 when a stream has fewer than `nframes` frames left in its chunk, 3 when a frame of the run is not staged -
+ * both are found by a dry run of every stream's schedule BEFORE the first launch: a refused run touches nothing and may be repeated. */
 typedef void (*thor_hip_frames_done_fn)(void* user, int first_stream, int num_streams);
 int thor_hip_encode_staged_run(thor_hip_encoder* e, int nframes, thor_hip_frames_done_fn done, void* user);
 /* Chunk-relative display index of the frame stream `stream` coded last (-1: none yet). */
@@ -173,6 +174,40 @@ int thor_hip_interp_luma_hbd(const uint16_t* ref_plane, int plane_w, int plane_h
 int thor_hip_code_tu_batch_hbd(const uint16_t* org, const uint16_t* pred, int size, int qp, int coeff_type, int fast, int n,
                                int bitdepth, int16_t* coefq, uint16_t* rec, int* cbp);
 int thor_hip_deblock_frame_hbd(uint16_t* yuv, int width, int height, int qp, int bitdepth, const thor_hip_cell* cells);
+
+/* ---- (3b) round 6: known-answer entry points for the remaining sample kernels.  `bitdepth` 8: samples are uint8_t (the reference's _lbd
+ * instances); 9..12: uint16_t (_hbd).  Every call runs the device function the encoder itself calls, one wavefront per item; known answers are
+ * recorded from the reference functions named below (tests/golden/gen_kat5.py -> kat5.npz).  Return 0, 1 = bad argument, 2 = an item reads outside
+ * the given frame, 3 = no usable device. */
+/* make_top_and_left + get_intra_prediction (common/intra_prediction.c:57-183, :403-428) of `n` transform units of `size` x `size` samples.
+ * plane: a reconstructed plane (stride in samples).  par[7*i..]: ypos, xpos of the CODING block, its upright / downleft availability, the intra
+ * mode (0..9), and the unit's offset (i, j) inside the block.  tb_split 0: the unit IS the block (i = j = 0).  tb_split 1: the block is
+ * 2*size wide, rblocks holds `n` block-local reconstructions of (2*size)^2 samples (what the units coded earlier left there).  out: n*size*size. */
+int thor_hip_kat_intra(const void* plane, int width, int height, int stride, int bitdepth, int size, int tb_split, int n, const int* par,
+                       const void* rblocks, void* out);
+/* get_inter_prediction_yuv (common/inter_prediction.c:185-226: clip_mv, quarter-pel luma, eighth-pel chroma, one PU or four quadrant PUs) of `n`
+ * blocks of `size` from a planar 4:2:0 reference frame (the library pads it like a reference picture).  par[5*i..]: ypos, xpos, sign,
+ * enable_bipred, split; mv[8*i..]: four vectors (x, y).  out: n blocks of size*size luma + 2 * (size/2)^2 chroma samples. */
+int thor_hip_kat_inter_yuv(const void* yuv, int width, int height, int bitdepth, int size, int n, const int* par, const int16_t* mv, void* out);
+/* average_blocks_all (common/inter_prediction.c:228-247): truncating average of two yuv blocks (layout as above). */
+int thor_hip_kat_average(const void* a, const void* b, int size, int bitdepth, int n, void* out);
+/* improve_uv_prediction (common/common_block.c:347-428), 4:2:0: y = luma prediction, ry = reconstructed luma (both n_luma^2, stride n_luma),
+ * uv = chroma predictions U then V ((n_luma/2)^2 each), updated in place. */
+int thor_hip_kat_cfl(const void* y, void* uv, const void* ry, int n_luma, int bitdepth, int n);
+/* cdef_find_dir (common/common_block.c:94-162) on `n` 8x8 blocks (64 samples each, coeff_shift = bitdepth - 8). */
+int thor_hip_kat_cdef_dir(const void* blocks, int bitdepth, int n, int* dir, int* var);
+/* cdef_filter_block (common/common_block.c:224-279) of `n` bsize x bsize blocks (8 luma, 4 chroma) of a plane; samples outside the plane count as
+ * CDEF_VERY_LARGE (cdef_prepare_input, common/common_frame.c:766).  par[7*i..]: x0, y0, pri_strength, sec_strength, dir, pri_damping, sec_damping. */
+int thor_hip_kat_cdef_filter(const void* plane, int width, int height, int stride, int bitdepth, int bsize, int n, const int* par, void* out);
+/* CLPF on one planar 4:2:0 frame: the per-8x8-block squared errors of detect_multi_clpf (enc/encode_block.c:2556-2621; stats[4*b..]: unfiltered,
+ * strength 1, 2, 4; blocks in luma raster order, then U, then V; a block whose top-left cell is skip-coded reports {0, 0xffffffff, 0, 0}) and the
+ * filtered frame of clpf_frame / clpf_block (common/common_frame.c:1005-1163, common/common_block.c:325-345) for the given per-plane strengths
+ * (0 = off, else 1 / 2 / 4), luma filter-block size 1 << fb_log2 and per-filter-block switches fb_on. */
+int thor_hip_kat_clpf(const void* rec_yuv, const void* org_yuv, int width, int height, int bitdepth, int qp, const thor_hip_cell* cells,
+                      const int* strength, int fb_log2, const uint8_t* fb_on, uint32_t* stats, void* out_yuv);
+/* interpolate_frames(new, ref0, ref1, 2, 1) (common/temporal_interp.c:909: the frame half way between two reference pictures; luma pyramid,
+ * block motion estimation per level, merge, motion-compensated average) through the engine's own device path (tk_interp_dev.h). */
+int thor_hip_kat_interpolate(const void* yuv0, const void* yuv1, int width, int height, int bitdepth, void* out_yuv);
 
 #ifdef __cplusplus
 }

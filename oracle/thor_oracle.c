@@ -97,7 +97,12 @@ void orc_fwd_transform(const int16_t* block, int16_t* coeff, int size, int fast,
       for (int j = 0; j < size1; j++) {
         int16_t s = 0;
         for (int m = 0; m < scale; m++)
-          for (int n = 0; n < scale; n++) s = (int16_t)clampi(s + block[(i * scale + m) * size + j * scale + n], -16384, 16383);
+          /* what the reference executes is transform_simd (common/common_kernels.c:1482-1562): saturating accumulation with `fast`
+           * (:1526-1531), a plain wrapping int16_t sum without (:1545-1550); the scalar transform.c:262-277 saturates always */
+          for (int n = 0; n < scale; n++) {
+            const int v = s + block[(i * scale + m) * size + j * scale + n];
+            s = fast ? (int16_t)clampi(v, -16384, 16383) : (int16_t)v;
+          }
         in[i * size1 + j] = s;
       }
   } else

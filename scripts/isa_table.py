@@ -35,7 +35,7 @@ def main():
     flags = [a for a in sys.argv[1:] if a.startswith('-')]
     with tempfile.TemporaryDirectory() as d:
         asm = os.path.join(d, 'dev.s')
-        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '--cuda-device-only', '-S', '-w'] + flags +
+        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-strict-aliasing', '--cuda-device-only', '-S', '-w'] + flags +
                               ['-o', asm, os.path.join(ROOT, 'thor_amd', 'csrc', 'thor_hip.cpp')])
         text = open(asm).read()
     # ---- per function instruction counts

@@ -4,13 +4,14 @@ oracle/_ref/libthorref.so (build container only; `make -C oracle reflib`): sad_c
 through enc_kernels_hbd.c), get_inter_prediction_luma_hbd (common/inter_prediction.c:117), transform / quantize /
 dequantize_hbd / inverse_transform / reconstruct_block_hbd (common/transform.c:245,411, enc/encode_block.c:84,
 common/common_block.c:45,75) and deblock_frame_y_hbd / deblock_frame_uv_hbd (common/common_frame.c:47,354), all with
-bitdepth 10.  Stores inputs + outputs in tests/golden/kat4.npz (travels to the GPU box; nothing there reads /root/reference)."""
-import ctypes as C, os, numpy as np
+bitdepth 10 (or the bitdepth given as argument).  Stores inputs + outputs in tests/golden/kat4.npz / kat4_<bitdepth>.npz (travels to the GPU box; nothing there reads /root/reference)."""
+import ctypes as C, os, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 L = C.CDLL(os.path.join(ROOT, 'oracle/_ref/libthorref.so'))
 P = lambda a: a.ctypes.data_as(C.c_void_p)
-BD = 10
+BD = int(sys.argv[1]) if len(sys.argv) > 1 else 10   # round 6: `gen_kat4.py 12` -> kat4_12.npz (the same families at bitdepth 12)
 MAXV = (1 << BD) - 1
+SC = 1 << (BD - 10)          # content amplitudes were chosen for 10 bits
 
 
 class MV(C.Structure):
@@ -73,10 +74,10 @@ def main():
     k = 0
     for size in (4, 8, 16, 32, 64, 128):
         for (qp, ctype, fast) in ((22, 0, 0), (32, 2, 0), (38, 1, 0), (30, 0, 1 if size in (32, 64) else 0)):
-            n = 6 if size <= 32 else 2
+            n = (6 if size <= 32 else 2) if BD == 10 else (3 if size <= 32 else 1)
             q = min(size, 16)
             org = rng.integers(0, MAXV + 1, size=(n, size, size), dtype=np.uint16)
-            smooth = (org.astype(np.int32) + rng.integers(-80, 81, size=org.shape)).clip(0, MAXV)
+            smooth = (org.astype(np.int32) + rng.integers(-80 * SC, 80 * SC + 1, size=org.shape)).clip(0, MAXV)
             pred = np.where(rng.random(org.shape) < 0.5, smooth, np.roll(smooth, 1, axis=2)).astype(np.uint16)
             if k % 3 == 0: pred = rng.integers(0, MAXV + 1, size=org.shape, dtype=np.uint16)   # large residuals
             coefq = np.zeros((n, q, q), dtype=np.int16); rec = np.zeros_like(org); cbp = np.zeros(n, dtype=np.int32)
@@ -101,11 +102,11 @@ def main():
     # --- deblocking
     chroma_qp = list((C.c_int * 52).in_dll(L, 'chroma_qp'))  # common/common_tables.c:68-72
     for k, (w, h, qp) in enumerate(((64, 48, 32), (128, 80, 38), (96, 64, 22))):
-        tiles = rng.integers(240, 800, size=(h // 8, w // 8))
-        Y = np.clip(np.kron(tiles, np.ones((8, 8))) + rng.normal(0, 12, size=(h, w)) + rng.integers(-24, 25, size=(h, 1)), 0, MAXV).astype(np.uint16)
-        tc = rng.integers(360, 680, size=(h // 16, w // 16))
-        U = np.clip(np.kron(tc, np.ones((8, 8))) + rng.normal(0, 8, size=(h // 2, w // 2)), 0, MAXV).astype(np.uint16)
-        V = np.clip(np.kron(tc[::-1], np.ones((8, 8))) + rng.normal(0, 8, size=(h // 2, w // 2)), 0, MAXV).astype(np.uint16)
+        tiles = rng.integers(240 * SC, 800 * SC, size=(h // 8, w // 8))
+        Y = np.clip(np.kron(tiles, np.ones((8, 8))) + rng.normal(0, 12 * SC, size=(h, w)) + rng.integers(-24 * SC, 24 * SC + 1, size=(h, 1)), 0, MAXV).astype(np.uint16)
+        tc = rng.integers(360 * SC, 680 * SC, size=(h // 16, w // 16))
+        U = np.clip(np.kron(tc, np.ones((8, 8))) + rng.normal(0, 8 * SC, size=(h // 2, w // 2)), 0, MAXV).astype(np.uint16)
+        V = np.clip(np.kron(tc[::-1], np.ones((8, 8))) + rng.normal(0, 8 * SC, size=(h // 2, w // 2)), 0, MAXV).astype(np.uint16)
         ch, cw = h // 4, w // 4
         dd = (DeblockData * (ch * cw))()
         cells = np.zeros((ch, cw, 16), dtype=np.uint8)
@@ -137,8 +138,10 @@ def main():
         out[f'db_cells{k}'] = cells
         out[f'db_out{k}'] = np.concatenate([yo.ravel(), uo.ravel(), vo.ravel()])
         print('deblock', k, 'changed samples:', int((yo != Y).sum()), int((uo != U).sum()), int((vo != V).sum()))
-    np.savez_compressed(os.path.join(ROOT, 'tests/golden/kat4.npz'), **out)
-    print('wrote kat4.npz with', len(out), 'arrays')
+    name = 'kat4.npz' if BD == 10 else f'kat4_{BD}.npz'
+    out['bitdepth'] = np.array([BD], dtype=np.int32)
+    np.savez_compressed(os.path.join(ROOT, 'tests/golden', name), **out)
+    print('wrote', name, 'with', len(out), 'arrays')
 
 
 if __name__ == '__main__':

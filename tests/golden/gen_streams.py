@@ -33,6 +33,12 @@ CASES = {
     # into the second lap of the 13-slot reference ring (enc/mainenc.c:455-500: long-term reference r1 = last HQ frame)
     '192x128_n27_q32_ldb': ('gen:192,128,27,7,2.0', 192, 128, 27, 32, []),
     '208x120_n26_q24_ldb': ('gen:208,120,26,8,3.0', 208, 120, 26, 24, []),
+    # round 6: 12-bit samples (enc/strings.c:552-554 allows 8 / 10 / 12) - the claim "10/12-bit" of DESIGN 0 had no evidence before
+    '192x128_n4_q32_12bit': ('gen:192,128,4,11,2.0,12', 192, 128, 4, 32, ['-bitdepth', '12', '-input_bitdepth', '12']),
+    '192x128_n5_q30_hdb16_gop4_12bit': ('gen:192,128,5,12,2.5,12', 192, 128, 5, 30,
+                                        ['-num_reorder_pics', '3', '-bitdepth', '12', '-input_bitdepth', '12'], 'hdb16_high_efficiency.cfg'),
+    '208x120_n4_q36_ldb_medium_clpf_12bit': ('gen:208,120,4,13,2.0,12', 208, 120, 4, 36, ['-clpf', '1', '-bitdepth', '12', '-input_bitdepth', '12'],
+                                             'ldb_medium_complexity.cfg'),
 }
 out = {}
 with tempfile.TemporaryDirectory() as d:

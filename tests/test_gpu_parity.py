@@ -63,6 +63,35 @@ def test_staggered_stream_groups_equal_reference_chunks():
     assert a == b
 
 
+def test_staggered_run_refuses_before_it_launches():
+    """thor_hip_encode_staged_run validates the whole run up front (include/thor_hip.h): a run that asks for more frames than a chunk holds returns
+    2, one whose frame is not staged returns 3 - and a refused run has touched nothing: the same encoder then codes the chunk bit-exactly."""
+    import thor_amd
+    clip = np.frombuffer(golden_clip('clip_192x128_6.yuv.gz'), dtype=np.uint8)
+    w, h, n = 192, 128, 3
+    fsz = w * h * 3 // 2
+    p = thor_amd.load_config(os.path.join(ROOT, 'configs', 'ldb_high_efficiency.cfg'), width=w, height=h, qp=32, f=30)
+    with thor_amd.Encoder(p, 2) as enc:
+        L = thor_amd.lib()
+        for s in range(2):
+            for f in range(n - 1):                      # the last frame of the chunk is NOT staged yet
+                enc.stage(s, f, clip[(3 * s + f) * fsz:(3 * s + f + 1) * fsz])
+            enc.begin_sequence(s, 3 * s, n, 6)
+        assert L.thor_hip_encode_staged_run(enc.h, n + 1, thor_amd.binding.FRAMES_DONE_FN(0), None) == 2   # a chunk has only n frames
+        assert L.thor_hip_encode_staged_run(enc.h, n, thor_amd.binding.FRAMES_DONE_FN(0), None) == 3       # frame n - 1 is not staged
+        for s in range(2):
+            enc.stage(s, n - 1, clip[(3 * s + n - 1) * fsz:(3 * s + n) * fsz])
+        rec = [b'', b'']
+
+        def done(first, count):
+            for s in range(first, first + count):
+                rec[s] += enc.recon(s).tobytes()
+        enc.encode_run(n, done)
+        bits = [enc.bitstream(s) for s in range(2)]
+    assert md5(bits[0]) == G['192x128_n3_q32']['bit_md5'] and md5(rec[0]) == G['192x128_n3_q32']['rec_md5']
+    assert md5(bits[1]) == G['192x128_n3_q32_skip3']['bit_md5'] and md5(rec[1]) == G['192x128_n3_q32_skip3']['rec_md5']
+
+
 @pytest.mark.skipif(not os.path.exists(REF_ENC), reason='oracle/_ref/Thorenc not in the snapshot')
 def test_live_reference_cif_hard_clip():
     from thor_amd import synth as gen_clip

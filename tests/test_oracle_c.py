@@ -98,10 +98,12 @@ def test_clpf_sample_and_block_statistics():
 
 
 # ---- 16-bit samples: the same restatement against vectors recorded from the reference's _hbd functions (kat4.npz) ----
-K4 = np.load(os.path.join(GOLD, 'kat4.npz'))
+K4S = {10: np.load(os.path.join(GOLD, 'kat4.npz')), 12: np.load(os.path.join(GOLD, 'kat4_12.npz'))}   # round 6: bitdepth 12 too
 
 
-def test_sad_16bit():
+@pytest.mark.parametrize('bd', [10, 12])
+def test_sad_16bit(bd):
+    K4 = K4S[bd]
     plane = np.ascontiguousarray(K4['sad_plane'])
     for i in range(6):
         org, cand, want = np.ascontiguousarray(K4[f'sad_org{i}']), K4[f'sad_cand{i}'], K4[f'sad_out{i}']
@@ -110,7 +112,9 @@ def test_sad_16bit():
         assert (np.array(got, dtype=np.uint32) == want).all()
 
 
-def test_interp_luma_16bit():
+@pytest.mark.parametrize('bd', [10, 12])
+def test_interp_luma_16bit(bd):
+    K4 = K4S[bd]
     ref = np.ascontiguousarray(K4['ip_ref'])
     pad, pw, ph = 16, 64, 48
     k = 0
@@ -119,13 +123,15 @@ def test_interp_luma_16bit():
         for i, (mx, my) in enumerate(K4[f'ip_mv{k}']):
             out = np.zeros((h, w), dtype=np.uint16)
             base = int(ref.ctypes.data) + 2 * ((pad + by) * ref.shape[1] + pad + bx)
-            O.orc_interp_luma16(vp(out), w, C.c_void_p(base), ref.shape[1], w, h, int(mx), int(my), 0, bip, pw, ph, bx, by, 10)
+            O.orc_interp_luma16(vp(out), w, C.c_void_p(base), ref.shape[1], w, h, int(mx), int(my), 0, bip, pw, ph, bx, by, bd)
             assert (out == K4[f'ip_out{k}'][i]).all(), (k, i)
         k += 1
     assert k == 8
 
 
-def test_tu_pipeline_16bit():
+@pytest.mark.parametrize('bd', [10, 12])
+def test_tu_pipeline_16bit(bd):
+    K4 = K4S[bd]
     k = 0
     while f'tu_par{k}' in K4:
         size, qp, ctype, fast = [int(v) for v in K4[f'tu_par{k}']]
@@ -133,7 +139,7 @@ def test_tu_pipeline_16bit():
         q = min(size, 16)
         for i in range(org.shape[0]):
             cq = np.zeros((q, q), dtype=np.int16); rec = np.zeros((size, size), dtype=np.uint16)
-            cbp = O.orc_code_tu16(vp(np.ascontiguousarray(org[i])), vp(np.ascontiguousarray(pred[i])), size, qp, ctype, fast, vp(cq), vp(rec), 10)
+            cbp = O.orc_code_tu16(vp(np.ascontiguousarray(org[i])), vp(np.ascontiguousarray(pred[i])), size, qp, ctype, fast, vp(cq), vp(rec), bd)
             assert cbp == K4[f'tu_cbp{k}'][i]
             assert (cq == K4[f'tu_coefq{k}'][i]).all(), ('coefq', k, i)
             assert (rec == K4[f'tu_rec{k}'][i]).all(), ('rec', k, i)

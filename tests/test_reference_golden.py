@@ -27,7 +27,8 @@ def test_reference_reproduces_golden_and_roundtrips(name):
                                   '128x96_n9_q32_ra', '192x128_n6_q30_ra_gop4', '192x128_n6_q36_ra_gop4_nointerp',
                                   '192x128_n5_q32_hdb16_gop4_10bit',
                                   '192x128_n6_q32_ldb_low', '208x120_n4_q30_ldb_medium', '208x120_n4_q38_ldb_medium_clpf',
-                                  '192x128_n5_q34_ldb_low_10bit', 'cfg1_352x288_n30_q32_ldb_low'])   # (the 26 / 27-frame LDB goldens: 4-wave simulation below and the GPU suite)
+                                  '192x128_n5_q34_ldb_low_10bit', 'cfg1_352x288_n30_q32_ldb_low',
+                                  '192x128_n4_q32_12bit', '192x128_n5_q30_hdb16_gop4_12bit', '208x120_n4_q36_ldb_medium_clpf_12bit'])   # (the 26 / 27-frame LDB goldens: 4-wave simulation below and the GPU suite)
 def test_engine_host_simulation_matches_golden(name):
     c = G[name]
     bits, rec = run_encoder(build_hostsim(), golden_clip(c['clip']), c['w'], c['h'], c['n'], c['qp'], c['extra'], cfg=c.get('cfg'))
@@ -47,7 +48,7 @@ def test_engine_multi_lane_host_simulation_matches_golden(name):
 
 
 @pytest.mark.parametrize('name', ['192x128_n6_q32', '208x120_n4_q32', '128x96_n9_q32_ra', '192x128_n6_q30_ra_gop4', '192x128_n4_q32_10bit',
-                                  '192x128_n5_q32_hdb16_gop4_10bit', '208x120_n4_q30_ldb_medium', '208x120_n26_q24_ldb'])
+                                  '192x128_n5_q32_hdb16_gop4_10bit', '208x120_n4_q30_ldb_medium', '208x120_n26_q24_ldb', '192x128_n4_q32_12bit'])
 def test_engine_multi_wave_host_simulation_matches_golden(name):
     """Workgroups of 4 wavefronts (one OS thread each): the block decision of the encoder_speed 0 operating points is
     spread over the waves through a work queue (tk_block.h:mode_decision_par) - fork/join barriers, atomics on the shared

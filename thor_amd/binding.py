@@ -22,7 +22,7 @@ def build_native(force=False):
     newest = max(os.path.getmtime(h) for h in hdrs)
     if force or not os.path.exists(out) or os.path.getmtime(out) < newest:
         hipcc = '/opt/rocm/bin/hipcc' if os.path.exists('/opt/rocm/bin/hipcc') else 'hipcc'
-        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-pthread',
+        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-strict-aliasing', '-fPIC', '-shared', '-pthread',
                                '-o', out, src])
     tool = os.path.join(REPO_ROOT, 'tools', 'thorenc_hip')
     tsrc = tool + '.c'
@@ -300,3 +300,86 @@ def deblock_frame(yuv, width, height, qp, cells, bitdepth=8):
     if rc:
         raise RuntimeError(f'thor_hip_deblock_frame rc={rc}')
     return yuv
+
+
+# ---- round 6: known-answer entry points (include/thor_hip.h, section 3b) ----------------------------------------------------------
+def _kat(name, *args):
+    fn = getattr(lib(), name)
+    fn.restype = C.c_int
+    rc = fn(*args)
+    if rc:
+        raise RuntimeError(f'{name} rc={rc}')
+
+
+def kat_intra(plane, size, par, bitdepth=8, rblocks=None):
+    """Intra prediction of len(par) transform units (thor_hip_kat_intra); par rows: ypos, xpos, upright, downleft, mode, i, j."""
+    T = _pix(bitdepth)
+    plane = np.ascontiguousarray(plane, dtype=T); par = np.ascontiguousarray(par, dtype=np.int32)
+    n = len(par)
+    out = np.zeros((n, size, size), dtype=T)
+    rb = np.ascontiguousarray(rblocks, dtype=T) if rblocks is not None else None
+    _kat('thor_hip_kat_intra', _vp(plane), plane.shape[1], plane.shape[0], plane.shape[1], bitdepth, size, 1 if rb is not None else 0, n, _vp(par),
+         _vp(rb) if rb is not None else None, _vp(out))
+    return out
+
+
+def kat_inter_yuv(yuv, width, height, size, par, mvs, bitdepth=8):
+    """thor_hip_kat_inter_yuv: par rows ypos, xpos, sign, enable_bipred, split; mvs [n][4][2]."""
+    T = _pix(bitdepth)
+    yuv = np.ascontiguousarray(yuv, dtype=T); par = np.ascontiguousarray(par, dtype=np.int32); mvs = np.ascontiguousarray(mvs, dtype=np.int16)
+    n = len(par)
+    out = np.zeros((n, size * size * 3 // 2), dtype=T)
+    _kat('thor_hip_kat_inter_yuv', _vp(yuv), width, height, bitdepth, size, n, _vp(par), _vp(mvs), _vp(out))
+    return out
+
+
+def kat_average(a, b, size, bitdepth=8):
+    T = _pix(bitdepth)
+    a = np.ascontiguousarray(a, dtype=T); b = np.ascontiguousarray(b, dtype=T)
+    out = np.zeros_like(a)
+    _kat('thor_hip_kat_average', _vp(a), _vp(b), size, bitdepth, len(a), _vp(out))
+    return out
+
+
+def kat_cfl(y, uv, ry, n_luma, bitdepth=8):
+    T = _pix(bitdepth)
+    y = np.ascontiguousarray(y, dtype=T); ry = np.ascontiguousarray(ry, dtype=T); uv = np.array(uv, dtype=T, order='C')
+    _kat('thor_hip_kat_cfl', _vp(y), _vp(uv), _vp(ry), n_luma, bitdepth, len(y))
+    return uv
+
+
+def kat_cdef_dir(blocks, bitdepth=8):
+    T = _pix(bitdepth)
+    blocks = np.ascontiguousarray(blocks, dtype=T)
+    n = len(blocks)
+    d = np.zeros(n, dtype=np.int32); v = np.zeros(n, dtype=np.int32)
+    _kat('thor_hip_kat_cdef_dir', _vp(blocks), bitdepth, n, _vp(d), _vp(v))
+    return d, v
+
+
+def kat_cdef_filter(plane, bsize, par, bitdepth=8):
+    T = _pix(bitdepth)
+    plane = np.ascontiguousarray(plane, dtype=T); par = np.ascontiguousarray(par, dtype=np.int32)
+    out = np.zeros((len(par), bsize, bsize), dtype=T)
+    _kat('thor_hip_kat_cdef_filter', _vp(plane), plane.shape[1], plane.shape[0], plane.shape[1], bitdepth, bsize, len(par), _vp(par), _vp(out))
+    return out
+
+
+def kat_clpf(rec, org, width, height, qp, cells, strength, fb_log2, fb_on, bitdepth=8):
+    T = _pix(bitdepth)
+    rec = np.ascontiguousarray(rec, dtype=T); org = np.ascontiguousarray(org, dtype=T)
+    cells = np.ascontiguousarray(cells, dtype=np.uint8); fb_on = np.ascontiguousarray(fb_on, dtype=np.uint8)
+    st = np.ascontiguousarray(strength, dtype=np.int32)
+    nblk = (width // 8) * (height // 8) + 2 * (width // 16) * (height // 16)
+    stats = np.zeros((nblk, 4), dtype=np.uint32)
+    out = np.zeros_like(rec)
+    _kat('thor_hip_kat_clpf', _vp(rec), _vp(org), width, height, bitdepth, qp, _vp(cells), _vp(st), fb_log2, _vp(fb_on), _vp(stats), _vp(out))
+    return stats, out
+
+
+def kat_interpolate(yuv0, yuv1, width, height, bitdepth=8):
+    T = _pix(bitdepth)
+    a = np.ascontiguousarray(yuv0, dtype=T); b = np.ascontiguousarray(yuv1, dtype=T)
+    out = np.zeros_like(a)
+    _kat('thor_hip_kat_interpolate', _vp(a), _vp(b), width, height, bitdepth, _vp(out))
+    return out

@@ -780,6 +780,26 @@ int thor_hip_encode_staged_run(thor_hip_encoder* e, int nframes, thor_hip_frames
   if (!e || nframes < 0) return 1;
   int rc = 0;
   ENC_DISPATCH(e, {
+    // Validate BEFORE the first launch (a failure inside encode_run would leave half-frames in flight): dry-run every stream's coding-order
+    // schedule on a copy - the sequence of display indices does not depend on the reference ring - and check that each of the next `nframes`
+    // frames exists (rc 2) and is staged (rc 3).  Nothing is touched when the run is refused.
+    for (int s = 0; s < e->S && !rc; s++) {
+      GopScheduler g = E.eng.st[s].gop;
+      if (!g.started) g.init(E.eng.sp, 0, 1 << 28, 1 << 28);
+      for (int f = 0; f < nframes && !rc; f++) {
+        FrameParams fpar;
+        int abs_frame = 0;
+        if (f == 0 && E.pending[s]) fpar = E.eng.st[s].cur;   // already scheduled by thor_hip_next_frame
+        else if (!g.next(fpar, abs_frame, [&](int idx) { return E.eng.st[s].ring[idx].frame_num; })) { rc = 2; break; }
+        g.advance(fpar);   // the engine advances the schedule when the frame is finished (tk_encoder.h:finish_frames)
+        const int slot = fpar.frame_num;
+        if (slot < 0 || slot >= (int)E.staged[s].size() || !E.staged[s][slot].base_y) {
+          fprintf(stderr, "thor_hip: stream %d: frame %d is not staged\n", s, slot);
+          rc = 3;
+        }
+      }
+    }
+    if (rc) return rc;
     std::vector<DevFrame<PIXT>> keep(e->S);
     for (int s = 0; s < e->S; s++) keep[s] = E.eng.st[s].orig;
     E.eng.encode_run(nframes,
@@ -1058,6 +1078,58 @@ __global__ __launch_bounds__(64) void k_kat_tu(const PIX* org, const PIX* pred, 
   for (int k = threadIdx.x; k < qs * qs; k += 64) coefq[(size_t)i * qs * qs + k] = cq[k];
   if (threadIdx.x == 0) cbp[i] = c;
 }
+
+// ---- round 6: known-answer kernels for the sample kernels that were only covered by whole-stream hashes -------------------------
+// One wavefront per item, running exactly the device functions the encoder calls.
+template <typename PIX>
+__global__ __launch_bounds__(64) void k_kat_intra(const PIX* plane, int stride, int bitdepth, int size, int tb_split, const int* par, const PIX* rblocks,
+                                                 PIX* out) {
+  __shared__ IntraEdge<PIX> edge;
+  const Team t = mk_team((int)threadIdx.x, 64);
+  const int it = blockIdx.x;
+  const int* q = par + 7 * it;   // ypos, xpos (coding block), upright, downleft, mode, i, j (transform unit inside the block)
+  const int cbs = tb_split ? 2 * size : size;
+  const PIX* rblock = tb_split ? rblocks + (size_t)it * cbs * cbs + q[5] * cbs + q[6] : nullptr;
+  make_edges<SP_GLOBAL>(t, &edge, plane + (size_t)q[0] * stride + q[1], stride, rblock, cbs, q[5], q[6], q[0], q[1], size, q[2], q[3], tb_split, bitdepth);
+  pred_intra<SP_GLOBAL>(t, &edge, q[0] + q[5], q[1] + q[6], size, out + (size_t)it * size * size, size, q[4], bitdepth);
+}
+template <typename PIX>
+__global__ __launch_bounds__(64) void k_kat_inter_yuv(Plane3<PIX> ref, int width, int height, int bitdepth, int size, const int* par, const int16_t* mv, PIX* out) {
+  const Team t = mk_team((int)threadIdx.x, 64);
+  const int it = blockIdx.x;
+  const int* q = par + 5 * it;   // ypos, xpos, sign, enable_bipred, split
+  mv_t m[4];
+  for (int k = 0; k < 4; k++) m[k] = mk_mv(mv[(it * 4 + k) * 2], mv[(it * 4 + k) * 2 + 1]);
+  PIX* o = out + (size_t)it * (size * size * 3 / 2);
+  pred_inter_yuv<SP_GLOBAL>(t, ref, o, o + size * size, o + size * size * 5 / 4, q[0], q[1], size, size, size, m, q[2], width, height, q[3], q[4], bitdepth);
+}
+template <typename PIX> __global__ __launch_bounds__(64) void k_kat_average(const PIX* a, const PIX* b, int size, PIX* out) {
+  const Team t = mk_team((int)threadIdx.x, 64);
+  const size_t o = (size_t)blockIdx.x * (size * size * 3 / 2);
+  const int n = size * size, c = n / 4;
+  average_yuv<SP_GLOBAL>(t, out + o, out + o + n, out + o + n + c, a + o, a + o + n, a + o + n + c, b + o, b + o + n, b + o + n + c, size, size, size);
+}
+template <typename PIX>
+__global__ __launch_bounds__(64) void k_kat_cfl(const PIX* y, PIX* uv, const PIX* ry, int n, int bitdepth) {
+  const Team t = mk_team((int)threadIdx.x, 64);
+  const int it = blockIdx.x, c = (n / 2) * (n / 2);
+  improve_uv<PIX, SP_GLOBAL>(t, nullptr, y + (size_t)it * n * n, uv + (size_t)it * 2 * c, uv + (size_t)it * 2 * c + c, ry + (size_t)it * n * n, n, n, n, bitdepth);
+}
+template <typename PIX> __global__ void k_kat_cdef_dir(const PIX* blocks, int n, int cs, int* dir, int* var) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  int v = 0;
+  dir[i] = cdef_find_dir(blocks + (size_t)i * 64, 8, &v, cs);
+  var[i] = v;
+}
+template <typename PIX>
+__global__ __launch_bounds__(64) void k_kat_cdef_filter(const PIX* plane, int w, int h, int stride, int bsize, int cs, const int* par, PIX* out) {
+  const int it = blockIdx.x, k = threadIdx.x;
+  if (k >= bsize * bsize) return;
+  const int* q = par + 7 * it;   // x0, y0, pri, sec, dir, pri_damping, sec_damping
+  const int x = q[0] + k % bsize, y = q[1] + k / bsize;
+  out[(size_t)it * bsize * bsize + k] = (PIX)cdef_filter_px(plane, stride, x, y, w, h, q[2], q[3], q[4], q[5], q[6], cs);
+}
 }  // namespace tk
 
 template <typename T> static T* to_dev(const T* h, size_t n) {
@@ -1188,4 +1260,230 @@ extern "C" int thor_hip_deblock_frame(uint8_t* yuv, int width, int height, int q
 extern "C" int thor_hip_deblock_frame_hbd(uint16_t* yuv, int width, int height, int qp, int bitdepth, const thor_hip_cell* cells) {
   if (bitdepth < 9 || bitdepth > 12) return 1;
   return kat_deblock_frame<uint16_t>(yuv, width, height, qp, bitdepth, cells);
+}
+
+// ---- round 6: known-answer entry points for intra prediction, inter prediction of a whole block (luma + chroma, quadrant split), the
+// bi-prediction average, chroma-from-luma, the CDEF direction search / filter, CLPF and the temporally interpolated reference --------------
+namespace {
+template <typename PIX>
+int kat_intra(const PIX* plane, int width, int height, int stride, int bitdepth, int size, int tb_split, int n, const int* par, const PIX* rblocks, PIX* out) {
+  if (!plane || !par || !out || n <= 0 || size < 4 || size > 64 || (size & (size - 1)) || (tb_split && !rblocks) || stride < width) return 1;
+  const int cbs = tb_split ? 2 * size : size;
+  for (int i = 0; i < n; i++) {
+    const int* q = par + 7 * i;
+    if (q[0] < 0 || q[1] < 0 || q[0] + cbs > height || q[1] + cbs > width || q[4] < 0 || q[5] < 0 || q[6] < 0 || q[5] + size > cbs || q[6] + size > cbs) return 2;
+    if ((q[2] && q[1] + 2 * cbs > width) || (q[3] && q[0] + 2 * cbs > height)) return 2;   // up-right / down-left samples must exist
+  }
+  if (!ensure_init(g_inited ? g_device : 0)) return 3;
+  PIX* d_p = to_dev(plane, (size_t)stride * height);
+  int* d_par = to_dev(par, (size_t)7 * n);
+  PIX* d_rb = tb_split ? to_dev(rblocks, (size_t)n * cbs * cbs) : nullptr;
+  PIX* d_o = to_dev<PIX>(nullptr, (size_t)n * size * size);
+  hipLaunchKernelGGL(k_kat_intra<PIX>, dim3(n), dim3(64), 0, g_stream, d_p, stride, bitdepth, size, tb_split, d_par, d_rb, d_o);
+  HIPCHECK(hipGetLastError());
+  backend::d2h(out, d_o, (size_t)n * size * size * sizeof(PIX));
+  backend::dev_free(d_p); backend::dev_free(d_par); if (d_rb) backend::dev_free(d_rb); backend::dev_free(d_o);
+  return 0;
+}
+// frame with the reference windows' replicate padding (what k_make_ref produces from a reconstruction)
+template <typename PIX> DevFrame<PIX> kat_padded_ref(const PIX* yuv, int width, int height) {
+  DevFrame<PIX> rec, ref;
+  rec.alloc(width, height, 0);
+  ref.alloc(width, height, kPadY);
+  const size_t B = sizeof(PIX);
+  const PIX* hu = yuv + (size_t)width * height;
+  const PIX* hv = hu + (size_t)(width / 2) * (height / 2);
+  HIPCHECK(hipMemcpy2D(rec.p.y, rec.p.sy * B, yuv, width * B, width * B, height, hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy2D(rec.p.u, rec.p.sc * B, hu, width / 2 * B, width / 2 * B, height / 2, hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy2D(rec.p.v, rec.p.sc * B, hv, width / 2 * B, width / 2 * B, height / 2, hipMemcpyHostToDevice));
+  FrameJob<PIX> J;
+  memset(&J, 0, sizeof(J));
+  J.cfg.width = width; J.cfg.height = height; J.rec = rec.p;
+  backend::run_make_ref<PIX>(&J, &ref.p, 1);
+  backend::dev_sync();
+  rec.release();
+  return ref;
+}
+template <typename PIX>
+int kat_inter_yuv(const PIX* yuv, int width, int height, int bitdepth, int size, int n, const int* par, const int16_t* mv, PIX* out) {
+  if (!yuv || !par || !mv || !out || n <= 0 || size < 8 || size > 128 || (size & (size - 1)) || width % 8 || height % 8) return 1;
+  for (int i = 0; i < n; i++) {
+    const int* q = par + 5 * i;
+    if (q[0] < 0 || q[1] < 0 || q[0] + size > height || q[1] + size > width || (q[4] && size < 16)) return 2;
+  }
+  if (!ensure_init(g_inited ? g_device : 0)) return 3;
+  DevFrame<PIX> ref = kat_padded_ref(yuv, width, height);
+  int* d_par = to_dev(par, (size_t)5 * n);
+  int16_t* d_mv = to_dev(mv, (size_t)8 * n);
+  const size_t per = (size_t)size * size * 3 / 2;
+  PIX* d_o = to_dev<PIX>(nullptr, per * n);
+  hipLaunchKernelGGL(k_kat_inter_yuv<PIX>, dim3(n), dim3(64), 0, g_stream, ref.p, width, height, bitdepth, size, d_par, d_mv, d_o);
+  HIPCHECK(hipGetLastError());
+  backend::d2h(out, d_o, per * n * sizeof(PIX));
+  backend::dev_free(d_par); backend::dev_free(d_mv); backend::dev_free(d_o);
+  ref.release();
+  return 0;
+}
+template <typename PIX> int kat_average(const PIX* a, const PIX* b, int size, int n, PIX* out) {
+  if (!a || !b || !out || n <= 0 || size < 8 || size > 128 || (size & (size - 1))) return 1;
+  if (!ensure_init(g_inited ? g_device : 0)) return 3;
+  const size_t tot = (size_t)n * size * size * 3 / 2;
+  PIX* d_a = to_dev(a, tot);
+  PIX* d_b = to_dev(b, tot);
+  PIX* d_o = to_dev<PIX>(nullptr, tot);
+  hipLaunchKernelGGL(k_kat_average<PIX>, dim3(n), dim3(64), 0, g_stream, d_a, d_b, size, d_o);
+  HIPCHECK(hipGetLastError());
+  backend::d2h(out, d_o, tot * sizeof(PIX));
+  backend::dev_free(d_a); backend::dev_free(d_b); backend::dev_free(d_o);
+  return 0;
+}
+template <typename PIX> int kat_cfl(const PIX* y, PIX* uv, const PIX* ry, int nl, int bitdepth, int n) {
+  if (!y || !uv || !ry || n <= 0 || nl < 8 || nl > 128 || (nl & (nl - 1))) return 1;
+  if (!ensure_init(g_inited ? g_device : 0)) return 3;
+  const size_t ny = (size_t)n * nl * nl, nc = (size_t)n * 2 * (nl / 2) * (nl / 2);
+  PIX* d_y = to_dev(y, ny);
+  PIX* d_r = to_dev(ry, ny);
+  PIX* d_uv = to_dev((const PIX*)uv, nc);
+  hipLaunchKernelGGL(k_kat_cfl<PIX>, dim3(n), dim3(64), 0, g_stream, d_y, d_uv, d_r, nl, bitdepth);
+  HIPCHECK(hipGetLastError());
+  backend::d2h(uv, d_uv, nc * sizeof(PIX));
+  backend::dev_free(d_y); backend::dev_free(d_r); backend::dev_free(d_uv);
+  return 0;
+}
+template <typename PIX> int kat_cdef_dir(const PIX* blocks, int bitdepth, int n, int* dir, int* var) {
+  if (!blocks || !dir || !var || n <= 0) return 1;
+  if (!ensure_init(g_inited ? g_device : 0)) return 3;
+  PIX* d_b = to_dev(blocks, (size_t)n * 64);
+  int* d_d = to_dev<int>(nullptr, n);
+  int* d_v = to_dev<int>(nullptr, n);
+  hipLaunchKernelGGL(k_kat_cdef_dir<PIX>, dim3((n + 63) / 64), dim3(64), 0, g_stream, d_b, n, bitdepth - 8, d_d, d_v);
+  HIPCHECK(hipGetLastError());
+  backend::d2h(dir, d_d, (size_t)n * 4); backend::d2h(var, d_v, (size_t)n * 4);
+  backend::dev_free(d_b); backend::dev_free(d_d); backend::dev_free(d_v);
+  return 0;
+}
+template <typename PIX> int kat_cdef_filter(const PIX* plane, int w, int h, int stride, int bitdepth, int bsize, int n, const int* par, PIX* out) {
+  if (!plane || !par || !out || n <= 0 || (bsize != 4 && bsize != 8) || stride < w) return 1;
+  for (int i = 0; i < n; i++) {
+    const int* q = par + 7 * i;
+    if (q[0] < 0 || q[1] < 0 || q[0] + bsize > w || q[1] + bsize > h || q[4] < 0 || q[4] > 7) return 2;
+  }
+  if (!ensure_init(g_inited ? g_device : 0)) return 3;
+  PIX* d_p = to_dev(plane, (size_t)stride * h);
+  int* d_par = to_dev(par, (size_t)7 * n);
+  PIX* d_o = to_dev<PIX>(nullptr, (size_t)n * bsize * bsize);
+  hipLaunchKernelGGL(k_kat_cdef_filter<PIX>, dim3(n), dim3(64), 0, g_stream, d_p, w, h, stride, bsize, bitdepth - 8, d_par, d_o);
+  HIPCHECK(hipGetLastError());
+  backend::d2h(out, d_o, (size_t)n * bsize * bsize * sizeof(PIX));
+  backend::dev_free(d_p); backend::dev_free(d_par); backend::dev_free(d_o);
+  return 0;
+}
+template <typename PIX> void kat_upload(DevFrame<PIX>& f, const PIX* yuv, int width, int height) {
+  const size_t B = sizeof(PIX);
+  const PIX* hu = yuv + (size_t)width * height;
+  const PIX* hv = hu + (size_t)(width / 2) * (height / 2);
+  HIPCHECK(hipMemcpy2D(f.p.y, f.p.sy * B, yuv, width * B, width * B, height, hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy2D(f.p.u, f.p.sc * B, hu, width / 2 * B, width / 2 * B, height / 2, hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy2D(f.p.v, f.p.sc * B, hv, width / 2 * B, width / 2 * B, height / 2, hipMemcpyHostToDevice));
+}
+template <typename PIX> void kat_download(const DevFrame<PIX>& f, PIX* yuv, int width, int height) {
+  const size_t B = sizeof(PIX);
+  PIX* hu = yuv + (size_t)width * height;
+  PIX* hv = hu + (size_t)(width / 2) * (height / 2);
+  HIPCHECK(hipMemcpy2D(yuv, width * B, f.p.y, f.p.sy * B, width * B, height, hipMemcpyDeviceToHost));
+  HIPCHECK(hipMemcpy2D(hu, width / 2 * B, f.p.u, f.p.sc * B, width / 2 * B, height / 2, hipMemcpyDeviceToHost));
+  HIPCHECK(hipMemcpy2D(hv, width / 2 * B, f.p.v, f.p.sc * B, width / 2 * B, height / 2, hipMemcpyDeviceToHost));
+}
+// CLPF: the two device passes of the product (statistics per 8x8 block, filter per 8x8 luma / 4x4 chroma unit) on one frame.
+template <typename PIX>
+int kat_clpf(const PIX* rec_yuv, const PIX* org_yuv, int width, int height, int bitdepth, int qp, const thor_hip_cell* cells, const int* strength, int fb_log2,
+             const uint8_t* fb_on, uint32_t* stats, PIX* out_yuv) {
+  if (!rec_yuv || !org_yuv || !cells || !strength || !fb_on || !stats || !out_yuv || width % 16 || height % 16 || fb_log2 < 5 || fb_log2 > 7) return 1;
+  if (!ensure_init(g_inited ? g_device : 0)) return 3;
+  DevFrame<PIX> rec, src, org;
+  rec.alloc(width, height, 0); src.alloc(width, height, 0); org.alloc(width, height, 0);
+  kat_upload(rec, rec_yuv, width, height); kat_upload(src, rec_yuv, width, height); kat_upload(org, org_yuv, width, height);
+  const size_t ncell = (size_t)(width / 4) * (height / 4);
+  DbCell* d_cells = to_dev((const DbCell*)cells, ncell);
+  const int nblk = (width / 8) * (height / 8) + 2 * (width / 16) * (height / 16);
+  const int nfb = ((width + (1 << fb_log2) - 1) >> fb_log2) * ((height + (1 << fb_log2) - 1) >> fb_log2);
+  uint32_t* d_stats = to_dev<uint32_t>(nullptr, (size_t)4 * nblk);
+  uint8_t* d_on = to_dev(fb_on, (size_t)nfb);
+  ClpfJob<PIX> J;
+  memset(&J, 0, sizeof(J));
+  J.rec = rec.p; J.src = src.p; J.org = org.p; J.width = width; J.height = height; J.bitdepth = bitdepth; J.qp = qp;
+  J.cells = d_cells; J.cs = width / 4; J.stats = d_stats;
+  for (int k = 0; k < 3; k++) J.strength[k] = strength[k];
+  J.fb_log2 = fb_log2; J.fb_on = d_on;
+  ClpfJob<PIX>* d_job = to_dev(&J, 1);
+  backend::run_clpf_stats<PIX>(d_job, &J, 1);
+  backend::run_clpf_apply<PIX>(d_job, &J, 1);
+  backend::dev_sync();
+  backend::d2h(stats, d_stats, (size_t)4 * nblk * 4);
+  kat_download(rec, out_yuv, width, height);
+  backend::dev_free(d_cells); backend::dev_free(d_stats); backend::dev_free(d_on); backend::dev_free(d_job);
+  rec.release(); src.release(); org.release();
+  return 0;
+}
+// interpolate_frames(new, ref0, ref1, 2, 1) (common/temporal_interp.c:909) through the engine's own path (Engine::make_interp_frames, tk_interp_dev.h)
+template <typename PIX> int kat_interpolate(const PIX* yuv0, const PIX* yuv1, int width, int height, int bitdepth, PIX* out_yuv) {
+  if (!yuv0 || !yuv1 || !out_yuv || width % 8 || height % 8 || width < 64 || height < 64) return 1;
+  if (!ensure_init(g_inited ? g_device : 0)) return 3;
+  SeqParams sp;
+  sp.width = width; sp.height = height; sp.bitdepth = bitdepth; sp.input_bitdepth = bitdepth;
+  sp.num_reorder_pics = 7; sp.interp_ref = 1; sp.max_num_ref = 2; sp.HQperiod = 8; sp.cdef = 0; sp.clpf = 0;
+  Engine<PIX>* eng = new Engine<PIX>();
+  eng->open(sp, 1);
+  Stream<PIX>& q = eng->st[0];
+  for (int k = 0; k < 2; k++) {
+    kat_upload(q.rec, k ? yuv1 : yuv0, width, height);
+    FrameJob<PIX> J;
+    memset(&J, 0, sizeof(J));
+    J.cfg.width = width; J.cfg.height = height; J.rec = q.rec.p;
+    backend::run_make_ref<PIX>(&J, &q.ring[k].p, 1);
+    backend::dev_sync();
+  }
+  std::vector<FrameParams> fp(1);
+  fp[0].interp_ref = 1; fp[0].interp_src[0] = 0; fp[0].interp_src[1] = 1; fp[0].frame_num = 1;
+  eng->make_interp_frames(fp, 0, 1);
+  backend::dev_sync();
+  kat_download(q.interp, out_yuv, width, height);
+  eng->close();
+  delete eng;
+  return 0;
+}
+}  // namespace
+#define KAT_BD(call8, call16) do { if (bitdepth == 8) return call8; if (bitdepth >= 9 && bitdepth <= 12) return call16; return 1; } while (0)
+extern "C" int thor_hip_kat_intra(const void* plane, int width, int height, int stride, int bitdepth, int size, int tb_split, int n, const int* par,
+                                  const void* rblocks, void* out) {
+  KAT_BD(kat_intra<uint8_t>((const uint8_t*)plane, width, height, stride, 8, size, tb_split, n, par, (const uint8_t*)rblocks, (uint8_t*)out),
+         kat_intra<uint16_t>((const uint16_t*)plane, width, height, stride, bitdepth, size, tb_split, n, par, (const uint16_t*)rblocks, (uint16_t*)out));
+}
+extern "C" int thor_hip_kat_inter_yuv(const void* yuv, int width, int height, int bitdepth, int size, int n, const int* par, const int16_t* mv, void* out) {
+  KAT_BD(kat_inter_yuv<uint8_t>((const uint8_t*)yuv, width, height, 8, size, n, par, mv, (uint8_t*)out),
+         kat_inter_yuv<uint16_t>((const uint16_t*)yuv, width, height, bitdepth, size, n, par, mv, (uint16_t*)out));
+}
+extern "C" int thor_hip_kat_average(const void* a, const void* b, int size, int bitdepth, int n, void* out) {
+  KAT_BD(kat_average<uint8_t>((const uint8_t*)a, (const uint8_t*)b, size, n, (uint8_t*)out),
+         kat_average<uint16_t>((const uint16_t*)a, (const uint16_t*)b, size, n, (uint16_t*)out));
+}
+extern "C" int thor_hip_kat_cfl(const void* y, void* uv, const void* ry, int n_luma, int bitdepth, int n) {
+  KAT_BD(kat_cfl<uint8_t>((const uint8_t*)y, (uint8_t*)uv, (const uint8_t*)ry, n_luma, 8, n),
+         kat_cfl<uint16_t>((const uint16_t*)y, (uint16_t*)uv, (const uint16_t*)ry, n_luma, bitdepth, n));
+}
+extern "C" int thor_hip_kat_cdef_dir(const void* blocks, int bitdepth, int n, int* dir, int* var) {
+  KAT_BD(kat_cdef_dir<uint8_t>((const uint8_t*)blocks, 8, n, dir, var), kat_cdef_dir<uint16_t>((const uint16_t*)blocks, bitdepth, n, dir, var));
+}
+extern "C" int thor_hip_kat_cdef_filter(const void* plane, int width, int height, int stride, int bitdepth, int bsize, int n, const int* par, void* out) {
+  KAT_BD(kat_cdef_filter<uint8_t>((const uint8_t*)plane, width, height, stride, 8, bsize, n, par, (uint8_t*)out),
+         kat_cdef_filter<uint16_t>((const uint16_t*)plane, width, height, stride, bitdepth, bsize, n, par, (uint16_t*)out));
+}
+extern "C" int thor_hip_kat_clpf(const void* rec_yuv, const void* org_yuv, int width, int height, int bitdepth, int qp, const thor_hip_cell* cells,
+                                 const int* strength, int fb_log2, const uint8_t* fb_on, uint32_t* stats, void* out_yuv) {
+  KAT_BD(kat_clpf<uint8_t>((const uint8_t*)rec_yuv, (const uint8_t*)org_yuv, width, height, 8, qp, cells, strength, fb_log2, fb_on, stats, (uint8_t*)out_yuv),
+         kat_clpf<uint16_t>((const uint16_t*)rec_yuv, (const uint16_t*)org_yuv, width, height, bitdepth, qp, cells, strength, fb_log2, fb_on, stats, (uint16_t*)out_yuv));
+}
+extern "C" int thor_hip_kat_interpolate(const void* yuv0, const void* yuv1, int width, int height, int bitdepth, void* out_yuv) {
+  KAT_BD(kat_interpolate<uint8_t>((const uint8_t*)yuv0, (const uint8_t*)yuv1, width, height, 8, (uint8_t*)out_yuv),
+         kat_interpolate<uint16_t>((const uint16_t*)yuv0, (const uint16_t*)yuv1, width, height, bitdepth, (uint16_t*)out_yuv));
 }

@@ -58,14 +58,8 @@ struct WgShared {
   mv_t ref_mv[kMaxRefs][4][4];   // [reference][partition][quadrant]
   // bi-prediction search of P frames, run by all waves in lock step (bipred_par)
   const void* bp_org8;           // 2*org - pred of the current step (leader's buffer)
-  unsigned bp_sad[kMaxRefs];
-  mv_t bp_mv[kMaxRefs][4];
   unsigned bp_sad2[2][kMaxRefs];   // results of a lock-step search step, double-buffered (bipred_par)
   mv_t bp_mv2[2][kMaxRefs][4];
-  unsigned bp_min_sad;
-  int bp_skip[4];                // per step: its inputs equal those of the previous step of the same list (see bipred_par)
-  int bp_ref0, bp_ref1;
-  mv_t bp_min0[4], bp_min1[4];
   // B frames: the telescope of the joint +mv / -mv search (motion_estimate_bi) runs as a queue item of its own (MD_BIJOINT) as soon as
   // the PART_NONE vector of its first reference is known; whoever gets there first - the item or the bi-prediction item that
   // needs its result - claims it (0 -> 1) and publishes the result (-> 2)
@@ -1542,7 +1536,7 @@ TK_DEVNI void bipred_par(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, Md
         const mv_t mvc_ = clip_mv(mo[0], nd.ypos, nd.xpos, c.width, c.height, size, size, sgn);
         const SubPel sp = luma_setup(mvc_, sgn, size, size, c.width, c.height, nd.xpos, nd.ypos, c.enable_bipred);
         const PIX* ry = rp.y + nd.ypos * rp.sy + nd.xpos;
-        const int rows = size / wg.nwaves > 0 ? size / wg.nwaves : size, r0 = wg.wave * rows, r1 = size / wg.nwaves > 0 ? r0 + rows : (wg.wave == 0 ? size : 0);
+        const int rows = (size + wg.nwaves - 1) / wg.nwaves, r0 = tmin(size, wg.wave * rows), r1 = tmin(size, r0 + rows);   // every row has an owner for any wave count
         const auto o8 = spc<SP>(org8);
         const auto oys = spc<SP>(ws->org_y);
         const int osy = ws->org_sy;
@@ -1591,7 +1585,7 @@ TK_DEVNI void bipred_par(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, Md
 
 // Executed by every wave of the workgroup between the fork and the join barrier.
 template <typename PIX, int SP>
-TK_DEVNI void md_worker_sp(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws) {
+TK_MDW void md_worker_sp(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws) {
   WgShared* sh_ = ws->sh;
   const auto sh = ldsc(sh_);
   MdCtx<PIX> M;
@@ -1695,7 +1689,7 @@ TK_DEV void wg_helper_loop(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws) 
 
 // Master side.  Result in nd.best; returns min cost.
 template <typename PIX>
-TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int node, int* win_wave) {
+TK_MDW unsigned mode_decision_par(const Wg wg, const Team t, JobR<PIX> J, WsP<PIX> ws, int node, int* win_wave) {
   const auto& c = J.cfg;
   WgShared* sh_ = ws->sh;
   const auto sh = ldsc(sh_);
@@ -1727,8 +1721,7 @@ TK_DEVNI unsigned mode_decision_par(const Wg wg, const Team t, JobR<PIX> J, WsP<
     sh->n_items = n; sh->next_item = 0;
     sh->refs_done = 0; sh->n_ref_items = inter ? J.num_ref : 0;
     sh->do_bipred = (inter && J.num_ref > 1 && c.enable_bipred) ? (J.frame_type == F_P ? 2 : 1) : 0;
-    sh->bp_min_sad = 1u << 30; sh->bp_ref0 = 0; sh->bp_ref1 = 0; sh->bj_state = 0;
-    for (int i = 0; i < 4; i++) { lds_st(&sh_->bp_min0[i], mvp); lds_st(&sh_->bp_min1[i], mvp); }
+    sh->bj_state = 0;
     sh->node = node; lds_st(&sh_->mvp, mvp);
     sh->bestkey = ~0ull;
     for (int w = 0; w < kWaves; w++) sh->wkey[w] = ~0ull;

@@ -37,6 +37,15 @@
 #if TK_HOST
 #define TK_DEVNI static
 #endif
+// The fork/join functions of a block decision (tk_block.h: md_worker_sp, mode_decision_par) save and restore every callee-saved register of the
+// 168-VGPR budget (64 VGPRs + 36 SGPRs) on every wave of every decision although their callers keep nothing in them.  -DTK_MDW_INLINE inlines
+// them into the kernel: measured in round 6 (profiles/r06_traffic_attribution.md) - HBM-side traffic -6 % (3 of 20 store instructions per pixel
+// gone), throughput -0.9 %: the scratch traffic is waste, not the limiter, and the calls stay.
+#if defined(TK_MDW_INLINE)
+#define TK_MDW TK_DEV
+#else
+#define TK_MDW TK_DEVNI
+#endif
 
 namespace tk {
 
@@ -123,7 +132,10 @@ struct BlockTeam {
 // teams) or a single wave (everything else).
 // ---------------------------------------------------------------------------------
 #if !TK_HOST
-enum { kWaves = 4 };
+#ifndef TK_WAVES
+#define TK_WAVES 4
+#endif
+enum { kWaves = TK_WAVES };   // wavefronts per workgroup = per superblock in flight (A/B builds: -DTK_WAVES=1 / 2)
 #elif defined(THOR_HOSTSIM_WAVES)
 enum { kWaves = THOR_HOSTSIM_WAVES };
 #else

@@ -424,6 +424,10 @@ TK_DEVNI unsigned long long me_cand8_fullpel(const Team t, MeWs* w_, const uint8
   auto lane_cost = [&](mv_t m, int valid, auto wide_tag, unsigned* osel) -> unsigned {
     constexpr int WIDE = decltype(wide_tag)::value;
     m = clip_mv(m, ypos, xpos, fw, fh, cb, cb, sign);
+    {  // lanes without a candidate evaluate lane 0's vector (always a candidate) and drop the result: their own may point outside the staged window
+      const int mp0 = team_bcast0(t, (int)(uint16_t)m.x | ((int)m.y << 16));
+      if (!valid) m = mk_mv((int16_t)(mp0 & 0xffff), mp0 >> 16);
+    }
     const int dx = s * (m.x >> 2), dy = s * (m.y >> 2);
     const int x0 = dx - (WIDE ? 3 : 0), x1 = dx + (WIDE ? 3 : 0);
     const int outside = valid && !(x0 >= win.ox && x1 + width <= win.ox + win.Ww && dy >= win.oy && dy + height <= win.oy + win.Wh);

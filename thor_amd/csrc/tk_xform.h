@@ -150,9 +150,12 @@ template <int SP, typename PIX, int NS> TK_DEV void store_samples(PIX* p, const 
   }
 #endif
 }
-// box sum of one scale x scale cell of the residual, rows of NS = scale samples per memory instruction (transform.c:262-277: the
-// running sum saturates after every sample, in raster order)
-template <int SP, typename PIX, int NS> TK_DEV int box_residual(const PIX* org, int ostride, const PIX* pred, int pstride) {
+// box sum of one scale x scale cell of the residual, rows of NS = scale samples per memory instruction.  What the reference EXECUTES is
+// transform_simd (common/common_kernels.c:1482-1562, use_simd = 1): with `fast` (encoder_speed > 1) the running sum saturates to
+// [-16384, 16383] after every sample, in raster order (:1526-1531); WITHOUT it the cell is a plain int16_t accumulation that wraps (:1545-1550) -
+// the scalar code (transform.c:262-277) saturates in both cases.  The two differ only when a cell's sum leaves +-16383: never up to 10 bits
+// (16 x 1023), but at 12 bits a 4x4 cell of a 128x128 block reaches 16 x 4095 (found by the 12-bit known answers of round 6).
+template <int SP, typename PIX, int NS> TK_DEV int box_residual(const PIX* org, int ostride, const PIX* pred, int pstride, int sat) {
   int sum = 0;
 #if !TK_HOST
 #pragma nounroll   // a rolled row loop: unrolled, the compiler fetches and unpacks all NS x NS samples at once (VGPR budget of the 8-bit kernel)
@@ -161,7 +164,7 @@ template <int SP, typename PIX, int NS> TK_DEV int box_residual(const PIX* org, 
     int o[NS], p[NS];
     load_samples<SP, PIX, NS>(org + m * ostride, o);
     load_samples<SP, PIX, NS>(pred + m * pstride, p);
-    for (int n = 0; n < NS; n++) sum = clampi((int16_t)sum + (int16_t)(o[n] - p[n]), -16384, 16383);
+    for (int n = 0; n < NS; n++) { const int v = (int16_t)sum + (int16_t)(o[n] - p[n]); sum = sat ? clampi(v, -16384, 16383) : (int)(int16_t)v; }
   }
   return sum;
 }
@@ -189,7 +192,7 @@ TK_DEV void fwd_transform(const Team t, XformWs* ws, const PIX* org_, int ostrid
     size1 = 32 >> fast;
     scale = size / size1;
   }
-  // residual (+ optional saturating box sum, transform.c:262-277)
+  // residual (+ optional box sum, common_kernels.c:1521-1556)
   lds_i16* const in_l = TK_LDS_PTR(ws->in);
 #ifndef TK_NOVEC
   {
@@ -223,8 +226,8 @@ TK_DEV void fwd_transform(const Team t, XformWs* ws, const PIX* org_, int ostrid
           split2(mk_pow2(size1), k, i, j);
           const PIX* o = org_ + i * scale * ostride + j * scale;
           const PIX* p = pred_ + i * scale * pstride + j * scale;
-          in_l[i * size1 + j] = (int16_t)(scale == 2 ? box_residual<SP, PIX, 2>(o, ostride, p, pstride)
-                                          : scale == 4 ? box_residual<SP, PIX, 4>(o, ostride, p, pstride) : box_residual<SP, PIX, 8>(o, ostride, p, pstride));
+          in_l[i * size1 + j] = (int16_t)(scale == 2 ? box_residual<SP, PIX, 2>(o, ostride, p, pstride, fast)
+                                          : scale == 4 ? box_residual<SP, PIX, 4>(o, ostride, p, pstride, fast) : box_residual<SP, PIX, 8>(o, ostride, p, pstride, fast));
         }
       }
       t.sync();
@@ -244,7 +247,7 @@ TK_DEV void fwd_transform(const Team t, XformWs* ws, const PIX* org_, int ostrid
         for (int n = 0; n < scale; n++) {
           int y = i * scale + m, x = j * scale + n;
           int r = (int16_t)((int)org[y * ostride + x] - (int)pred[y * pstride + x]);
-          sum = clampi((int16_t)sum + r, -16384, 16383);
+          sum = fast ? clampi((int16_t)sum + r, -16384, 16383) : (int)(int16_t)((int16_t)sum + r);   // transform_simd: see box_residual
         }
     }
     in_l[i * size1 + j] = (int16_t)sum;
