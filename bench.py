@@ -310,10 +310,20 @@ def one_frame_baseline(t_hi, t_lo, frame_px, what):
     return v, d_cpu, d_wall
 
 
+def base_n_lo(reordered, warmup, nv):
+    """Length of the shorter of the two full-geometry baseline legs.  Low delay: the warm-up frames, so that the difference to the nv-frame leg is the
+    TIMED coded frames warmup..nv-1 at the benched geometry (round 6; it was nv - 1 = one frame); when the live leg does not reach into the timed
+    region, one frame less.  Frame reordering: the I frame alone (the difference is every other frame of the chunk)."""
+    if reordered:
+        return 1
+    return warmup if 1 <= warmup < nv else nv - 1
+
+
 def cpu_baseline_object(times, base_tag, tf_legs, nv, n_ref, reordered, a, p, w, h, cw, ch, legs, world, my_ids, refs, qp, clipn):
-    """The cpu_baseline object of the line from the (wall, CPU seconds) of the reference legs."""
+    """The cpu_baseline object of the line from the (wall, CPU seconds) of the reference legs.  `value` is measured on the GPU box's host at the
+    geometry of `geometry` - the benched one unless --cpu-sample asked for a crop -: the CPU seconds of the timed frames the live leg reaches."""
     nframes = a.warmup + a.steps
-    n_lo = 1 if reordered else nv - 1
+    n_lo = base_n_lo(reordered, a.warmup, nv)
     nproc = len(legs.procs)
     if not (n_lo >= 1 and n_lo < n_ref):
         raise RuntimeError(f'cpu_baseline needs two reference runs of different length (have {n_ref} frames)')
@@ -322,7 +332,8 @@ def cpu_baseline_object(times, base_tag, tf_legs, nv, n_ref, reordered, a, p, w,
     # aggregate of all concurrently running reference processes of the benched geometry: pixels coded / wall of the slowest
     same_geom = {k: t for k, t in times.items() if k[0] != 't'}
     agg = sum(n for (_, n) in same_geom) * float(cw) * ch / max(t[0] for t in same_geom.values()) / 1e6
-    what = (f'coded frame {nv - 1} ({min(int(p.max_num_ref), nv - 1)} references)' if not reordered
+    what = ((f'the TIMED coded frames {n_lo}..{nv - 1}' if n_lo == a.warmup and nv - n_lo > 1 else f'coded frame {nv - 1}') +
+            f' ({min(int(p.max_num_ref), nv - 1)} references)' if not reordered
             else f'coded frames 1..{n_ref - 1} of the chunk (everything but the I frame)')
     geom = (f'at the benched geometry {w}x{h}' if (cw, ch) == (w, h) else
             f'top-left {cw}x{ch} crop of the {w}x{h} frames (a bounded sample: the full-size reference run takes many minutes per stream)')
@@ -331,16 +342,17 @@ def cpu_baseline_object(times, base_tag, tf_legs, nv, n_ref, reordered, a, p, w,
     one = {'value': round(v1, 4), 'unit': 'Mpixels/s',
            'sample': f'stream {my_ids[0]} of the same workload, {geom}: {what} = CPU time (user + system, wait4 rusage) of the {n_ref}-frame run - of the '
                      f'{n_lo}-frame run = {t_hi[1]:.1f} s - {t_lo[1]:.1f} s = {d_cpu:.1f} s (wall until exit: {t_hi[0]:.1f} s - {t_lo[0]:.1f} s = {d_wall:.1f} s)'}
-    out = {'value': one['value'], 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'reference', 'sample': one['sample'] + '; ' + tail}
-    if tf_legs is not None:   # the figure over exactly the timed frames (LDB): it is the headline value
+    out = {'value': one['value'], 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'reference', 'geometry': f'{cw}x{ch}', 'host': 'the GPU box (live, beside the GPU run)',
+           'frames': list(range(n_lo, n_ref)), 'sample': one['sample'] + '; ' + tail}
+    if tf_legs is not None:   # every timed frame on a crop: a SECONDARY figure (round 6; it was the value, which then had another geometry than the GPU figure)
         tw, th = tf_legs
         t_hi, t_lo = times[('t', nframes)], times[('t', a.warmup)]
         vt, dt_cpu, dt_wall = one_frame_baseline(t_hi, t_lo, float(tw) * th * a.steps, {'frames_lo': a.warmup})
-        out['value'] = round(vt, 4)
-        out['sample'] = (f'stream {my_ids[0]} of the same workload, the TIMED coded frames {a.warmup}..{nframes - 1} on the top-left {tw}x{th} crop of the {w}x{h} frames (a bounded '
-                         f'sample: the full-size pair of runs takes {nframes * w * h / 0.3e6 / 60:.0f} minutes): CPU time (user + system, wait4 rusage) of the {nframes}-frame run - of the '
-                         f'{a.warmup}-frame run = {t_hi[1]:.1f} s - {t_lo[1]:.1f} s = {dt_cpu:.1f} s (wall until exit: {t_hi[0]:.1f} s - {t_lo[0]:.1f} s); ' + tail)
-        out['one_frame_full_geometry'] = one
+        out['all_timed_frames_on_a_crop'] = {
+            'value': round(vt, 4), 'unit': 'Mpixels/s', 'geometry': f'{tw}x{th}',
+            'sample': (f'stream {my_ids[0]}, ALL timed coded frames {a.warmup}..{nframes - 1} on the top-left {tw}x{th} crop of the {w}x{h} frames (the full-size pair of runs would take '
+                       f'{nframes * w * h / 0.3e6 / 60:.0f} minutes): CPU time of the {nframes}-frame run - of the {a.warmup}-frame run = {t_hi[1]:.1f} s - {t_lo[1]:.1f} s = {dt_cpu:.1f} s '
+                       f'(wall until exit: {t_hi[0]:.1f} s - {t_lo[0]:.1f} s)')}
     # the same difference at the full geometry, recorded in the build container (another host: reported, never the value)
     k_hi = refs.get(ref_key(a.config, w, h, a.bitdepth, qp, nframes, a.sigma, my_ids[0]))
     k_lo = refs.get(ref_key(a.config, w, h, a.bitdepth, qp, a.warmup, a.sigma, my_ids[0]) + f'_cpu_of_n{nframes}')
@@ -482,11 +494,15 @@ def main():
             if missing:
                 raise KeyError(f'--verify recorded: no recorded reference run for streams {missing} of this workload (scripts/record_bench_refs.py)')
     live = a.verify in ('auto', 'live') and not a.no_verify and rank == 0 and legs.available() and (cw, ch) == (w, h)
+    # N > 1 (round 6): rank 0 starts NO reference process beside the timed region of a weak-scaling figure when recorded reference runs verify the
+    # run anyway (every rank checks its own recorded streams); live legs remain the fall-back for workloads nobody recorded.  cpu_baseline: N = 1 only.
+    if world > 1 and live and recorded and a.verify == 'auto':
+        live = False
     if a.verify == 'recorded':
         nv = nframes
     verify = {}        # local stream index -> [host frames or None, {coded frame: (display index, md5 of the GPU reconstruction)}]
     do_verify = not a.no_verify and (live or bool(recorded))
-    do_base = rank == 0 and not a.no_cpu_baseline and legs.available()
+    do_base = rank == 0 and world == 1 and not a.no_cpu_baseline and legs.available()
     n_ref = nframes if reordered else nv   # with frame reordering the coding order depends on the chunk length: run it all
     vs_live = sorted({0, S // 2, S - 1}) if live else []
     for s_ in recorded:
@@ -510,7 +526,7 @@ def main():
             base_tag = f'v{my_ids[0]}'
             # second leg of the one-frame figure: one frame less (LDB: the difference is coded frame nv - 1 with every reference in
             # use); with frame reordering the I frame alone (the difference is every other frame of the chunk)
-            n_lo = 1 if reordered else nv - 1
+            n_lo = base_n_lo(reordered, a.warmup, nv)
             if n_lo >= 1 and n_lo < n_ref:
                 legs.start(base_tag, None, n_lo, False)
             # LDB: the CPU figure over EXACTLY the timed frames - a top-left crop of stream 0 (at most 1920x1080) coded with warmup + steps
@@ -623,6 +639,34 @@ def main():
         dt = reduce_max_time(dt, dist)
     total_px = float(w) * h * a.steps * S * world
     value = total_px / dt / 1e6
+
+    # ---- what the hand-over of HOST frames would add (measured, never part of `value`: the contract quotes value with the inputs resident in HBM) ----
+    # One step's worth of input frames (S frames, in pieces of at most 32 frames of pinned host memory) copied host-to-device after the timed region,
+    # timed with events: `io.h2d.value_including_h2d` adds that time to every step as if nothing overlapped it (a double-buffered upload would hide it
+    # behind the seconds a step takes).
+    h2d = None
+    if have_gpu and rank == 0:
+        try:
+            nb = min(S, 32)
+            hbuf = torch.empty(nb * fpx * bps, dtype=torch.uint8).pin_memory()
+            dbuf = torch.empty(nb * fpx * bps, dtype=torch.uint8, device=dev)
+            dbuf.copy_(hbuf, non_blocking=True)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range((S + nb - 1) // nb):
+                dbuf.copy_(hbuf, non_blocking=True)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) * S / (((S + nb - 1) // nb) * nb)
+            step_ms = dt * 1e3 / max(a.steps, 1)
+            h2d = {'ms_per_step': round(ms, 2), 'GB_per_s': round(S * fpx * bps / (ms / 1e3) / 1e9, 1), 'bytes_per_step': S * fpx * bps,
+                   'value_including_h2d': round(value * step_ms / (step_ms + ms), 3),
+                   'how': f'{S} frames of {fpx * bps / 1e6:.1f} MB from pinned host memory, copied after the timed region and timed with HIP events; added to every step '
+                          'without any overlap (an upper bound of the cost: the upload of the next frame can run while a step codes)'}
+            del hbuf, dbuf
+        except Exception as e:   # pinned memory is a host resource: a failure here must not take the line down
+            h2d = {'error': str(e)}
 
     # ---- output side: ordered gather of the chunk bitstreams to rank 0, totals by all-reduce ------------------------
     t_g = time.perf_counter()
@@ -779,14 +823,16 @@ def main():
                                  'DESIGN.md 8a) is what loads the memory system; filters+ref kernels took %.1f ms in the timed region' % filt_ms},
             'io': {'input_setup_s': round(t_in, 2), 'gather_s': round(t_g, 3), 'cpu_legs_wait_s': round(t_w, 1),
                    'stream_bytes_total': int(total_bytes), 'frames_total': int(total_frames),
-                   'inputs': 'resident in HBM before the timed region (staged device-to-device); host-to-device transfer of the input frames is EXCLUDED from value '
-                             f'(one {fpx * bps / 1e6:.1f} MB frame per stream and step: ~{S * fpx * bps / 50e9 * 1e3:.0f} ms per step at PCIe Gen5 rates); the device-to-host '
-                             'transfer of every stream\'s bits and of the verified reconstructions is inside it',
+                   'inputs': 'resident in HBM before the timed region (staged device-to-device), as the measurement contract quotes `value`; the host-to-device transfer of the '
+                             f'input frames is EXCLUDED from value and MEASURED beside it (io.h2d: one {fpx * bps / 1e6:.1f} MB frame per stream and step); the device-to-host '
+                             'transfer of every stream\'s bits and of the verified reconstructions is inside the timed region',
+                   'h2d': h2d,
                    'timed_region_ms_per_step': {'k_superblocks': round(sb_ms / max(a.steps, 1), 1), 'filters_reference_creation_bit_gather_kernels': round(filt_ms / max(a.steps, 1), 1),
                                                 'verified_reconstructions_d2h': round(verify_host_s[0] * 1e3 / max(a.steps, 1), 1),
                                                 'other_host_work_and_launch_gaps': round((dt * 1e3 - sb_ms - filt_ms - verify_host_s[0] * 1e3) / max(a.steps, 1), 1),
                                                 'note': 'rank-local figures of this rank; the kernels of a step do not overlap (a launch, then the filters of the stream group whose frame it completed)'},
-                   'rank0_host_load': f'{len(legs.procs)} reference processes (checker + cpu_baseline legs) ran on rank 0\'s host beside its GPU work; the other ranks ran none'},
+                   'rank0_host_load': (f'{len(legs.procs)} reference processes (checker + cpu_baseline legs) ran on rank 0\'s host beside its GPU work; the other ranks ran none' +
+                                       ('' if world == 1 or legs.procs else ' (N > 1: recorded reference runs verify every rank, no reference process runs beside a timed region)'))},
         }
         if stats:
             out['content'] = stats

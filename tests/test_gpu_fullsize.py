@@ -40,7 +40,8 @@ def _frames(c):
 
 
 @pytest.mark.parametrize('name', [n for n in ('1080p_ldb_n5_q32', '4k_ldb_n2_q32', '4k_hdb16_10bit_n3_q32', 'hdb16_416x240_10bit_n17_q32',
-                                              '4k_ra_n9_q27', '4k_ldb_n6_q32', '1080p_ldb_n14_q32', '4k_hdb16_10bit_n17_q32', '4k_ldb_sigma6_n6_q32') if n in BIG])
+                                              '4k_ra_n9_q27', '4k_ldb_n6_q32', '1080p_ldb_n14_q32', '4k_hdb16_10bit_n17_q32', '4k_ldb_sigma6_n6_q32',
+                                              '4k_ra_n17_q27', '4k_ldb_12bit_n3_q32') if n in BIG])   # round 6: two RA sub-GOPs at 3840x2160, 12-bit samples at 3840x2160
 def test_full_size_configuration_matches_reference_golden(name):
     c = BIG[name]
     bits, rec = _encode(c, [_frames(c)])

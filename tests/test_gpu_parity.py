@@ -77,10 +77,10 @@ def test_staggered_run_refuses_before_it_launches():
             for f in range(n - 1):                      # the last frame of the chunk is NOT staged yet
                 enc.stage(s, f, clip[(3 * s + f) * fsz:(3 * s + f + 1) * fsz])
             enc.begin_sequence(s, 3 * s, n, 6)
-        assert L.thor_hip_encode_staged_run(enc.h, n + 1, thor_amd.binding.FRAMES_DONE_FN(0), None) == 2   # a chunk has only n frames
         assert L.thor_hip_encode_staged_run(enc.h, n, thor_amd.binding.FRAMES_DONE_FN(0), None) == 3       # frame n - 1 is not staged
         for s in range(2):
             enc.stage(s, n - 1, clip[(3 * s + n - 1) * fsz:(3 * s + n) * fsz])
+        assert L.thor_hip_encode_staged_run(enc.h, n + 1, thor_amd.binding.FRAMES_DONE_FN(0), None) == 2   # a chunk has only n frames
         rec = [b'', b'']
 
         def done(first, count):
