@@ -1,4 +1,4 @@
-// unit_me_lanes.cpp - TEST INFRASTRUCTURE ONLY.  The motion search with one lane per candidate (tk_me.h: me_cand8_fullpel / me_cand8_subpel, taken
+// unit_me_lanes.cpp - TEST INFRASTRUCTURE ONLY.  The motion search with one lane per candidate (tk_me.h: me_cand_fullpel / me_cand8_subpel, taken
 // by teams of 64 lanes for 8-bit PUs of up to 32x32 samples) against the generic search (every other team size) on the CPU: the product's
 // motion_estimate runs the same sequence of searches twice - once with a team of 64 lanes (64 OS threads, the cross-lane primitives go through the
 // exchange below) and once with a 1-lane team - and vector and cost of every search must be equal.  On the MI355X the same comparison is made inside
@@ -45,11 +45,13 @@ struct Case { int pw, ph, cb; };
 struct Result { unsigned cost; mv_t mv; };
 
 // One sequence of searches (the per-"superblock" candidate list evolves along it) with a team of `lanes` lanes.
-static std::vector<Result> run_sequence(int lanes, const Case& c, int iters, const uint8_t* cur0, const uint8_t* ref0, int bipred, int sign, int window, unsigned seed, double lam = 9.5, int list_period = 8) {
+template <typename PIX>
+static std::vector<Result> run_sequence(int lanes, const Case& c, int iters, const PIX* cur0, const PIX* ref0, int bipred, int sign, int window, unsigned seed, double lam = 9.5, int list_period = 8,
+                                        int bitdepth = 8) {
   std::vector<Result> out(iters);
-  static MeWs ws; static MeLists lists; static uint32_t win[1200]; static uint8_t org[32 * 32]; static long long prof[32];
+  static MeWs ws; static MeLists lists; static uint32_t win[2400]; alignas(16) static PIX org[32 * 32]; static long long prof[32];
   memset(&ws, 0, sizeof(ws)); memset(&lists, 0, sizeof(lists));
-  ws.lists = &lists; ws.prof = prof; ws.win = window ? win : nullptr; ws.win_cap = window ? 4500 : 0; ws.cwin_valid = 0;   // no window: every candidate is read from the plane
+  ws.lists = &lists; ws.prof = prof; ws.win = window ? win : nullptr; ws.win_cap = window ? 4500 * (int)sizeof(PIX) : 0; ws.cwin_valid = 0;   // no window: every candidate is read from the plane
   hostlanes::Shared sh;
   sh.n = lanes;
   std::vector<std::thread> th;
@@ -59,7 +61,7 @@ static std::vector<Result> run_sequence(int lanes, const Case& c, int iters, con
       const Team t = mk_team(r, lanes);
       MeArgs a;
       a.cb_size = c.cb; a.ostride = c.pw; a.width = c.pw; a.height = c.ph; a.rstride = PITCH; a.sign = sign; a.fwidth = W; a.fheight = H;
-      a.enable_bipred = bipred; a.bitdepth = 8; a.speed = 0; a.lam = lam;
+      a.enable_bipred = bipred; a.bitdepth = bitdepth; a.speed = 0; a.lam = lam;
       unsigned rng = seed;
       for (int it = 0; it < iters; it++) {
         // positions all over the frame, its corners and edges included (clipped vectors, windows cut by the padding)
@@ -81,7 +83,7 @@ static std::vector<Result> run_sequence(int lanes, const Case& c, int iters, con
         }
         const mv_t mvc = (it % 5 == 4) ? mk_mv(mvp.x + 6, mvp.y - 9) : mvp;
         mv_t mv;
-        const unsigned cost = (unsigned)motion_estimate<uint8_t, SP_LDS>(t, &ws, org, ref0 + by * PITCH + bx, a, mvc, mvp, 0, &mv);
+        const unsigned cost = (unsigned)motion_estimate<PIX, SP_LDS>(t, &ws, org, ref0 + by * PITCH + bx, a, mvc, mvp, 0, &mv);
         if (r == 0) { out[it].cost = cost; out[it].mv = mv; add_mvcand(&ws, 0, mv); }
         t.sync();
       }
@@ -122,8 +124,8 @@ int main(int argc, char** argv) {
       const double lam = variant == 4 ? 28.3 : variant == 5 ? 2.1 : 9.5;
       const int period = variant == 4 ? 1000 : 8;
       const unsigned seed = 777u + (unsigned)c.pw * 31u + (unsigned)c.ph + 1000u * (unsigned)variant;
-      const std::vector<Result> a = run_sequence(64, c, iters, cur0, ref0, bipred, sign, window, seed, lam, period);
-      const std::vector<Result> b = run_sequence(1, c, iters, cur0, ref0, bipred, sign, window, seed, lam, period);
+      const std::vector<Result> a = run_sequence<uint8_t>(64, c, iters, cur0, ref0, bipred, sign, window, seed, lam, period);
+      const std::vector<Result> b = run_sequence<uint8_t>(1, c, iters, cur0, ref0, bipred, sign, window, seed, lam, period);
       for (int it = 0; it < iters; it++) {
         total++;
         if (a[it].cost != b[it].cost || a[it].mv.x != b[it].mv.x || a[it].mv.y != b[it].mv.y) {
@@ -133,7 +135,41 @@ int main(int argc, char** argv) {
       }
     }
   }
-  if (fails) { fprintf(stderr, "%d of %d searches differ\n", fails, total); return 1; }
-  printf("ok: %d searches, lane-per-candidate (64 lanes) == generic (1 lane)\n", total);
+  // Round 6: the same comparison on 16-bit samples (bitdepth 10: me_cand_fullpel<uint16_t> - full-pel passes with one lane per candidate and v_sad_u16;
+  // the sub-pel passes of 16-bit PUs stay generic), plain / future reference / no window / long list
+  int total16 = 0;
+  {
+    std::vector<uint16_t> cur16(cur.size()), ref16(ref.size());
+    unsigned r2 = 999u;
+    for (size_t i = 0; i < cur.size(); i++) {
+      r2 = r2 * 1664525u + 1013904223u;
+      ref16[i] = (uint16_t)(ref[i] * 4 + ((r2 >> 20) & 3)); cur16[i] = (uint16_t)(cur[i] * 4 + ((r2 >> 24) & 3));
+    }
+    const uint16_t* c16 = cur16.data() + (size_t)kPadY * PITCH + kPadY;
+    const uint16_t* r16 = ref16.data() + (size_t)kPadY * PITCH + kPadY;
+    ci = -1;
+    for (const Case& c : cases) {
+      ci++;
+      if (ci < first || ci >= first + count) continue;
+      for (int variant : {0, 1, 3, 4}) {
+        const int iters = c.pw * c.ph >= 512 ? 12 : 24;
+        const int sign = variant == 1, window = variant != 3;
+        const double lam = variant == 4 ? 28.3 : 9.5;
+        const int period = variant == 4 ? 1000 : 8;
+        const unsigned seed = 4242u + (unsigned)c.pw * 31u + (unsigned)c.ph + 1000u * (unsigned)variant;
+        const std::vector<Result> a = run_sequence<uint16_t>(64, c, iters, c16, r16, 1, sign, window, seed, lam, period, 10);
+        const std::vector<Result> b = run_sequence<uint16_t>(1, c, iters, c16, r16, 1, sign, window, seed, lam, period, 10);
+        for (int it = 0; it < iters; it++) {
+          total16++;
+          if (a[it].cost != b[it].cost || a[it].mv.x != b[it].mv.x || a[it].mv.y != b[it].mv.y) {
+            if (fails++ < 20) fprintf(stderr, "FAIL 16-bit PU %dx%d (CB %d) variant %d search %d: 64 lanes cost %u mv (%d, %d) != 1 lane cost %u mv (%d, %d)\n", c.pw, c.ph, c.cb, variant, it,
+                                      a[it].cost, a[it].mv.x, a[it].mv.y, b[it].cost, b[it].mv.x, b[it].mv.y);
+          }
+        }
+      }
+    }
+  }
+  if (fails) { fprintf(stderr, "%d of %d searches differ\n", fails, total + total16); return 1; }
+  printf("ok: %d searches (8-bit) + %d (16-bit), lane-per-candidate (64 lanes) == generic (1 lane)\n", total, total16);
   return 0;
 }

@@ -75,13 +75,25 @@ def test_sixteen_lane_teams_search_window_and_row_segments_vs_live_reference():
 @needs_ref
 def test_sixty_four_lane_teams_run_the_lane_per_candidate_search_vs_live_reference():
     """64-lane teams (the device's team size) on a 64x64 clip (I + 2 P; the second P frame searches two references and their bi-prediction): with 64 lanes the 8-bit PUs of up to
-    32x32 samples take the lane-per-candidate search (tk_me.h: me_cand8_fullpel / me_cand8_subpel) - the code the MI355X runs - inside a complete
+    32x32 samples take the lane-per-candidate search (tk_me.h: me_cand_fullpel / me_cand8_subpel) - the code the MI355X runs - inside a complete
     encode, on the CPU; stream and reconstruction must equal the live reference run.  (A whole small golden, 192x128 x 3 frames, was run this way once
     in round 5: profiles/r05_hostsim_l64.log - 64 OS threads per team make it too slow for the suite.)"""
     from thor_amd import synth
     clip = b''.join(p.tobytes() for fr in synth.make_clip(64, 64, 3, 13, 4.0) for p in fr)
     rb, rr = run_encoder(REF_ENC, clip, 64, 64, 3, 32)
     bits, rec = run_encoder(build_hostsim(lanes=64), clip, 64, 64, 3, 32)
+    assert bits == rb and rec == rr
+
+
+@needs_ref
+def test_sixty_four_lane_teams_16bit_lane_per_candidate_search_vs_live_reference():
+    """Round 6: the same on 10-bit samples - 64-lane teams take me_cand_fullpel<uint16_t> (v_sad_u16 on 16-byte segments, SAD >> 2) for the full-pel passes of
+    PUs up to 32x32 inside a complete encode (I + 2 P, 64x64); stream and reconstruction must equal the live reference run (_hbd path)."""
+    from thor_amd import synth
+    clip = b''.join(p.tobytes() for fr in synth.make_clip(64, 64, 3, 17, 4.0, 10) for p in fr)
+    ex = ['-bitdepth', '10', '-input_bitdepth', '10']
+    rb, rr = run_encoder(REF_ENC, clip, 64, 64, 3, 32, ex)
+    bits, rec = run_encoder(build_hostsim(lanes=64), clip, 64, 64, 3, 32, ex)
     assert bits == rb and rec == rr
 
 

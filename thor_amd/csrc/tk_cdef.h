@@ -193,18 +193,19 @@ template <typename PIX> TK_DEV void cdef_pass_dir(const CdefJob<PIX>& J, int gid
   }
 }
 
-// dist_8x8 (encode_frame.c:194-221): perceptually weighted 8x8 distortion, double arithmetic.
-template <typename PIX>
-TK_DEV unsigned long long cdef_dist8(const int* dst /*64 filtered*/, const PIX* org, int ostride, int cs) {
+// dist_8x8 (encode_frame.c:194-221): perceptually weighted 8x8 distortion, double arithmetic.  The five sums are accumulated sample by sample while
+// the block is filtered (round 6: the 64 filtered samples used to sit in a private array - 400 bytes of scratch per lane, a store and a load per sample).
+struct CdefDist {
   unsigned long long sum_s = 0, sum_d = 0, sum_s2 = 0, sum_d2 = 0, sum_sd = 0;
-  for (int i = 0; i < 8; i++)
-    for (int j = 0; j < 8; j++) {
-      unsigned long long s = org[i * ostride + j], d = (unsigned long long)dst[i * 8 + j];
-      sum_s += s; sum_d += d; sum_s2 += s * s; sum_d2 += d * d; sum_sd += s * d;
-    }
-  unsigned long long svar = sum_s2 - ((sum_s * sum_s + 32) >> 6);
-  unsigned long long dvar = sum_d2 - ((sum_d * sum_d + 32) >> 6);
-  double num = (double)(sum_d2 + sum_s2 - 2 * sum_sd) * .5;
+};
+TK_DEV void cdef_dist_add(CdefDist& a, unsigned s_, unsigned d_) {
+  const unsigned long long s = s_, d = d_;
+  a.sum_s += s; a.sum_d += d; a.sum_s2 += s * s; a.sum_d2 += d * d; a.sum_sd += s * d;
+}
+TK_DEV unsigned long long cdef_dist_finish(const CdefDist& a, int cs) {
+  unsigned long long svar = a.sum_s2 - ((a.sum_s * a.sum_s + 32) >> 6);
+  unsigned long long dvar = a.sum_d2 - ((a.sum_d * a.sum_d + 32) >> 6);
+  double num = (double)(a.sum_d2 + a.sum_s2 - 2 * a.sum_sd) * .5;
   num = num * (double)(svar + dvar + (unsigned long long)(400 << (2 * cs)));
   double den = sqrt((double)(20000 << (4 * cs)) + (double)svar * (double)dvar);
   return (unsigned long long)floor(.5 + num / den);
@@ -229,12 +230,13 @@ template <typename PIX> TK_DEV void cdef_pass_mse(const CdefJob<PIX>& J, int gid
       const int adj = cdef_adjust_strength(pri, J.var[b]);
       const int pd = adj ? tmax(ilog2((unsigned)adj), J.damping) : J.damping;
       const int dir = pri ? J.dir[b] : 0;
-      int out[64];
+      CdefDist acc;
+      const PIX* const org = J.org.y + by * 8 * J.org.sy + bx * 8;
       for (int i = 0; i < 8; i++)
         for (int j = 0; j < 8; j++)
-          out[i * 8 + j] = cdef_filter_px(J.src.y, J.src.sy, bx * 8 + j, by * 8 + i, J.width, J.height, adj << cs, sec << cs,
-                                          dir, pd + cs, J.damping + cs, cs);
-      unsigned long long d = cdef_dist8(out, J.org.y + by * 8 * J.org.sy + bx * 8, J.org.sy, cs);
+          cdef_dist_add(acc, org[i * J.org.sy + j], (unsigned)cdef_filter_px(J.src.y, J.src.sy, bx * 8 + j, by * 8 + i, J.width, J.height, adj << cs, sec << cs,
+                                                                            dir, pd + cs, J.damping + cs, cs));
+      unsigned long long d = cdef_dist_finish(acc, cs);
       team_add64(&J.mse[(0 * nfb + fb) * kCdefMaxStr + gi], d);
     }
     // chroma (encode_frame.c:295-372 with bs = 8 for every plane): the search walks CHROMA 8x8 blocks

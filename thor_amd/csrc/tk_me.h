@@ -346,10 +346,14 @@ struct MeArgs {
 // Same passes, same order, same costs, winner = min over (cost, evaluation index) = the reference's sequential strict-'<' scan
 // (enc/encode_block.c:517-616); no duplicate-candidate bookkeeping (a vector evaluated twice cannot win twice).
 //   NB: bytes per row segment (4, 8: the PU width; 16: widths 16 and 32 = one or two segments per row)
-template <int NB, int SP>
-TK_DEVNI unsigned long long me_cand8_fullpel(const Team t, MeWs* w_, const uint8_t* org_, const uint8_t* ref, int a_cb, int a_ostride, int a_width, int a_height,
-                                             int a_rstride, int a_sign, int a_fw, int a_fh, int a_xpos, int a_ypos, double a_lam, const uint32_t* win_w32, int win_ox,
-                                             int win_oy, int win_Ww, int win_Wh, int win_pitch, int win_on, mv_t mvc, mv_t mvp, int ref_idx) {
+//   Round 6: PIX = uint16_t too (the reference's _hbd searches: SAD >> (bitdepth - 8), enc/encode_block.c:417-428): the same walk with v_sad_u16 on
+//   16-byte segments of eight samples - one (8 wide), two (16) or four (32) segments per row, `sh` = bitdepth - 8.
+template <typename PIX, int NB, int SP>
+TK_DEVNI unsigned long long me_cand_fullpel(const Team t, MeWs* w_, const PIX* org_, const PIX* ref, int a_cb, int a_ostride, int a_width, int a_height,
+                                            int a_rstride, int a_sign, int a_fw, int a_fh, int a_xpos, int a_ypos, double a_lam, const uint32_t* win_w32, int win_ox,
+                                            int win_oy, int win_Ww, int win_Wh, int win_pitch, int win_on, mv_t mvc, mv_t mvp, int ref_idx, int a_sh) {
+  constexpr int S = (int)sizeof(PIX), SPS = 16 / S;   // bytes per sample, samples per 16-byte segment
+  const int sh = tk_uniform(a_sh);
   // (scalars one by one and the result in registers: a struct - by reference or by value - is a trip through the caller's stack in scratch memory)
   struct { int cb_size, ostride, width, height, rstride, sign, fwidth, fheight, xpos, ypos; double lam; } a_in = {a_cb, a_ostride, a_width, a_height, a_rstride, a_sign, a_fw, a_fh, a_xpos, a_ypos, a_lam};
   MeWin win_in;
@@ -369,7 +373,7 @@ TK_DEVNI unsigned long long me_cand8_fullpel(const Team t, MeWs* w_, const uint8
   org_ = tk_uniform_ptr(org_);
   ref = tk_uniform_ptr(ref);
   const int s = sign ? -1 : 1;
-  const int spr = NB == 16 ? (width >> 4) : 1;   // 16-byte segments per row
+  const int spr = NB == 16 ? ((width * S) >> 4) : 1;   // 16-byte segments per row
   unsigned min_sad = kCostInit;
   mv_t mv_opt = mk_mv(0, 0);
   mv_t mv_ref = mk_mv(((mvc.x + 2) >> 2) << 2, ((mvc.y + 2) >> 2) << 2);
@@ -381,11 +385,11 @@ TK_DEVNI unsigned long long me_cand8_fullpel(const Team t, MeWs* w_, const uint8
   // multiples of four); window / plane and one / two segments per row are decided outside the loop (straight-line bodies: all eight or
   // sixteen reads of an iteration are issued before the first SAD waits for them)
   auto rows_sad = [&](auto win_tag, auto spr_tag, int dx, int dy, int off) -> unsigned {
-    constexpr int WIN = decltype(win_tag)::value, SPR = decltype(spr_tag)::value, ROWS = 4 / SPR;   // four segments in flight
+    constexpr int WIN = decltype(win_tag)::value, SPR = decltype(spr_tag)::value, ROWS = SPR >= 4 ? 1 : 4 / SPR;   // four segments in flight
     unsigned sad = 0;
-    int wb = mul24(dy - win.oy, win.pitch) + (dx + off - win.ox);
-    const uint8_t* gb = ref + mul24(dy, rstride) + (dx + off);
-    const uint8_t* ob = org_;
+    int wb = mul24(dy - win.oy, win.pitch) + (dx + off - win.ox) * S;   // bytes
+    const PIX* gb = ref + mul24(dy, rstride) + (dx + off);
+    const PIX* ob = org_;
     for (int i = 0; i < height; i += ROWS) {
       Seg16 o[ROWS * SPR], r[ROWS * SPR];
 #if !TK_HOST
@@ -396,14 +400,14 @@ TK_DEVNI unsigned long long me_cand8_fullpel(const Team t, MeWs* w_, const uint8
 #pragma unroll
 #endif
         for (int sg = 0; sg < SPR; sg++) {
-          o[k * SPR + sg] = seg_load<SP, NB>(ob + mul24(k, ostride) + 16 * sg);   // the same address in every lane
+          o[k * SPR + sg] = seg_load<SP, NB>(ob + mul24(k, ostride) + SPS * sg);   // the same address in every lane
           if constexpr (WIN) r[k * SPR + sg] = win_seg<NB>(win.w32, wb + mul24(k, win.pitch) + 16 * sg);
-          else r[k * SPR + sg] = seg_load<SP_GLOBAL, NB>(gb + mul24(k, rstride) + 16 * sg);
+          else r[k * SPR + sg] = seg_load<SP_GLOBAL, NB>(gb + mul24(k, rstride) + SPS * sg);
         }
 #if !TK_HOST
 #pragma unroll
 #endif
-      for (int q = 0; q < ROWS * SPR; q++) sad = (unsigned)seg_sad<uint8_t, NB>(o[q], r[q], (int)sad);
+      for (int q = 0; q < ROWS * SPR; q++) sad = (unsigned)seg_sad<PIX, NB>(o[q], r[q], (int)sad);
       wb += ROWS * win.pitch; gb += ROWS * rstride; ob += ROWS * ostride;
     }
     return sad;
@@ -411,9 +415,11 @@ TK_DEVNI unsigned long long me_cand8_fullpel(const Team t, MeWs* w_, const uint8
   struct T0 { enum { value = 0 }; };
   struct T1 { enum { value = 1 }; };
   struct T2 { enum { value = 2 }; };
+  struct T4 { enum { value = 4 }; };
   auto block_sad = [&](int use_win, int dx, int dy, int off) -> unsigned {
     if constexpr (NB == 16) {
       if (spr == 2) return use_win ? rows_sad(T1(), T2(), dx, dy, off) : rows_sad(T0(), T2(), dx, dy, off);
+      if constexpr (S == 2) { if (spr == 4) return use_win ? rows_sad(T1(), T4(), dx, dy, off) : rows_sad(T0(), T4(), dx, dy, off); }
     }
     return use_win ? rows_sad(T1(), T1(), dx, dy, off) : rows_sad(T0(), T1(), dx, dy, off);
   };
@@ -445,7 +451,7 @@ TK_DEVNI unsigned long long me_cand8_fullpel(const Team t, MeWs* w_, const uint8
       mx = (int16_t)(m.x + ((s * bx) << 2));
     } else
       sad = block_sad(use_win, dx, dy, 0);
-    const unsigned cost = sad + mv_cost(lam, m.y - mvp.y, mx - mvp.x);
+    const unsigned cost = (sad >> sh) + mv_cost(lam, m.y - mvp.y, mx - mvp.x);
     return valid ? cost : ~0u;
   };
   // min over the lanes [lo, lo + n) of (cost << 8 | lane - lo): the first candidate in evaluation order among the cheapest; ~0u for n == 0
@@ -999,17 +1005,18 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
   };
   const int lw_ = (a.width < 16 / (int)sizeof(PIX)) ? a.width : 16 / (int)sizeof(PIX);   // samples per row segment (seg_sads)
   const int dedup = a.speed == 0 && a.height * (a.width / lw_) >= 16;
-  // 8-bit PUs of up to 32x32 samples, encoder_speed 0: the one-lane-per-candidate full-pel search (me_cand8_fullpel) - same passes, same result
+  // PUs of up to 32x32 samples, encoder_speed 0: the one-lane-per-candidate full-pel search (me_cand_fullpel; 16-bit samples since round 6) - same passes, same result
   int small_done = 0;
-  if constexpr (sizeof(PIX) == 1) {
+  {
     // (rows of 64 and 128 samples keep the 64-lane evaluator: a lane walking 256+ row segments of the plane by itself measured 2x slower, profiles/r05_ubench_me.md)
     if (TKU(a.speed == 0 && t.size == 64 && a.width <= 32 && a.height <= 32)) {
 #ifndef TK_ME_NO_SMALL
       unsigned long long fr;
-#define TK_ME_FP_ARGS t, w_, org, ref, a.cb_size, a.ostride, a.width, a.height, a.rstride, a.sign, a.fwidth, a.fheight, a.xpos, a.ypos, a.lam, win.w32, win.ox, win.oy, win.Ww, win.Wh, win.pitch, win.on, mvc, mvp, ref_idx
-      if (a.width == 4) fr = me_cand8_fullpel<4, SP>(TK_ME_FP_ARGS);
-      else if (a.width == 8) fr = me_cand8_fullpel<8, SP>(TK_ME_FP_ARGS);
-      else fr = me_cand8_fullpel<16, SP>(TK_ME_FP_ARGS);
+#define TK_ME_FP_ARGS t, w_, org, ref, a.cb_size, a.ostride, a.width, a.height, a.rstride, a.sign, a.fwidth, a.fheight, a.xpos, a.ypos, a.lam, win.w32, win.ox, win.oy, win.Ww, win.Wh, win.pitch, win.on, mvc, mvp, ref_idx, sh
+      const int rowb = a.width * (int)sizeof(PIX);   // bytes per row: the segment size
+      if (rowb == 4) { if constexpr (sizeof(PIX) == 1) fr = me_cand_fullpel<PIX, 4, SP>(TK_ME_FP_ARGS); else fr = 0; }
+      else if (rowb == 8) fr = me_cand_fullpel<PIX, 8, SP>(TK_ME_FP_ARGS);
+      else fr = me_cand_fullpel<PIX, 16, SP>(TK_ME_FP_ARGS);
 #undef TK_ME_FP_ARGS
       min_sad = (unsigned)(fr >> 32);
       mv_opt = mk_mv((int16_t)(uint16_t)(fr >> 16), (int16_t)(uint16_t)fr);
