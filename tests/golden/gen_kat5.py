@@ -50,7 +50,7 @@ def smooth(rng, h, w, bd, noise=6.0):
     img = np.apply_along_axis(lambda r: np.convolve(r, k, mode='same'), 0, img)
     img += rng.normal(0, noise, size=(h, w))
     img[:, w // 3] += 40
-    return np.clip(np.rint(img * sc), 0, (1 << bd) - 1).astype(dt(bd))
+    return np.ascontiguousarray(np.clip(np.rint(img * sc), 0, (1 << bd) - 1).astype(dt(bd)))   # C order: the reference functions get raw pointers
 
 
 def frame_planes(fr, bd):
@@ -254,7 +254,7 @@ def rec_clpf(out, rng, bd):
     det = L.ref_detect_multi_clpf
     blk = getattr(L, 'clpf_block' + sfx(bd))
     stats = []
-    outp = [p.copy() for p in rec]
+    outp = [np.ascontiguousarray(p).copy() for p in rec]
     for pl in range(3):
         sub = 1 if pl else 0
         w, h = W >> sub, H >> sub
@@ -276,7 +276,7 @@ def rec_clpf(out, rng, bd):
                 lin = ((y0 << sub) // 4) * (w // 4) + ((x0 << sub) // 4)   # sic: plane width as row pitch (common_frame.c:1048,1075)
                 if cells.reshape(-1, 16)[lin, 8] == 0: continue
                 if pl == 0 and not fb_on[(y0 >> fb_log2) * nfb_h + (x0 >> fb_log2)]: continue
-                bt = (1 if x0 == 0 else 0) | (2 if y0 == 0 else 0) | (4 if x0 + bs == w else 0) | (8 if y0 + bs == h else 0)
+                bt = (1 if x0 == 0 else 0) | (2 if x0 + bs == w else 0) | (4 if y0 == 0 else 0) | (8 if y0 + bs == h else 0)   # boundary_type, common/types.h:41-44
                 blk(P(r), P(outp[pl]), w, w, x0, y0, bs, bs, bt, strength[pl] << shift, dmp)
     out[f'cl{bd}_par'] = np.array([W, H, qp, fb_log2] + strength, dtype=np.int32)
     out[f'cl{bd}_rec'] = flat(rec); out[f'cl{bd}_org'] = flat(org); out[f'cl{bd}_cells'] = cells; out[f'cl{bd}_fb_on'] = fb_on
