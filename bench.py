@@ -681,6 +681,15 @@ def main():
             assert len(allbits) == S * world and allbits[:S] == local_bits, 'ordered gather lost the chunk order'
     t_g = time.perf_counter() - t_g
     stats = enc.stats() if hasattr(enc, 'stats') else None
+    kinfo = None
+    if have_gpu:   # registers / LDS / workgroups per CU of the superblock kernel as the runtime reports them (an occupancy regression shows in the line)
+        try:
+            import ctypes as C_
+            r_, l_, p_, w_ = C_.c_int(), C_.c_int(), C_.c_int(), C_.c_int()
+            if thor_amd.lib().thor_hip_superblock_kernel_info(bps, C_.byref(r_), C_.byref(l_), C_.byref(p_), C_.byref(w_)) == 0:
+                kinfo = {'vgprs': r_.value, 'lds_bytes': l_.value, 'private_bytes_per_lane': p_.value, 'workgroups_per_cu': w_.value}
+        except (AttributeError, OSError):
+            pass
 
     rc = 0
     if rank == 0:
@@ -807,7 +816,8 @@ def main():
                                    f'({R:.2f} references on average), synthetic content sigma {a.sigma:g}',
                        'streams_per_gpu': S, 'frames_timed_per_stream': a.steps, 'parallelism': f'stream-sharded x{world}',
                        'per_stream_fps': round(a.steps / dt, 4), 'per_stream_mpx_s': round(w * h * a.steps / dt / 1e6, 4),
-                       'superblock_queue': 'fifo', 'schedule': 'lockstep' if a.lockstep else 'two groups half a frame apart', 'csrc_digest': csrc_digest()},   # thor_amd/csrc/tk_sched.h
+                       'superblock_queue': 'fifo', 'schedule': 'lockstep' if a.lockstep else 'two groups half a frame apart', 'csrc_digest': csrc_digest(),
+                       'superblock_kernel': kinfo},   # thor_amd/csrc/tk_sched.h
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 4), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 8), 'traffic': traffic, 'traffic_unit': 'bytes per launch', 'traffic_source': traffic_src,
                          'alg_bytes_per_launch': round(alg_bytes_per_launch),

@@ -209,6 +209,10 @@ int thor_hip_kat_clpf(const void* rec_yuv, const void* org_yuv, int width, int h
  * block motion estimation per level, merge, motion-compensated average) through the engine's own device path (tk_interp_dev.h). */
 int thor_hip_kat_interpolate(const void* yuv0, const void* yuv1, int width, int height, int bitdepth, void* out_yuv);
 
+/* Resources of the persistent superblock kernel (sample_bytes 1: 8-bit kernel, 2: 16-bit kernel) as the HIP runtime reports them: registers per lane,
+ * static LDS and private (scratch) bytes, and how many workgroups of it fit one CU - what the resident-workgroup count of every launch derives from. */
+int thor_hip_superblock_kernel_info(int sample_bytes, int* num_regs, int* lds_bytes, int* private_bytes, int* workgroups_per_cu);
+
 #ifdef __cplusplus
 }
 #endif

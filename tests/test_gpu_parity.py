@@ -161,3 +161,16 @@ def test_dropin_tiny_all_skip_frames_header_backpatch():
         assert bits == rb and rec == rr, qp
         b2, r2 = encode_gpu(clip, 64, 64, 4, qp)
         assert b2[0] == rb and r2[0] == rr, qp
+
+
+def test_superblock_kernel_keeps_three_workgroups_per_cu():
+    """Occupancy guard (round 6): the 8-bit superblock kernel is built for 168 VGPRs = three workgroups of four waves per CU (768 resident on the chip), the
+    16-bit one for 256 = two.  A kernel that shares a __noinline__ function with it and has a larger register budget silently raises that function's budget
+    and with it this kernel's register count (measured: 227 VGPRs, two workgroups per CU, -16 % throughput) - caught here instead of in a bench line."""
+    import ctypes as C
+    import thor_amd
+    L = thor_amd.lib()
+    for sb, regs_max, wgs in ((1, 168, 3), (2, 256, 2)):
+        r, lds, prv, per = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        assert L.thor_hip_superblock_kernel_info(sb, C.byref(r), C.byref(lds), C.byref(prv), C.byref(per)) == 0
+        assert r.value <= regs_max and per.value == wgs, (sb, r.value, lds.value, prv.value, per.value)

@@ -1093,8 +1093,11 @@ __global__ __launch_bounds__(64) void k_kat_intra(const PIX* plane, int stride, 
   make_edges<SP_GLOBAL>(t, &edge, plane + (size_t)q[0] * stride + q[1], stride, rblock, cbs, q[5], q[6], q[0], q[1], size, q[2], q[3], tb_split, bitdepth);
   pred_intra<SP_GLOBAL>(t, &edge, q[0] + q[5], q[1] + q[6], size, out + (size_t)it * size * size, size, q[4], bitdepth);
 }
+// (pred_inter_yuv / improve_uv are __noinline__ functions the superblock kernel calls too: a kernel with a larger register budget calling them would raise
+// THEIR budget and with it the superblock kernel's VGPR count - 227 instead of 168, two workgroups per CU instead of three, measured in round 6 - so these two
+// kernels carry the superblock kernel's launch bounds)
 template <typename PIX>
-__global__ __launch_bounds__(64) void k_kat_inter_yuv(Plane3<PIX> ref, int width, int height, int bitdepth, int size, const int* par, const int16_t* mv, PIX* out) {
+__global__ __launch_bounds__(kWgThreads, (sizeof(PIX) == 1 ? (int)kOcc : 2)) void k_kat_inter_yuv(Plane3<PIX> ref, int width, int height, int bitdepth, int size, const int* par, const int16_t* mv, PIX* out) {
   const Team t = mk_team((int)threadIdx.x, 64);
   const int it = blockIdx.x;
   const int* q = par + 5 * it;   // ypos, xpos, sign, enable_bipred, split
@@ -1110,7 +1113,7 @@ template <typename PIX> __global__ __launch_bounds__(64) void k_kat_average(cons
   average_yuv<SP_GLOBAL>(t, out + o, out + o + n, out + o + n + c, a + o, a + o + n, a + o + n + c, b + o, b + o + n, b + o + n + c, size, size, size);
 }
 template <typename PIX>
-__global__ __launch_bounds__(64) void k_kat_cfl(const PIX* y, PIX* uv, const PIX* ry, int n, int bitdepth) {
+__global__ __launch_bounds__(kWgThreads, (sizeof(PIX) == 1 ? (int)kOcc : 2)) void k_kat_cfl(const PIX* y, PIX* uv, const PIX* ry, int n, int bitdepth) {
   const Team t = mk_team((int)threadIdx.x, 64);
   const int it = blockIdx.x, c = (n / 2) * (n / 2);
   improve_uv<PIX, SP_GLOBAL>(t, nullptr, y + (size_t)it * n * n, uv + (size_t)it * 2 * c, uv + (size_t)it * 2 * c + c, ry + (size_t)it * n * n, n, n, n, bitdepth);
@@ -1486,4 +1489,24 @@ extern "C" int thor_hip_kat_clpf(const void* rec_yuv, const void* org_yuv, int w
 extern "C" int thor_hip_kat_interpolate(const void* yuv0, const void* yuv1, int width, int height, int bitdepth, void* out_yuv) {
   KAT_BD(kat_interpolate<uint8_t>((const uint8_t*)yuv0, (const uint8_t*)yuv1, width, height, 8, (uint8_t*)out_yuv),
          kat_interpolate<uint16_t>((const uint16_t*)yuv0, (const uint16_t*)yuv1, width, height, bitdepth, (uint16_t*)out_yuv));
+}
+
+// Resources of the superblock kernel as the runtime sees them (a guard against silent occupancy regressions: round 6 found the 8-bit kernel at 227 VGPRs =
+// two workgroups per CU after an unrelated kernel had raised the register budget of a shared __noinline__ function).
+extern "C" int thor_hip_superblock_kernel_info(int sample_bytes, int* num_regs, int* lds_bytes, int* private_bytes, int* workgroups_per_cu) {
+  if (!ensure_init(g_inited ? g_device : 0)) return 3;
+  hipFuncAttributes a;
+  int per_cu = 0;
+  if (sample_bytes == 1) {
+    HIPCHECK(hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_superblocks<uint8_t>)));
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_superblocks<uint8_t>, kWgThreads, 0));
+  } else if (sample_bytes == 2) {
+    HIPCHECK(hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_superblocks<uint16_t>)));
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_superblocks<uint16_t>, kWgThreads, 0));
+  } else return 1;
+  if (num_regs) *num_regs = a.numRegs;
+  if (lds_bytes) *lds_bytes = (int)a.sharedSizeBytes;
+  if (private_bytes) *private_bytes = (int)a.localSizeBytes;
+  if (workgroups_per_cu) *workgroups_per_cu = per_cu;
+  return 0;
 }
