@@ -209,7 +209,8 @@ int thor_hip_kat_clpf(const void* rec_yuv, const void* org_yuv, int width, int h
  * block motion estimation per level, merge, motion-compensated average) through the engine's own device path (tk_interp_dev.h). */
 int thor_hip_kat_interpolate(const void* yuv0, const void* yuv1, int width, int height, int bitdepth, void* out_yuv);
 
-/* Resources of the persistent superblock kernel (sample_bytes 1: 8-bit kernel, 2: 16-bit kernel) as the HIP runtime reports them: registers per lane,
+/* Resources of the persistent superblock kernel (sample_bytes 1: 8-bit kernel, 2: 16-bit kernel, 0: the 8-bit kernel's second build for runs of few
+ * streams - 256 registers, two workgroups per CU, chosen by the library when a run cannot fill more; THOR_HIP_KERNEL=std|lat forces one) as the HIP runtime reports them: registers per lane,
  * static LDS and private (scratch) bytes, and how many workgroups of it fit one CU - what the resident-workgroup count of every launch derives from. */
 int thor_hip_superblock_kernel_info(int sample_bytes, int* num_regs, int* lds_bytes, int* private_bytes, int* workgroups_per_cu);
 

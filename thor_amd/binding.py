@@ -13,17 +13,27 @@ def lib_path():
     return os.environ.get('THOR_HIP_LIB') or os.path.join(REPO_ROOT, 'thor_amd', 'libthor_hip.so')
 
 
+HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-strict-aliasing', '-fPIC', '-pthread']
+NATIVE_SOURCES = ['thor_hip.cpp', 'thor_hip_lat.cpp']   # the throughput build of the engine + its second build for the few-stream operating point
+
+
 def build_native(force=False):
-    """Compile libthor_hip.so (gfx950) and the C front end in-tree with hipcc/gcc."""
-    src = os.path.join(REPO_ROOT, 'thor_amd', 'csrc', 'thor_hip.cpp')
+    """Compile libthor_hip.so (gfx950) and the C front end in-tree with hipcc/gcc: the two translation units are compiled side by side, then linked."""
+    csrc = os.path.join(REPO_ROOT, 'thor_amd', 'csrc')
     out = os.path.join(REPO_ROOT, 'thor_amd', 'libthor_hip.so')
-    hdrs = [os.path.join(REPO_ROOT, 'thor_amd', 'csrc', f) for f in os.listdir(os.path.join(REPO_ROOT, 'thor_amd', 'csrc'))]
+    hdrs = [os.path.join(csrc, f) for f in os.listdir(csrc)]
     hdrs += [os.path.join(REPO_ROOT, 'include', f) for f in os.listdir(os.path.join(REPO_ROOT, 'include'))]
     newest = max(os.path.getmtime(h) for h in hdrs)
     if force or not os.path.exists(out) or os.path.getmtime(out) < newest:
         hipcc = '/opt/rocm/bin/hipcc' if os.path.exists('/opt/rocm/bin/hipcc') else 'hipcc'
-        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-strict-aliasing', '-fPIC', '-shared', '-pthread',
-                               '-o', out, src])
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            objs = [os.path.join(d, f[:-4] + '.o') for f in NATIVE_SOURCES]
+            procs = [subprocess.Popen([hipcc] + HIPCC_FLAGS + ['-c', '-o', o, os.path.join(csrc, f)]) for f, o in zip(NATIVE_SOURCES, objs)]
+            rcs = [p.wait() for p in procs]
+            if any(rcs):
+                raise subprocess.CalledProcessError(max(rcs), 'hipcc -c ' + ' '.join(NATIVE_SOURCES))
+            subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-pthread', '-o', out] + objs)
     tool = os.path.join(REPO_ROOT, 'tools', 'thorenc_hip')
     tsrc = tool + '.c'
     if force or not os.path.exists(tool) or os.path.getmtime(tool) < os.path.getmtime(tsrc):

@@ -18,6 +18,7 @@
 #include "tk_encoder.h"
 #include "tk_cli.h"
 #include "tk_sched.h"
+#include "tk_kernel.h"
 #include "../../include/thor_hip.h"
 
 #define HIPCHECK(x)                                                                              \
@@ -30,6 +31,12 @@
     }                                                                                            \
   } while (0)
 
+// the second build of the engine (thor_hip_lat.cpp: 256 VGPRs, two workgroups per CU - the few-stream operating point)
+extern "C" __attribute__((visibility("hidden"))) int thor_lat_upload_tables(const void* tables, size_t bytes);
+extern "C" __attribute__((visibility("hidden"))) int thor_lat_workgroups_per_cu(void);
+extern "C" __attribute__((visibility("hidden"))) int thor_lat_kernel_info(int* num_regs, int* lds_bytes, int* private_bytes);
+extern "C" __attribute__((visibility("hidden"))) int thor_lat_launch_u8(int wgs, void* stream, const void* jobs, const void* dfargs, size_t dfargs_bytes, size_t job_bytes, size_t slot_bytes);
+
 namespace tk {
 __device__ Tables g_tab;
 
@@ -39,81 +46,6 @@ __device__ Tables g_tab;
 // Dependency-driven persistent superblock kernel.  A task is (stream, superblock).  SB(k,l) needs its left
 // neighbour (k,l-1) and its up-right neighbour (k-1,l+1) ((k-1,l) in the last column) - SURVEY.md Appendix A.
 // The ready-task queue is in tk_sched.h.
-
-// Workgroup = kWaves wavefronts on one superblock: wave 0 walks the quadtree (process_sb), the others are parked on
-// the workgroup barrier and take work items of the block decisions (tk_block.h:mode_decision_par).  3 workgroups of
-// 4 waves per CU = 3 waves per SIMD (168 VGPRs each), 768 workgroups resident on the chip.
-enum { kWgThreads = 64 * kWaves };
-enum { kOcc = TK_OCC };   // wavefronts per SIMD the register allocation is sized for (168 VGPRs); 2 and 4 measured slower (profiles/r02_ab_variants.md)
-// 16-bit samples: two waves per SIMD (256 VGPRs; the 16-bit instances need ~245 and their 80 KB of LDS per workgroup allow two per CU anyway) -
-// the register budget of a kernel is also the budget of every function only it calls.
-template <typename PIX> __global__ __launch_bounds__(kWgThreads, (sizeof(PIX) == 1 ? (int)kOcc : 2)) void k_superblocks(const FrameJob<PIX>* jobs, DfArgs A) {
-  __shared__ FrameJob<PIX> sJ;
-  __shared__ WgShared sh;
-  __shared__ SmallWs<PIX> sws[kWaves];
-  __shared__ unsigned s_task;
-  JobR<PIX> J = *ldsc(&sJ);
-  const unsigned total = A.total;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
-#ifdef THOR_PROF
-  const Wg wg{wave, kWaves, sws[wave].prof};
-#else
-  const Wg wg{wave, kWaves};
-#endif
-  __shared__ TeamWs<PIX> s_view[kWaves];   // per-wave view of the workspaces: in LDS so that the callees read it with ds_read
-  lds_st(&s_view[wave], make_ws(&sws[wave], &sh, (BigWs<PIX>*)(A.pool + ((size_t)blockIdx.x * kWaves + wave) * A.slot_bytes)));
-  WsP<PIX> ws = ldsc(&s_view[wave]);
-  const Team t = mk_team(lane, 64, sh.tabs.izz);
-  xform_tables_fill(&sh.tabs, (int)threadIdx.x, kWgThreads);  // constant: once per workgroup
-  for (;;) {
-    __syncthreads();
-    unsigned long long tpop = 0;
-    if (threadIdx.x == 0) {
-      if (A.times) tpop = wall_clock64();
-      s_task = df_next(A, total);
-    }
-    __syncthreads();
-    const unsigned task = (unsigned)__builtin_amdgcn_readfirstlane((int)s_task);
-    if (task == kDfEmpty) break;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const int sidx = (int)(task / (unsigned)A.nsb), sb = (int)(task % (unsigned)A.nsb);
-    const int k = sb / A.cols, l = sb % A.cols;
-    {
-      const uint32_t* src = (const uint32_t*)&jobs[sidx];
-      uint32_t* dst = (uint32_t*)&sJ;
-      for (int i = threadIdx.x; i < (int)(sizeof(FrameJob<PIX>) / 4); i += kWgThreads) dst[i] = src[i];
-    }
-#ifdef THOR_PROF
-    if (lane < kProfSlots) sws[wave].prof[lane] = 0;
-#endif
-    __syncthreads();
-    if (wave == 0) {
-      if (A.times && lane == 0) { A.times[3 * (size_t)task] = tpop; A.times[3 * (size_t)task + 1] = wall_clock64(); }
-      BitSink out;
-      out.buf = J.sb_bits + (size_t)sb * J.sb_words;
-      out.pos = 0;
-      out.cap = J.sb_words * 32;
-      out.emit = 1;
-      out.ovf = 0;
-      process_sb(wg, t, J, ws, k * kMaxSb, l * kMaxSb, out);
-      if (lane == 0) {
-        J.sb_nbits[sb] = out.pos;
-        J.sb_status[sb] = out.ovf;
-      }
-    } else
-      wg_helper_loop(wg, t, J, ws);
-#ifdef THOR_PROF
-    __syncthreads();
-    if (J.prof && lane < kProfSlots) atomicAdd((unsigned long long*)&J.prof[lane], (unsigned long long)sws[wave].prof[lane]);
-#endif
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      if (A.times) A.times[3 * (size_t)task + 2] = wall_clock64();
-      df_finish(A, sidx, k, l);
-    }
-  }
-}
 
 template <typename PIX> __global__ void k_deblock(const FrameJob<PIX>* jobs, int pass) {
   const FrameJob<PIX>& J = jobs[blockIdx.y];
@@ -303,6 +235,7 @@ static bool ensure_init(int device) {
   static Tables h;
   init_tables(&h);
   HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tab), &h, sizeof(h)));
+  if (thor_lat_upload_tables(&h, sizeof(h))) { fprintf(stderr, "Run-time error...\nthor_hip: table upload of the latency kernel failed\n...now exiting to system...\n"); abort(); }
   g_inited = true;
   return true;
 }
@@ -353,6 +286,7 @@ struct DfState {  // per engine (keyed by its device job array)
   int S = 0, nsb = 0, wgs = 0;
   size_t slot = 0;
   int frame = 0;
+  int lat = 0;   // 1: this engine's launches use the latency kernel (thor_hip_lat.cpp)
 };
 static std::map<const void*, DfState> g_df;
 static void df_free(DfState& D) {
@@ -376,7 +310,17 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
     HIPCHECK(hipGetDevice(&dev));
     HIPCHECK(hipGetDeviceProperties(&prop, dev));
     long cap = (long)(per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
-    if (const char* e = getenv("THOR_HIP_WGS")) cap = atol(e);
+    // Which build of the kernel: a stream offers at most min(rows, (cols + 1) / 2) superblocks at a time (the dependency wavefront); when all streams
+    // together cannot occupy more workgroups than the latency kernel (256 VGPRs, two per CU) has room for, that kernel runs them - no spills, larger
+    // search windows, nothing lost.  8-bit samples only (the 16-bit kernel has that budget anyway).  THOR_HIP_KERNEL=std|lat forces one (tests, A/B).
+    if constexpr (sizeof(PIX) == 1) {
+      const long lat_cap = (long)thor_lat_workgroups_per_cu() * prop.multiProcessorCount;
+      const long wave_front = (long)S * (rows < (cols + 1) / 2 ? rows : (cols + 1) / 2);
+      D.lat = lat_cap > 0 && wave_front <= lat_cap;
+      if (const char* e = getenv("THOR_HIP_KERNEL")) { if (!strcmp(e, "lat")) D.lat = lat_cap > 0; else if (!strcmp(e, "std")) D.lat = 0; }
+      if (D.lat) cap = lat_cap;
+    }
+    if (const char* e = getenv("THOR_HIP_WGS")) { if (*e) cap = atol(e); }
     D.wgs = (int)(cap < (long)all ? cap : (long)all);
     HIPCHECK(hipMalloc(&D.ctl, sizeof(DfCtl)));
     HIPCHECK(hipMalloc(&D.queue, sizeof(unsigned) * all));
@@ -419,7 +363,10 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
   if (const char* e = getenv("THOR_HIP_SPIN_TIMEOUT_S")) lim_s = atof(e);
   A.spin_limit = (unsigned long long)(lim_s * 1e8);
   auto ev = ev_begin();
-  hipLaunchKernelGGL(k_superblocks<PIX>, dim3(D.wgs), dim3(kWgThreads), 0, g_stream, jobs, A);
+  if (D.lat) {
+    if (thor_lat_launch_u8(D.wgs, (void*)g_stream, jobs, &A, sizeof(A), sizeof(FrameJob<PIX>), slot)) { fprintf(stderr, "Run-time error...\nthor_hip: launch of the latency kernel failed\n...now exiting to system...\n"); abort(); }
+  } else
+    hipLaunchKernelGGL(k_superblocks<PIX>, dim3(D.wgs), dim3(kWgThreads), 0, g_stream, jobs, A);
   g_clk.sb_launches++;
   HIPCHECK(hipEventRecord(ev.second, g_stream));
   g_sb_events.push_back(ev);
@@ -1503,6 +1450,10 @@ extern "C" int thor_hip_superblock_kernel_info(int sample_bytes, int* num_regs, 
   } else if (sample_bytes == 2) {
     HIPCHECK(hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_superblocks<uint16_t>)));
     HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_superblocks<uint16_t>, kWgThreads, 0));
+  } else if (sample_bytes == 0) {   // the latency build of the 8-bit kernel (thor_hip_lat.cpp)
+    if (thor_lat_kernel_info(num_regs, lds_bytes, private_bytes)) return 2;
+    if (workgroups_per_cu) *workgroups_per_cu = thor_lat_workgroups_per_cu();
+    return 0;
   } else return 1;
   if (num_regs) *num_regs = a.numRegs;
   if (lds_bytes) *lds_bytes = (int)a.sharedSizeBytes;
