@@ -32,11 +32,12 @@ def short(n):
 
 def main():
     out_md = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith('-') else None
-    flags = [a for a in sys.argv[1:] if a.startswith('-')]
+    flags = [a for a in sys.argv[1:] if a.startswith('-') and not a.startswith('--src=')]
+    src = ([a[6:] for a in sys.argv[1:] if a.startswith('--src=')] or ['thor_hip.cpp'])[0]   # --src=thor_hip_lat.cpp: the second build of the engine (round 6)
     with tempfile.TemporaryDirectory() as d:
         asm = os.path.join(d, 'dev.s')
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-strict-aliasing', '--cuda-device-only', '-S', '-w'] + flags +
-                              ['-o', asm, os.path.join(ROOT, 'thor_amd', 'csrc', 'thor_hip.cpp')])
+                              ['-o', asm, os.path.join(ROOT, 'thor_amd', 'csrc', src)])
         text = open(asm).read()
     # ---- per function instruction counts
     cur = None
@@ -67,7 +68,7 @@ def main():
         g = lambda k: (re.search(r'\.' + k + r':\s*(\S+)', blk) or [None, '?'])[1]
         kern.append({k: g(k) for k in ('name', 'vgpr_count', 'sgpr_count', 'vgpr_spill_count', 'sgpr_spill_count', 'private_segment_fixed_size', 'group_segment_fixed_size', 'max_flat_workgroup_size')})
     dm = demangle([k['name'] for k in kern] + list(cnt))
-    L = ['# Static resources of the gfx950 code object (`thor_amd/csrc/thor_hip.cpp`, hipcc -O3' + (' ' + ' '.join(flags) if flags else '') + ')', '',
+    L = ['# Static resources of the gfx950 code object (`thor_amd/csrc/' + src + '`, hipcc -O3' + (' ' + ' '.join(flags) if flags else '') + ')', '',
          'From `hipcc --cuda-device-only -S`: the kernel descriptors (`.amdgpu_metadata`) and instruction counts of the assembly; `scripts/isa_table.py`.', '',
          '## Kernels', '', '| kernel | VGPRs | SGPRs | VGPR spill slots | SGPR spill slots | private bytes / lane | LDS bytes / workgroup | waves / SIMD |', '|---|---|---|---|---|---|---|---|']
     for k in kern:

@@ -688,6 +688,92 @@ TK_DEVNI unsigned me_cand8_subpel(const Team t, const uint8_t* org_, int a_ostri
 }
 
 
+// The same pass on 16-bit samples (round 6): lane (c, p) = candidate c = lane / 8, part p = lane % 8; a strip is one column of 8 (4) samples whose 13 (9)
+// window rows are read once - six samples = three dwords at the candidate's byte offset (win_seg: any alignment), the six horizontal taps packed in
+// pairs: three v_dot2_i32_i16 per row sum (|sum| <= 94 * 4095 < 2^19), six 24-bit multiply-adds per sample vertically; the (1/2, 1/2) position's 12-tap
+// filter as two horizontal tap sets with vertical weights {0,1,1,1,1,0} and (sum + 8) >> 4, exactly as in me_cand8_subpel.  SAD >> (bitdepth - 8).
+template <int SP>
+TK_DEVNI unsigned me_cand16_subpel(const Team t, const uint16_t* org_, int a_ostride, int a_width, int a_height, int a_sign, int a_fw, int a_fh, int a_xpos, int a_ypos,
+                                   int a_bipred, double a_lam, const uint32_t* win_w32, int win_ox, int win_oy, int win_Ww, int win_Wh, int win_pitch, int win_on, mv_t base,
+                                   int d, mv_t mvp, int a_bitdepth) {
+  enum : unsigned { kNone = 0xffffffffu };
+  struct { int ostride, width, height, sign, fwidth, fheight, xpos, ypos, enable_bipred, bitdepth; double lam; } a_in = {a_ostride, a_width, a_height, a_sign, a_fw, a_fh, a_xpos, a_ypos, a_bipred, a_bitdepth, a_lam};
+  MeWin win_in;
+  win_in.w32 = win_w32; win_in.ox = win_ox; win_in.oy = win_oy; win_in.Ww = win_Ww; win_in.Wh = win_Wh; win_in.pitch = win_pitch; win_in.on = win_on;
+  const int ostride = tk_uniform(a_in.ostride), width = tk_uniform(a_in.width), height = tk_uniform(a_in.height), sign = tk_uniform(a_in.sign);
+  const int fw = tk_uniform(a_in.fwidth), fh = tk_uniform(a_in.fheight), xpos = tk_uniform(a_in.xpos), ypos = tk_uniform(a_in.ypos);
+  const int bip = tk_uniform(a_in.enable_bipred), bitdepth = tk_uniform(a_in.bitdepth);
+  const double lam = tk_uniform_f64(a_in.lam);
+  MeWin win;
+  win.w32 = tk_uniform_ptr(win_in.w32); win.ox = tk_uniform(win_in.ox); win.oy = tk_uniform(win_in.oy); win.Ww = tk_uniform(win_in.Ww);
+  win.Wh = tk_uniform(win_in.Wh); win.pitch = tk_uniform(win_in.pitch); win.on = tk_uniform(win_in.on);
+  base = mk_mv(tk_uniform(base.x), tk_uniform(base.y));
+  mvp = mk_mv(tk_uniform(mvp.x), tk_uniform(mvp.y));
+  d = tk_uniform(d);
+  org_ = tk_uniform_ptr(org_);
+  if (!win.on) return kNone;
+  const int c = t.rank >> 3, part = t.rank & 7;
+  const int oy = c == 0 ? 0 : c == 1 ? -d : c == 2 ? d : c == 3 ? 0 : c == 4 ? -d : c == 5 ? -d : d;
+  const int ox = c == 0 ? -d : c == 1 ? 0 : c == 2 ? 0 : c == 3 ? d : c == 4 ? -d : c == 5 ? d : c == 6 ? -d : d;
+  const mv_t mv = mk_mv(base.x + ox, base.y + oy);
+  const SubPel sp = luma_setup(mv, sign, width, height, fw, fh, xpos, ypos, bip);
+  const int centre = sp.ver_frac == 2 && sp.hor_frac == 2 && bip < 2;
+  const int outside = !(sp.hor_int - 2 >= win.ox && sp.hor_int + width + 6 <= win.ox + win.Ww && sp.ver_int - 2 >= win.oy && sp.ver_int + height + 3 <= win.oy + win.Wh);
+  if (team_ballot(t, outside) != 0ull) return kNone;
+  const int dual = team_ballot(t, centre) != 0ull;   // wave-uniform
+  auto pair = [](int a, int b) -> uint32_t { return (uint32_t)(uint16_t)(int16_t)a | ((uint32_t)(uint16_t)(int16_t)b << 16); };
+  uint32_t tA[3], tB[3];
+  for (int q = 0; q < 3; q++) {
+    tA[q] = centre ? (q == 1 ? pair(1, 1) : 0u) : pair(sp.th[2 * q], sp.th[2 * q + 1]);                                        // rows 0, 1, 4, 5: {0,0,1,1,0,0}
+    tB[q] = centre ? (q == 0 ? pair(0, 1) : q == 1 ? pair(2, 2) : pair(1, 0)) : pair(sp.th[2 * q], sp.th[2 * q + 1]);         // rows 2, 3:       {0,1,2,2,1,0}
+  }
+  int tv[6];
+  for (int m = 0; m < 6; m++) tv[m] = centre ? (m >= 1 && m <= 4 ? 1 : 0) : sp.tv[m];
+  const int rnd = centre ? 8 : 2048, rsh = centre ? 4 : 12;
+  const int lgw = ilog2((unsigned)width);
+  const int SH = height == 4 ? 4 : 8;
+  const int units = width * (height == 4 ? 1 : (height >> 3));
+  unsigned sad = 0;
+  auto strip = [&](auto sh_tag, auto dual_tag, int i0, int j) {
+    constexpr int SHC = decltype(sh_tag)::value, DUAL = decltype(dual_tag)::value, NR = SHC + 5;
+    const int woff = mul24(i0 + sp.ver_int - 2 - win.oy, win.pitch) + ((j + sp.hor_int - 2 - win.ox) << 1);   // bytes
+    int hA[NR], hB[NR];
+#if !TK_HOST
+#pragma unroll
+#endif
+    for (int r = 0; r < NR; r++) {
+      const Seg16 sg = win_seg<12>(win.w32, woff + mul24(r, win.pitch));   // six samples
+      hA[r] = dot2_i16(tA[0], sg.d[0], dot2_i16(tA[1], sg.d[1], dot2_i16(tA[2], sg.d[2], 0)));
+      if constexpr (DUAL) hB[r] = dot2_i16(tB[0], sg.d[0], dot2_i16(tB[1], sg.d[1], dot2_i16(tB[2], sg.d[2], 0)));
+      else hB[r] = hA[r];
+    }
+#if !TK_HOST
+#pragma unroll
+#endif
+    for (int q = 0; q < SHC; q++) {
+      int sum = mul24(tv[0], hA[q]) + mul24(tv[1], hA[q + 1]) + mul24(tv[2], hB[q + 2]) + mul24(tv[3], hB[q + 3]) + mul24(tv[4], hA[q + 4]) + mul24(tv[5], hA[q + 5]);
+      const int pr = sat_pix((sum + rnd) >> rsh, bitdepth);
+      const int o = (int)spc<SP>(org_)[mul24(i0 + q, ostride) + j];
+      sad += (unsigned)(o > pr ? o - pr : pr - o);
+    }
+  };
+  struct S4 { enum { value = 4 }; };
+  struct S8 { enum { value = 8 }; };
+  struct D0 { enum { value = 0 }; };
+  struct D1 { enum { value = 1 }; };
+  for (int u = part; u < units; u += 8) {
+    const int j = u & (width - 1), i0 = (u >> lgw) << 3;
+    if (SH == 4) { if (dual) strip(S4(), D1(), 0, j); else strip(S4(), D0(), 0, j); }
+    else { if (dual) strip(S8(), D1(), i0, j); else strip(S8(), D0(), i0, j); }
+  }
+  const unsigned tot = (unsigned)team_group_sum(t, (int)sad, 8);
+  const unsigned cost = (tot >> (bitdepth - 8)) + mv_cost(lam, mv.y - mvp.y, mv.x - mvp.x);
+  unsigned k = (cost << 8) | (unsigned)c;
+  if (part != 0) k = ~0u;
+  return team_min32(t, k);
+}
+
+
 // Bilinear sub-pel approximations of encoder_speed > 0 (sad_calc_fasthalf enc/encode_block.c:174-283 ==
 // sad_calc_fasthalf_simd enc_kernels.c:330, sad_calc_fastquarter :286-415): the SADs of the 8 half-
 // (quarter-) pel neighbours of the centre built from rounding (avg) and truncating (rdavg) byte averages;
@@ -1211,12 +1297,18 @@ TK_DEVNI unsigned motion_estimate(const Team t, MeWs* w_, const PIX* org, const 
     auto sub_cost = [&](int, const SPc& x, int sad) -> unsigned {
       return ((unsigned)sad >> sh) + mv_cost(a.lam, x.mv.y - mvp.y, x.mv.x - mvp.x);
     };
-    // 8-bit PUs of up to 32x32 samples whose interpolation windows lie in the staged window: eight lanes per candidate (me_cand8_subpel)
-    if constexpr (sizeof(PIX) == 1) {
+    // PUs of up to 16x16 samples whose interpolation windows lie in the staged window: eight lanes per candidate (me_cand8_subpel; 16-bit samples since
+    // round 6: me_cand16_subpel)
+    {
 #ifndef TK_ME_NO_SMALL
       if (TKU(a.width * a.height <= 256 && t.size == 64)) {   // (32x32: the 64-lane strip form below is faster - tools/ubench_me.cpp)
-        const unsigned k32 = me_cand8_subpel<SP>(t, org, a.ostride, a.width, a.height, a.sign, a.fwidth, a.fheight, a.xpos, a.ypos, a.enable_bipred, a.lam, win.w32, win.ox, win.oy,
-                                                 win.Ww, win.Wh, win.pitch, win.on, base, d, mvp);
+        unsigned k32;
+        if constexpr (sizeof(PIX) == 1)
+          k32 = me_cand8_subpel<SP>(t, org, a.ostride, a.width, a.height, a.sign, a.fwidth, a.fheight, a.xpos, a.ypos, a.enable_bipred, a.lam, win.w32, win.ox, win.oy,
+                                    win.Ww, win.Wh, win.pitch, win.on, base, d, mvp);
+        else
+          k32 = me_cand16_subpel<SP>(t, org, a.ostride, a.width, a.height, a.sign, a.fwidth, a.fheight, a.xpos, a.ypos, a.enable_bipred, a.lam, win.w32, win.ox, win.oy,
+                                     win.Ww, win.Wh, win.pitch, win.on, base, d, mvp, a.bitdepth);
         if (k32 != 0xffffffffu) {
 #ifdef TK_ME_CROSSCHECK
           xs_sub = k32;
