@@ -59,7 +59,7 @@ CONFIGS = {  # operating points of BASELINE.json: config file, default qp
 }
 REF_ENC = os.path.join(ROOT, 'oracle', '_ref', 'Thorenc')
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
-PMC_JSON = 'r05_pmc_bench.json'
+PMC_JSON = 'r06_pmc_bench.json'
 # v_sad_u8: 4 sample differences per lane and instruction, 64 lanes, one wave64 VALU instruction per 4 clocks and SIMD,
 # 1024 SIMDs at 2.4 GHz (MI355X_MICROARCH.md) -> pixel-differences per second the chip could accumulate
 SAD_PEAK_PXOPS = 1024 * 2.4e9 / 4 * 64 * 4
@@ -786,7 +786,7 @@ def main():
         avg_launch_s = (sb_ms / 1e3) / max(launches, 1)
         achieved = alg_bytes_per_launch / max(avg_launch_s, 1e-12) / 1e9
         # HBM traffic and SQ figures: only from a committed PMC pass of THIS workload geometry AND of this very library
-        # (profiles/r05_pmc_bench.json, written by scripts/pmc_summary.py from rocprofv3 --pmc passes of the same bench geometry; it
+        # (profiles/r06_pmc_bench.json, written by scripts/pmc_summary.py from rocprofv3 --pmc passes of the same bench geometry; it
         # carries csrc_digest() of the sources it profiled); otherwise null - a counter of other code is not attached to this line.
         traffic, traffic_src, valu_util = None, None, None
         try:

@@ -8,5 +8,5 @@ import thor_amd
 import bench
 from test_bench_contract import _HostsimEncoder
 thor_amd.Encoder = _HostsimEncoder
-sys.argv = ['bench.py', '--gpus', '2', '--streams', '2', '--width', '192', '--height', '128', '--steps', '2', '--warmup', '1']
+sys.argv = ['bench.py', '--gpus', '2', '--streams', '2', '--width', '192', '--height', '128', '--steps', '2', '--warmup', '1'] + os.environ.get('THOR_TEST_BENCH_ARGS', '').split()
 bench.main()
