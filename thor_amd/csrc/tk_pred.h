@@ -496,8 +496,13 @@ TK_DEV void pred_chroma(const Team t, PIX* dst_, int dstride, const PIX* ref, in
 // get_inter_prediction_yuv (inter_prediction.c:185-226), 4:2:0.  dst planes are compact blocks
 // of stride `size` (luma) / size/2 (chroma).  `split`: 1 => four quadrant PUs with mv_arr[0..3].
 // SP: address space of the destination blocks py / pu / pv
+#if defined(TK_PIY_INLINE)   // A/B switch (round 6): inline the block prediction into its callers instead of a call that saves 21-27 callee-saved VGPRs
+#define TK_PIY TK_DEV
+#else
+#define TK_PIY TK_DEVNI
+#endif
 template <int SP, typename PIX>
-TK_DEVNI void pred_inter_yuv(const Team t, const Plane3<PIX> ref, PIX* py, PIX* pu, PIX* pv, int ypos, int xpos,
+TK_PIY void pred_inter_yuv(const Team t, const Plane3<PIX> ref, PIX* py, PIX* pu, PIX* pv, int ypos, int xpos,
                            int size, int bw, int bh, const mv_t* mv_arr, int sign, int pic_w, int pic_h,
                            int enable_bipred, int split, int bitdepth, int luma_only = 0) {
   const int div = split + 1;
