@@ -230,7 +230,10 @@ template <typename PIX> void run_cdef(const CdefJob<PIX>* cj, const CdefJob<PIX>
     }
     cdef_pass_flags(C, 0, 1);
     cdef_pass_dir(C, 0, 1);
-    if (C.cdef_bits) cdef_pass_mse(C, 0, 1);
+    if (C.cdef_bits) {   // the wavefront form the device runs (lanes as a loop); the plain form is compared with it in tests/hostsim/unit_cdef.cpp
+      static CdefWaveWs<PIX> ws;
+      for (int b = 0; b < (C.width / 8) * (C.height / 8); b++) cdef_mse_block_wave(t, C, b, &ws);
+    }
     cdef_pass_select(t, C);
     cdef_pass_apply(C, 0, 1);
   }

@@ -97,13 +97,24 @@ template <typename PIX> __global__ void k_copy_planes(const CdefJob<PIX>* cj) {
     for (int x = threadIdx.x; x < w; x += blockDim.x) d[x] = s[x];
   }
 }
-template <typename PIX> __global__ void k_cdef(const CdefJob<PIX>* cj, int pass) {
+// passes 0 (flags), 1 (direction / variance per 8x8 block) and 4 (apply) of CDEF: one instance per pass, so that each gets its own register allocation
+template <typename PIX, int PASS> __global__ __launch_bounds__(256) void k_cdef(const CdefJob<PIX>* cj) {   // (no bound = 1024 threads = a 128-VGPR cap: the apply pass spilled 30)
   const CdefJob<PIX>& C = cj[blockIdx.y];
   const int gid = (int)(blockIdx.x * blockDim.x + threadIdx.x), gsize = (int)(gridDim.x * blockDim.x);
-  if (pass == 0) cdef_pass_flags(C, gid, gsize);
-  else if (pass == 1) cdef_pass_dir(C, gid, gsize);
-  else if (pass == 2) { if (C.cdef_bits) cdef_pass_mse(C, gid, gsize); }
-  else if (pass == 4) cdef_pass_apply(C, gid, gsize);
+  if constexpr (PASS == 0) cdef_pass_flags(C, gid, gsize);
+  else if constexpr (PASS == 1) cdef_pass_dir(C, gid, gsize);
+  else cdef_pass_apply(C, gid, gsize);
+}
+// pass 2 of the CDEF search (tk_cdef.h: wavefront form): one wavefront per 8x8 luma-unit block, four independent wavefronts per workgroup (no workgroup
+// barrier: a wavefront whose block is skipped leaves at once)
+template <typename PIX> __global__ __launch_bounds__(256) void k_cdef_mse(const CdefJob<PIX>* cj) {
+  const CdefJob<PIX>& C = cj[blockIdx.y];
+  if (!C.cdef_bits) return;
+  __shared__ CdefWaveWs<PIX> ws[4];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+  const int b = (int)blockIdx.x * 4 + wave;
+  if (b >= (C.width / 8) * (C.height / 8)) return;
+  cdef_mse_block_wave(mk_team(lane, 64), C, b, &ws[wave]);
 }
 template <typename PIX> __global__ void k_clpf(const ClpfJob<PIX>* lj, int pass) {
   const ClpfJob<PIX>& L = lj[blockIdx.y];
@@ -428,14 +439,13 @@ template <typename PIX> void run_make_ref(const FrameJob<PIX>* hjobs, const Plan
 }
 template <typename PIX> void run_cdef(const CdefJob<PIX>* cj, const CdefJob<PIX>* hcj, int S) {
   const int blocks8 = (hcj[0].width / 8) * (hcj[0].height / 8);
-  const int total = cdef_total_strengths(hcj[0].speed);
   auto ev = ev_begin();
   hipLaunchKernelGGL(k_copy_planes<PIX>, dim3(hcj[0].height * 2, S), dim3(256), 0, g_stream, cj);
-  hipLaunchKernelGGL(k_cdef<PIX>, dim3(64, S), dim3(256), 0, g_stream, cj, 0);
-  hipLaunchKernelGGL(k_cdef<PIX>, dim3((blocks8 + 63) / 64, S), dim3(64), 0, g_stream, cj, 1);
-  hipLaunchKernelGGL(k_cdef<PIX>, dim3((blocks8 * total + 63) / 64, S), dim3(64), 0, g_stream, cj, 2);
+  hipLaunchKernelGGL((k_cdef<PIX, 0>), dim3(64, S), dim3(256), 0, g_stream, cj);
+  hipLaunchKernelGGL((k_cdef<PIX, 1>), dim3((blocks8 + 63) / 64, S), dim3(64), 0, g_stream, cj);
+  hipLaunchKernelGGL(k_cdef_mse<PIX>, dim3((blocks8 + 3) / 4, S), dim3(256), 0, g_stream, cj);
   hipLaunchKernelGGL(k_cdef_select<PIX>, dim3(S), dim3(1024), 0, g_stream, cj);
-  hipLaunchKernelGGL(k_cdef<PIX>, dim3((blocks8 + 63) / 64, S), dim3(64), 0, g_stream, cj, 4);
+  hipLaunchKernelGGL((k_cdef<PIX, 4>), dim3((blocks8 + 63) / 64, S), dim3(64), 0, g_stream, cj);
   HIPCHECK(hipEventRecord(ev.second, g_stream));
   g_filt_events.push_back(ev);
   HIPCHECK(hipGetLastError());

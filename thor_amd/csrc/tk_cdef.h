@@ -40,7 +40,7 @@ template <typename PIX> struct CdefJob {
   int* sel;                        // per compact index: selected preset
   int* fb_sel;                     // per fb: selected preset (or 0)
   CdefResult* res;
-  unsigned long long* tot;         // [64*64] scratch for the joint search
+  unsigned long long* tot;         // [64*64] scratch for the joint search + [nfb] (what the chosen pairs give each non-skip filter block)
 };
 
 TK_DEV int cdef_priconv(int speed, int i) {
@@ -271,6 +271,201 @@ template <typename PIX> TK_DEV void cdef_pass_mse(const CdefJob<PIX>& J, int gid
   }
 }
 
+// ---- pass 2, wavefront form (round 6) ---------------------------------------------------------
+// cdef_pass_mse above is the plain statement: one lane per (block, strength), every lane filtering all the block's samples by itself - 12 bounds-checked
+// loads and 12 constrain() per sample and strength.  Per sample, though, the taps, their differences to the centre and the clamp range depend on the
+// direction only, the primary sum on (direction, primary strength) only and the secondary sum on (direction, secondary strength) only: the 64 strengths of a
+// block need 15 primary sums and 2 x 3 secondary sums per sample (strengths with primary 0 filter along direction 0, common_block.c / encode_frame.c:318),
+// not 64 x 12 constrain().  So here ONE WAVEFRONT takes a block:
+//   load:   the block with its 2-sample halo into LDS once (12 x 12 int16, kCdefVeryLarge outside the frame), the original block beside it;
+//   filter: lane = SAMPLE.  Two tap sets (direction 0, the block's direction), the sums above, then the 64 filtered values of the sample, written to an LDS
+//           matrix [strength][sample] (luma: the value; chroma: |value - original|);
+//   sums:   lane = STRENGTH.  Its row of 64 samples as packed dot products (v_dot4_u32_u8 / v_dot2_u32_u16): sum d, sum d^2, sum s*d -> dist_8x8 in double
+//           arithmetic exactly as before; chroma: sum e^2.  One atomic add per strength.
+// Integer results identical to the plain form by construction (no (int16_t) wrap can occur: |sum| <= 12 * 240 + 12 * 48, samples < 4096);
+// tests/hostsim/unit_cdef.cpp compares the two on random frames (edges, skipped blocks, partial filter blocks, 8/10/12 bits, the three speeds), and the
+// host simulation runs THIS form (lanes as a loop), so every golden stream with cdef on checks it.
+template <typename PIX> struct CdefWaveWs {
+  enum { kRow = 64 * (int)sizeof(PIX) / 4 + 1 };   // dwords per strength row: 64 samples + one pad dword (lane = strength reads stride kRow: conflict-free)
+  int16_t tile[12 * 12];
+  uint32_t org[64 * sizeof(PIX) / 4];
+  uint32_t rows[64 * kRow];
+};
+TK_DEV unsigned cdef_udot4(unsigned a, unsigned b, unsigned c) {
+#if TK_HOST
+  for (int k = 0; k < 4; k++) c += ((a >> (8 * k)) & 0xffu) * ((b >> (8 * k)) & 0xffu);
+  return c;
+#else
+  return __builtin_amdgcn_udot4(a, b, c, false);
+#endif
+}
+TK_DEV unsigned cdef_udot2(unsigned a, unsigned b, unsigned c) {
+#if TK_HOST
+  return c + (a & 0xffffu) * (b & 0xffffu) + (a >> 16) * (b >> 16);
+#else
+  typedef unsigned short __attribute__((ext_vector_type(2))) u16x2;
+  u16x2 x, y;
+  __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4);
+  return __builtin_amdgcn_udot2(x, y, c, false);
+#endif
+}
+// constrain() with the threshold's shift taken out (wave-uniform): thr > 0, sh = damping - ilog2(thr)
+TK_DEV int cdef_constrain_sh(int diff, int thr, int sh) {
+  const int a = iabs(diff);
+  const int m = tmax(thr - (a >> sh), 0);
+  const int r = tmin(a, m);
+  return diff < 0 ? -r : r;
+}
+// load (one lane's share): tile entries lane, lane + 64, lane + 128 and original sample `lane`; (x0, y0) = the block's position in a plane of w x h samples,
+// sx x sy = the part of the 8x8 block inside the plane (chroma blocks at the right / bottom edge)
+template <typename PIX>
+TK_DEV void cdef_wave_load(CdefWaveWs<PIX>* ws, int lane, const PIX* src, int sstride, const PIX* org, int ostride, int x0, int y0, int w, int h, int sx, int sy) {
+  for (int e = lane; e < 144; e += 64) {
+    const int ty = e / 12, tx = e - ty * 12;
+    ldsc(ws->tile)[e] = (int16_t)cdef_fetch(src, sstride, x0 + tx - 2, y0 + ty - 2, w, h);
+  }
+  const int i = lane >> 3, j = lane & 7;
+  ((TK_LDS PIX*)ldsc(ws->org))[lane] = (i < sy && j < sx) ? org[(y0 + i) * ostride + x0 + j] : (PIX)0;
+}
+// tap k (0: near, 1: far) along direction d as an offset in the 12-wide tile: cdef_dy(d, k) * 12 + cdef_dx(d, k), from packed bytes biased by 32 (d is
+// wave-uniform: scalar shifts instead of a table in memory)
+TK_DEV int cdef_off12(int d, int k) {
+  const unsigned long long t = k ? 0x3738393a2e22160aull : 0x2c2c2c2d21212115ull;
+  return (int)((t >> (8 * d)) & 0xffu) - 32;
+}
+// the twelve taps of a sample along direction `dir`: primary differences pd[4] (+near, -near, +far, -far), the clamp range, the secondary sums of sec = 1..3
+TK_DEV void cdef_wave_taps(const TK_LDS int16_t* c, int X, int dir, int cs, int sec_damp, int* pd, int& mn, int& mx, int* S) {
+  const int d2 = (dir + 2) & 7, d6 = (dir + 6) & 7;
+  int lo = X, hi = X;
+  int sd[2][4];
+  for (int k = 0; k < 2; k++) {
+    const int po = cdef_off12(dir, k), ao = cdef_off12(d2, k), bo = cdef_off12(d6, k);
+    const int t[6] = {c[po], c[-po], c[ao], c[-ao], c[bo], c[-bo]};
+    for (int q = 0; q < 6; q++) {
+      lo = tmin(lo, t[q]);
+      hi = tmax(hi, t[q] == kCdefVeryLarge ? X : t[q]);
+    }
+    pd[2 * k] = t[0] - X; pd[2 * k + 1] = t[1] - X;
+    for (int q = 0; q < 4; q++) sd[k][q] = t[2 + q] - X;
+  }
+  mn = lo; mx = hi;
+  for (int sec = 1; sec < 4; sec++) {
+    const int thr = sec << cs, sh = sec_damp - ilog2((unsigned)thr);
+    int s = 0;
+    for (int q = 0; q < 4; q++) s += 2 * cdef_constrain_sh(sd[0][q], thr, sh) + cdef_constrain_sh(sd[1][q], thr, sh);
+    S[sec - 1] = s;
+  }
+}
+// filter (one lane = one sample).  CHROMA: thresholds from the primary strength itself (no variance adjustment), damping - 1, and |filtered - original|
+// into the matrix (0 outside sx x sy).
+template <typename PIX, bool CHROMA>
+TK_DEV void cdef_wave_filter(CdefWaveWs<PIX>* ws, int lane, int speed, int var, int dirb, int damping, int cs, int sx, int sy) {
+  const int npri = cdef_total_strengths(speed) / 4;
+  const int i = lane >> 3, j = lane & 7;
+  const TK_LDS int16_t* const c = ldsc(ws->tile) + (i + 2) * 12 + (j + 2);
+  const int X = c[0];
+  const int damp = CHROMA ? damping - 1 : damping;
+  // [0]: direction 0 (strengths with primary 0), [1]: the block's direction
+  int pd0[4], pd[4], mn0, mx0, mn1, mx1, S0[3], S1[3];
+  cdef_wave_taps(c, X, 0, cs, damp + cs, pd0, mn0, mx0, S0);
+  if (dirb) cdef_wave_taps(c, X, dirb, cs, damp + cs, pd, mn1, mx1, S1);   // wave-uniform branch
+  else {
+    mn1 = mn0; mx1 = mx0;
+    for (int q = 0; q < 3; q++) S1[q] = S0[q];
+    for (int q = 0; q < 4; q++) pd[q] = pd0[q];
+  }
+  const int O = CHROMA ? (int)((const TK_LDS PIX*)ldsc(ws->org))[lane] : 0;
+  const bool inside = !CHROMA || (i < sy && j < sx);
+  TK_LDS PIX* const out = (TK_LDS PIX*)ldsc(ws->rows) + lane;
+  const int rowpix = CdefWaveWs<PIX>::kRow * 4 / (int)sizeof(PIX);
+  for (int k = 0; k < npri; k++) {
+    const int pri = cdef_priconv(speed, k);
+    const int str = CHROMA ? pri : cdef_adjust_strength(pri, var);
+    const int thr = str << cs;
+    const int v = pri ? 1 : 0;
+    int P = 0;
+    if (thr) {   // wave-uniform
+      const int sh = tmax(ilog2((unsigned)str), damp) + cs - ilog2((unsigned)thr);
+      const int w0 = (str & 1) ? 3 : 4, w1 = (str & 1) ? 3 : 2;
+      P = w0 * (cdef_constrain_sh(pd[0], thr, sh) + cdef_constrain_sh(pd[1], thr, sh)) + w1 * (cdef_constrain_sh(pd[2], thr, sh) + cdef_constrain_sh(pd[3], thr, sh));
+    }
+    for (int sec = 0; sec < 4; sec++) {
+      const int sum = P + (sec ? (v ? S1[sec ? sec - 1 : 0] : S0[sec ? sec - 1 : 0]) : 0);
+      int y = X + ((8 + sum - (sum < 0)) >> 4);
+      const int lo = v ? mn1 : mn0, hi = v ? mx1 : mx0;
+      y = y < lo ? lo : y;
+      y = y > hi ? hi : y;
+      out[(k * 4 + sec) * rowpix] = (PIX)(CHROMA ? (inside ? iabs(y - O) : 0) : y);
+    }
+  }
+}
+// sums (one lane = one strength gi): luma -> dist_8x8 of the filtered block against the original; chroma -> sum of squared errors
+template <typename PIX, bool CHROMA> TK_DEV unsigned long long cdef_wave_sums(const CdefWaveWs<PIX>* ws, int gi, int cs) {
+  const TK_LDS uint32_t* const row = ldsc(ws->rows) + gi * CdefWaveWs<PIX>::kRow;
+  const TK_LDS uint32_t* const org = ldsc(ws->org);
+  unsigned sd = 0, sd2 = 0, ssd = 0, ss = 0, ss2 = 0;
+  const unsigned ones = sizeof(PIX) == 1 ? 0x01010101u : 0x00010001u;
+  for (int q = 0; q < 64 * (int)sizeof(PIX) / 4; q++) {
+    const unsigned d = row[q];
+    if constexpr (sizeof(PIX) == 1) {
+      sd2 = cdef_udot4(d, d, sd2);
+      if (!CHROMA) { const unsigned s = org[q]; sd = cdef_udot4(d, ones, sd); ssd = cdef_udot4(d, s, ssd); ss = cdef_udot4(s, ones, ss); ss2 = cdef_udot4(s, s, ss2); }
+    } else {
+      sd2 = cdef_udot2(d, d, sd2);
+      if (!CHROMA) { const unsigned s = org[q]; sd = cdef_udot2(d, ones, sd); ssd = cdef_udot2(d, s, ssd); ss = cdef_udot2(s, ones, ss); ss2 = cdef_udot2(s, s, ss2); }
+    }
+  }
+  if (CHROMA) return sd2;
+  CdefDist a;
+  a.sum_s = ss; a.sum_d = sd; a.sum_s2 = ss2; a.sum_d2 = sd2; a.sum_sd = ssd;
+  return cdef_dist_finish(a, cs);
+}
+// The lanes of the wavefront: the hardware's on the device (t.rank), a loop on the host.
+#if TK_HOST
+#define TK_CDEF_LANES(l) for (int l = 0; l < 64; l++)
+#else
+#define TK_CDEF_LANES(l) for (int l = t.rank, once_ = 1; once_; once_ = 0)
+#endif
+// One 8x8 luma-unit block b (all of the team's lanes call this with the same b): the same skips, strengths and sums as one b of cdef_pass_mse.
+template <typename PIX> TK_DEV void cdef_mse_block_wave(const Team t, const CdefJob<PIX>& J, int b, CdefWaveWs<PIX>* ws) {
+  const int bw = J.width / 8;
+  const int total = cdef_total_strengths(J.speed);
+  const int nfb = J.nfb_h * J.nfb_v;
+  const int cs = J.bitdepth - 8;
+  const int by = b / bw, bx = b - by * bw;
+  const int fb = (by / 8) * J.nfb_h + bx / 8;
+  if (J.fb_compact[fb] < 0) return;
+  if (J.cells[(by * 2) * J.cs + bx * 2].mode == M_SKIP) return;
+  const int var = J.var[b], dirb = J.dir[b];
+  // luma
+  TK_CDEF_LANES(l) cdef_wave_load(ws, l, J.src.y, J.src.sy, J.org.y, J.org.sy, bx * 8, by * 8, J.width, J.height, 8, 8);
+  t.sync();
+  TK_CDEF_LANES(l) cdef_wave_filter<PIX, false>(ws, l, J.speed, var, dirb, J.damping, cs, 8, 8);
+  t.sync();
+  TK_CDEF_LANES(l) if (l < total) team_add64(&J.mse[(0 * nfb + fb) * kCdefMaxStr + l], cdef_wave_sums<PIX, false>(ws, l, cs));
+  // chroma: the (m, n)-th 8x8 CHROMA block of the filter block with this luma block's skip flag and direction, the first (h+7)>>4 x (w+7)>>4 only (see above)
+  const int fbx = bx / 8, fby = by / 8, n = bx & 7, m = by & 7;
+  int h = tmin(J.height, (fby + 1) << 6) & 63, w = tmin(J.width, (fbx + 1) << 6) & 63;
+  h += (!h) << 6;
+  w += (!w) << 6;
+  if (m < ((h + 7) >> 4) && n < ((w + 7) >> 4)) {
+    const int cx = fbx * 32 + n * 8, cy = fby * 32 + m * 8;
+    const int sizex = tmin(J.width / 2 - cx, 8), sizey = tmin(J.height / 2 - cy, 8);
+    unsigned long long sse[TK_HOST ? 64 : 1];
+    TK_CDEF_LANES(l) sse[TK_HOST ? l : 0] = 0;
+    for (int pl = 0; pl < 2; pl++) {
+      t.sync();   // the previous sums have read the matrix
+      TK_CDEF_LANES(l) cdef_wave_load(ws, l, pl ? J.src.v : J.src.u, J.src.sc, pl ? J.org.v : J.org.u, J.org.sc, cx, cy, J.width / 2, J.height / 2, sizex, sizey);
+      t.sync();
+      TK_CDEF_LANES(l) cdef_wave_filter<PIX, true>(ws, l, J.speed, var, dirb, J.damping, cs, sizex, sizey);
+      t.sync();
+      TK_CDEF_LANES(l) if (l < total) sse[TK_HOST ? l : 0] += cdef_wave_sums<PIX, true>(ws, l, cs);
+    }
+    TK_CDEF_LANES(l) if (l < total) team_add64(&J.mse[(1 * nfb + fb) * kCdefMaxStr + l], sse[TK_HOST ? l : 0]);
+  }
+  t.sync();
+}
+
 // ---- pass 3: joint luma+chroma strength selection (single team) ------------------------------
 // search_one_dual / joint_strength_search_dual (encode_frame.c:86-192) + the sort / dedupe /
 // per-block assignment tail of cdef_search (:380-470).
@@ -278,17 +473,18 @@ template <typename PIX, class TeamT> TK_DEV void cdef_pass_select(const TeamT t,
   const int nfb = J.nfb_h * J.nfb_v;
   const int total = cdef_total_strengths(J.speed);
   CdefResult* R = J.res;
-  // compact list of non-skip filter blocks, raster order
+  // compact list of non-skip filter blocks, raster order (J.sel holds the list during the search; its final contents are written at the end)
   if (t.rank == 0) {
     int n = 0;
     for (int fb = 0; fb < nfb; fb++)
-      if (J.fb_compact[fb] >= 0) J.fb_compact[fb] = n++;
+      if (J.fb_compact[fb] >= 0) { J.sel[n] = fb; J.fb_compact[fb] = n++; }
     R->sb_count = n;
   }
   t.block_sync();
   const int sbc = R->sb_count;
   const unsigned long long* mse0 = J.mse;
   const unsigned long long* mse1 = J.mse + (size_t)nfb * kCdefMaxStr;
+  unsigned long long* const bestv = J.tot + kCdefMaxStr * kCdefMaxStr;   // [sb_count]
   if (J.cdef_bits == 0) {
     // fixed strengths guessed from the frame QP (encode_frame.c:260-281); no per-block signalling
     if (t.rank == 0) {
@@ -314,19 +510,26 @@ template <typename PIX, class TeamT> TK_DEV void cdef_pass_select(const TeamT t,
       nsel = nb_strengths - 1;
     }
     t.block_sync();
+    // what the already chosen pairs give each filter block does not depend on the candidate pair (j, k): once per call, not once per candidate
+    for (int q = t.rank; q < sbc; q += t.size) {
+      const int fb = J.sel[q];
+      const unsigned long long* m0 = mse0 + (size_t)fb * kCdefMaxStr;
+      const unsigned long long* m1 = mse1 + (size_t)fb * kCdefMaxStr;
+      unsigned long long best = 1ull << 63;
+      for (int g = 0; g < nsel; g++) {
+        unsigned long long c = m0[lev0[g]] + m1[lev1[g]];
+        if (c < best) best = c;
+      }
+      bestv[q] = best;
+    }
+    t.block_sync();
     for (int jk = t.rank; jk < total * total; jk += t.size) {
       const int j = jk / total, k = jk - j * total;
       unsigned long long acc = 0;
-      for (int fb = 0; fb < nfb; fb++) {
-        if (J.fb_compact[fb] < 0) continue;
-        const unsigned long long* m0 = mse0 + (size_t)fb * kCdefMaxStr;
-        const unsigned long long* m1 = mse1 + (size_t)fb * kCdefMaxStr;
-        unsigned long long best = 1ull << 63;
-        for (int g = 0; g < nsel; g++) {
-          unsigned long long c = m0[lev0[g]] + m1[lev1[g]];
-          if (c < best) best = c;
-        }
-        unsigned long long c = m0[j] + m1[k];
+      for (int q = 0; q < sbc; q++) {
+        const int fb = J.sel[q];
+        const unsigned long long c = mse0[(size_t)fb * kCdefMaxStr + j] + mse1[(size_t)fb * kCdefMaxStr + k];
+        const unsigned long long best = bestv[q];
         acc += c < best ? c : best;
       }
       J.tot[jk] = acc;
@@ -386,7 +589,6 @@ template <typename PIX, class TeamT> TK_DEV void cdef_pass_select(const TeamT t,
       R->uv_strengths[q] = cdef_priconv(J.speed, uvs[q] / 4) * 4 + (uvs[q] % 4);
     }
     R->nb_bits = nb_bits;
-    (void)sbc;
   }
   t.block_sync();
 }

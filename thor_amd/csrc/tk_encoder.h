@@ -441,7 +441,7 @@ template <typename PIX> class Engine {
       s.cdef_sel = (int*)backend::dev_alloc(nfb * sizeof(int));
       s.cdef_fbsel = (int*)backend::dev_alloc(nfb * sizeof(int));
       s.cdef_res = (CdefResult*)backend::dev_alloc(sizeof(CdefResult));
-      s.cdef_tot = (unsigned long long*)backend::dev_alloc((size_t)kCdefMaxStr * kCdefMaxStr * 8);
+      s.cdef_tot = (unsigned long long*)backend::dev_alloc(((size_t)kCdefMaxStr * kCdefMaxStr + nfb) * 8);
       if (p.clpf) {
         s.clpf_stats = (uint32_t*)backend::dev_alloc(clpf_stat_words() * 4);
         s.clpf_fb_on = (uint8_t*)backend::dev_alloc((size_t)((p.width + 31) / 32) * ((p.height + 31) / 32));
