@@ -686,8 +686,13 @@ def main():
         try:
             import ctypes as C_
             r_, l_, p_, w_ = C_.c_int(), C_.c_int(), C_.c_int(), C_.c_int()
-            if thor_amd.lib().thor_hip_superblock_kernel_info(bps, C_.byref(r_), C_.byref(l_), C_.byref(p_), C_.byref(w_)) == 0:
-                kinfo = {'vgprs': r_.value, 'lds_bytes': l_.value, 'private_bytes_per_lane': p_.value, 'workgroups_per_cu': w_.value}
+            # the build of the 8-bit kernel this run launched (the library picks by stream count and geometry): its resources, not the throughput build's
+            in_use = thor_amd.lib().thor_hip_superblock_kernel_in_use() if bps == 1 else 0
+            which = {0: bps, 1: 0, 2: 3}[in_use]
+            if thor_amd.lib().thor_hip_superblock_kernel_info(which, C_.byref(r_), C_.byref(l_), C_.byref(p_), C_.byref(w_)) == 0:
+                kinfo = {'build': ('throughput (thor_hip.cpp, four wavefronts per workgroup)', 'latency (thor_hip_lat.cpp, four wavefronts per workgroup)',
+                                   'wide (thor_hip_wide.cpp, eight wavefronts per workgroup)')[in_use],
+                         'vgprs': r_.value, 'lds_bytes': l_.value, 'private_bytes_per_lane': p_.value, 'workgroups_per_cu': w_.value}
         except (AttributeError, OSError):
             pass
 

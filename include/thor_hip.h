@@ -210,9 +210,13 @@ int thor_hip_kat_clpf(const void* rec_yuv, const void* org_yuv, int width, int h
 int thor_hip_kat_interpolate(const void* yuv0, const void* yuv1, int width, int height, int bitdepth, void* out_yuv);
 
 /* Resources of the persistent superblock kernel (sample_bytes 1: 8-bit kernel, 2: 16-bit kernel, 0: the 8-bit kernel's second build for runs of few
- * streams - 256 registers, two workgroups per CU, chosen by the library when a run cannot fill more; THOR_HIP_KERNEL=std|lat forces one) as the HIP runtime reports them: registers per lane,
+ * streams - 256 registers, two workgroups per CU, chosen by the library when a run cannot fill more; THOR_HIP_KERNEL=std|lat|wide forces one; 3: its third build - eight wavefronts per workgroup, one workgroup per CU, for runs of very few streams) as the HIP runtime reports them: registers per lane,
  * static LDS and private (scratch) bytes, and how many workgroups of it fit one CU - what the resident-workgroup count of every launch derives from. */
 int thor_hip_superblock_kernel_info(int sample_bytes, int* num_regs, int* lds_bytes, int* private_bytes, int* workgroups_per_cu);
+/* The build of the 8-bit superblock kernel the most recently configured engine launches: 0 = throughput build (168 registers, three four-wavefront
+ * workgroups per CU), 1 = latency build (sample_bytes 0 above), 2 = eight wavefronts per workgroup, one workgroup per CU (sample_bytes 3 above: chosen when
+ * all streams of a run together never offer more superblocks than the chip has CUs).  Valid after the engine's first encode call. */
+int thor_hip_superblock_kernel_in_use(void);
 
 #ifdef __cplusplus
 }

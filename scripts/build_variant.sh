@@ -5,5 +5,5 @@ set -e
 R="$(cd "$(dirname "$0")/.." && pwd)"
 name=$1; shift
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-strict-aliasing -fPIC -shared -pthread "$@" \
-  -o "$R/thor_amd/libthor_hip_$name.so" "$R/thor_amd/csrc/thor_hip.cpp" $( [ -f "$R/thor_amd/csrc/thor_hip_lat.cpp" ] && echo "$R/thor_amd/csrc/thor_hip_lat.cpp" ) 2>&1 | grep -E "error:" || true
+  -o "$R/thor_amd/libthor_hip_$name.so" "$R/thor_amd/csrc/thor_hip.cpp" $( [ -f "$R/thor_amd/csrc/thor_hip_lat.cpp" ] && echo "$R/thor_amd/csrc/thor_hip_lat.cpp" ) $( [ -f "$R/thor_amd/csrc/thor_hip_wide.cpp" ] && echo "$R/thor_amd/csrc/thor_hip_wide.cpp" ) 2>&1 | grep -E "error:" || true
 ls -la "$R/thor_amd/libthor_hip_$name.so"

@@ -24,9 +24,10 @@ def encode_gpu(clip, w, h, n, qp, streams=1, skip=0, cfg=None, staggered=False, 
 
 
 def _kernels(name):
-    # 8-bit goldens run through BOTH builds of the superblock kernel (round 6): the throughput build (168 VGPRs, three workgroups per CU) and the build for
-    # runs of few streams (256 VGPRs, two per CU: what the library picks by itself for one or a few streams); 16-bit samples have one kernel
-    return ['std'] if 'bit' in name and ('10bit' in name or '12bit' in name) else ['std', 'lat']
+    # 8-bit goldens run through ALL THREE builds of the superblock kernel (round 6): the throughput build (168 VGPRs, three four-wave workgroups per CU), the
+    # latency build (256 VGPRs, two per CU) and the wide build (eight wavefronts per workgroup, one per CU) - the library picks by itself among them from the
+    # number of streams and the geometry; 16-bit samples have one kernel
+    return ['std'] if 'bit' in name and ('10bit' in name or '12bit' in name) else ['std', 'lat', 'wide']
 
 
 @pytest.mark.parametrize('name,kernel', [(n, k) for n in sorted(G) for k in _kernels(n)])
@@ -177,7 +178,7 @@ def test_superblock_kernel_keeps_three_workgroups_per_cu():
     import ctypes as C
     import thor_amd
     L = thor_amd.lib()
-    for sb, regs_max, wgs in ((1, 168, 3), (2, 256, 2), (0, 256, 2)):   # 0: the 8-bit kernel's build for runs of few streams
+    for sb, regs_max, wgs in ((1, 168, 3), (2, 256, 2), (0, 256, 2), (3, 256, 1)):   # 0 / 3: the 8-bit kernel's builds for runs of few streams
         r, lds, prv, per = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         assert L.thor_hip_superblock_kernel_info(sb, C.byref(r), C.byref(lds), C.byref(prv), C.byref(per)) == 0
         assert r.value <= regs_max and per.value == wgs, (sb, r.value, lds.value, prv.value, per.value)

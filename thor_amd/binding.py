@@ -14,7 +14,7 @@ def lib_path():
 
 
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-strict-aliasing', '-fPIC', '-pthread']
-NATIVE_SOURCES = ['thor_hip.cpp', 'thor_hip_lat.cpp']   # the throughput build of the engine + its second build for the few-stream operating point
+NATIVE_SOURCES = ['thor_hip.cpp', 'thor_hip_lat.cpp', 'thor_hip_wide.cpp']   # the throughput build of the engine + its two builds for the few-stream operating points
 
 
 def build_native(force=False):

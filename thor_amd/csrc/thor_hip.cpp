@@ -32,10 +32,14 @@
   } while (0)
 
 // the second build of the engine (thor_hip_lat.cpp: 256 VGPRs, two workgroups per CU - the few-stream operating point)
-extern "C" __attribute__((visibility("hidden"))) int thor_lat_upload_tables(const void* tables, size_t bytes);
-extern "C" __attribute__((visibility("hidden"))) int thor_lat_workgroups_per_cu(void);
-extern "C" __attribute__((visibility("hidden"))) int thor_lat_kernel_info(int* num_regs, int* lds_bytes, int* private_bytes);
-extern "C" __attribute__((visibility("hidden"))) int thor_lat_launch_u8(int wgs, void* stream, const void* jobs, const void* dfargs, size_t dfargs_bytes, size_t job_bytes, size_t slot_bytes);
+#define TK_ALT_DECLS(P)                                                                                                                  \
+  extern "C" __attribute__((visibility("hidden"))) int P##upload_tables(const void* tables, size_t bytes);                                 \
+  extern "C" __attribute__((visibility("hidden"))) int P##workgroups_per_cu(void);                                                         \
+  extern "C" __attribute__((visibility("hidden"))) int P##waves(void);                                                                     \
+  extern "C" __attribute__((visibility("hidden"))) int P##kernel_info(int* num_regs, int* lds_bytes, int* private_bytes);                  \
+  extern "C" __attribute__((visibility("hidden"))) int P##launch_u8(int wgs, void* stream, const void* jobs, const void* dfargs, size_t dfargs_bytes, size_t job_bytes, size_t slot_bytes);
+TK_ALT_DECLS(thor_lat_)    // thor_hip_lat.cpp: 256 VGPRs, two four-wave workgroups per CU
+TK_ALT_DECLS(thor_wide_)   // thor_hip_wide.cpp: eight-wave workgroups, one per CU
 
 namespace tk {
 __device__ Tables g_tab;
@@ -246,7 +250,7 @@ static bool ensure_init(int device) {
   static Tables h;
   init_tables(&h);
   HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tab), &h, sizeof(h)));
-  if (thor_lat_upload_tables(&h, sizeof(h))) { fprintf(stderr, "Run-time error...\nthor_hip: table upload of the latency kernel failed\n...now exiting to system...\n"); abort(); }
+  if (thor_lat_upload_tables(&h, sizeof(h)) || thor_wide_upload_tables(&h, sizeof(h))) { fprintf(stderr, "Run-time error...\nthor_hip: table upload of the few-stream kernels failed\n...now exiting to system...\n"); abort(); }
   g_inited = true;
   return true;
 }
@@ -297,9 +301,10 @@ struct DfState {  // per engine (keyed by its device job array)
   int S = 0, nsb = 0, wgs = 0;
   size_t slot = 0;
   int frame = 0;
-  int lat = 0;   // 1: this engine's launches use the latency kernel (thor_hip_lat.cpp)
+  int kern = 0;  // the build of the 8-bit kernel this engine's launches use: 0 thor_hip.cpp (throughput), 1 thor_hip_lat.cpp, 2 thor_hip_wide.cpp
 };
 static std::map<const void*, DfState> g_df;
+static int g_last_kern = 0;   // build of the 8-bit kernel the most recently configured engine uses (thor_hip_superblock_kernel_in_use)
 static void df_free(DfState& D) {
   if (!D.ctl) return;
   HIPCHECK(hipFree(D.ctl)); HIPCHECK(hipFree(D.queue)); HIPCHECK(hipFree(D.cnt)); HIPCHECK(hipFree(D.pool)); HIPCHECK(hipFree(D.range));
@@ -321,23 +326,32 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
     HIPCHECK(hipGetDevice(&dev));
     HIPCHECK(hipGetDeviceProperties(&prop, dev));
     long cap = (long)(per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
-    // Which build of the kernel: a stream offers at most min(rows, (cols + 1) / 2) superblocks at a time (the dependency wavefront); when all streams
-    // together cannot occupy more workgroups than the latency kernel (256 VGPRs, two per CU) has room for, that kernel runs them - no spills, larger
-    // search windows, nothing lost.  8-bit samples only (the 16-bit kernel has that budget anyway).  THOR_HIP_KERNEL=std|lat forces one (tests, A/B).
+    // Which build of the kernel: a stream offers at most min(rows, (cols + 1) / 2) superblocks at a time (the dependency wavefront).  When all streams
+    // together can never offer more superblocks than there are CUs, eight-wave workgroups (one per CU) run them; when they cannot occupy more workgroups
+    // than the latency kernel (256 VGPRs, two per CU) has room for, that kernel does - no spills, larger search windows, nothing lost.  8-bit samples only
+    // (the 16-bit kernel has that budget anyway).  THOR_HIP_KERNEL=std|lat|wide forces one (tests, A/B).
+    int pool_waves = kWaves;
     if constexpr (sizeof(PIX) == 1) {
       const long lat_cap = (long)thor_lat_workgroups_per_cu() * prop.multiProcessorCount;
+      const long wide_cap = (long)thor_wide_workgroups_per_cu() * prop.multiProcessorCount;
       const long wave_front = (long)S * (rows < (cols + 1) / 2 ? rows : (cols + 1) / 2);
-      D.lat = lat_cap > 0 && wave_front <= lat_cap;
-      if (const char* e = getenv("THOR_HIP_KERNEL")) { if (!strcmp(e, "lat")) D.lat = lat_cap > 0; else if (!strcmp(e, "std")) D.lat = 0; }
-      if (D.lat) cap = lat_cap;
+      D.kern = wide_cap > 0 && wave_front <= wide_cap ? 2 : lat_cap > 0 && wave_front <= lat_cap ? 1 : 0;
+      if (const char* e = getenv("THOR_HIP_KERNEL")) {
+        if (!strcmp(e, "lat")) D.kern = lat_cap > 0 ? 1 : 0;
+        else if (!strcmp(e, "wide")) D.kern = wide_cap > 0 ? 2 : 0;
+        else if (!strcmp(e, "std")) D.kern = 0;
+      }
+      if (D.kern == 1) cap = lat_cap;
+      if (D.kern == 2) { cap = wide_cap; pool_waves = thor_wide_waves(); }
     }
+    g_last_kern = sizeof(PIX) == 1 ? D.kern : 0;
     if (const char* e = getenv("THOR_HIP_WGS")) { if (*e) cap = atol(e); }
     D.wgs = (int)(cap < (long)all ? cap : (long)all);
     HIPCHECK(hipMalloc(&D.ctl, sizeof(DfCtl)));
     HIPCHECK(hipMalloc(&D.queue, sizeof(unsigned) * all));
     HIPCHECK(hipMalloc(&D.cnt, sizeof(unsigned) * all));
     HIPCHECK(hipMalloc(&D.range, sizeof(unsigned) * S));
-    HIPCHECK(hipMalloc(&D.pool, slot * (size_t)D.wgs * kWaves));  // one BigWs slot per wavefront
+    HIPCHECK(hipMalloc(&D.pool, slot * (size_t)D.wgs * pool_waves));  // one BigWs slot per wavefront
     if (getenv("THOR_SBTIMES")) { HIPCHECK(hipMalloc(&D.times, sizeof(unsigned long long) * 3 * all)); }
   }
   // launch start: the superblocks of every stream's range whose dependencies all lie below the range (whole frames: SB(0,0))
@@ -374,8 +388,8 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
   if (const char* e = getenv("THOR_HIP_SPIN_TIMEOUT_S")) lim_s = atof(e);
   A.spin_limit = (unsigned long long)(lim_s * 1e8);
   auto ev = ev_begin();
-  if (D.lat) {
-    if (thor_lat_launch_u8(D.wgs, (void*)g_stream, jobs, &A, sizeof(A), sizeof(FrameJob<PIX>), slot)) { fprintf(stderr, "Run-time error...\nthor_hip: launch of the latency kernel failed\n...now exiting to system...\n"); abort(); }
+  if (D.kern) {
+    if ((D.kern == 2 ? thor_wide_launch_u8 : thor_lat_launch_u8)(D.wgs, (void*)g_stream, jobs, &A, sizeof(A), sizeof(FrameJob<PIX>), slot)) { fprintf(stderr, "Run-time error...\nthor_hip: launch of a few-stream kernel failed\n...now exiting to system...\n"); abort(); }
   } else
     hipLaunchKernelGGL(k_superblocks<PIX>, dim3(D.wgs), dim3(kWgThreads), 0, g_stream, jobs, A);
   g_clk.sb_launches++;
@@ -1464,6 +1478,10 @@ extern "C" int thor_hip_superblock_kernel_info(int sample_bytes, int* num_regs, 
     if (thor_lat_kernel_info(num_regs, lds_bytes, private_bytes)) return 2;
     if (workgroups_per_cu) *workgroups_per_cu = thor_lat_workgroups_per_cu();
     return 0;
+  } else if (sample_bytes == 3) {   // the eight-wavefront build of the 8-bit kernel (thor_hip_wide.cpp)
+    if (thor_wide_kernel_info(num_regs, lds_bytes, private_bytes)) return 2;
+    if (workgroups_per_cu) *workgroups_per_cu = thor_wide_workgroups_per_cu();
+    return 0;
   } else return 1;
   if (num_regs) *num_regs = a.numRegs;
   if (lds_bytes) *lds_bytes = (int)a.sharedSizeBytes;
@@ -1471,3 +1489,6 @@ extern "C" int thor_hip_superblock_kernel_info(int sample_bytes, int* num_regs, 
   if (workgroups_per_cu) *workgroups_per_cu = per_cu;
   return 0;
 }
+// Which build of the 8-bit superblock kernel the engine configured last launches with: 0 throughput (thor_hip.cpp), 1 latency (thor_hip_lat.cpp), 2 eight
+// wavefronts per workgroup (thor_hip_wide.cpp).  Decided at the engine's first launch from the number of streams and the geometry (run_superblocks).
+extern "C" int thor_hip_superblock_kernel_in_use(void) { return tk::backend::g_last_kern; }
