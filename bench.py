@@ -4,9 +4,11 @@
 
 Workload ("step"): one lock-step frame of S independent closed streams (sequence chunks - the only partition of this
 path that is bit-exact, SURVEY.md 8e: stream s is exactly what the reference produces with -skip/-n for its chunk).
-128 streams per GPU: a stream's superblocks form a 62-step dependency chain at 3840x2160, so a frame takes at least 62
-superblock times whatever the number of streams; 128 streams keep 88 % of the 768 resident workgroups busy through the
-ramp-up / ramp-down of the dependency wavefront (profiles/r04_sbtimes_4k_s128_fifo.log).
+160 streams per GPU: a stream's superblocks form a 62-step dependency chain at 3840x2160, so a frame takes at least 62
+superblock times whatever the number of streams; the streams are coded in two groups half a frame apart so that the ramp-up of
+one group's dependency wavefront fills the slots the other's ramp-down leaves (93-95 % of the 768 resident workgroups busy).
+Measured in the driver's regime (round 6, call 12, same library): 128 streams ~124.7, 144 -> 126.9, 160 -> 128.2 Mpixels/s
+(round 5 had 192 streams 3 % below 128): 160 is the default.
 Warm-up steps include each stream's I frame; the timed K steps are the following frames in coding order.  Defaults:
 warm-up 1 (the I frame) + 4 timed P frames, the last of which searches all 4 reference frames of the operating point; the
 driver's `--steps 20 --warmup 5` times P frames 5..24, all with 4 references + bi-prediction.  Inputs are resident in HBM
@@ -22,8 +24,8 @@ timed region (with the driver's flags: I, P1..P4 and the first timed 4-reference
 frames and the reconstruction of EVERY one of them must equal the reference's; `bit_exact_scope` says which timed frames that
 covers; "bit_exact": false zeroes the metric and the exit code is 1.  On top of the live runs EVERY RANK compares every coded frame -
 the whole bitstream and the reconstruction of each frame, so all the timed frames - of those of its streams for which a reference run
-was recorded in the build container (scripts/record_bench_refs.py -> tests/golden/bench_refs.json: 11 streams of rank 0 of the headline
-workload with the driver's flags and the first stream of each further rank up to 8 GPUs; the reference needs ~11 minutes per 25-frame 3840x2160
+was recorded in the build container (scripts/record_bench_refs.py -> tests/golden/bench_refs.json: the first, middle and last stream of rank 0 and ten more of its streams of the headline
+workload with the driver's flags, and streams of every further rank up to 8 GPUs; the reference needs ~11 minutes per 25-frame 3840x2160
 stream on one core, which no default run can wait for).  `--verify recorded` uses the records only (the RA / HDB16 operating points at
 3840x2160), `--verify live` the live runs only.
 cpu_baseline: CPU seconds (wait4 rusage) of reference runs taken when the processes exit; an implausible value is an error, not a number.
@@ -372,7 +374,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=4)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--streams', type=int, default=int(os.environ.get('THOR_BENCH_STREAMS', '128')), help='streams PER GPU')
+    ap.add_argument('--streams', type=int, default=int(os.environ.get('THOR_BENCH_STREAMS', '160')), help='streams PER GPU')
     ap.add_argument('--width', type=int, default=3840)
     ap.add_argument('--height', type=int, default=2160)
     ap.add_argument('--config', choices=sorted(CONFIGS), default='ldb')
