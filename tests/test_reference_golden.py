@@ -60,6 +60,16 @@ def test_engine_multi_wave_host_simulation_matches_golden(name):
         assert md5(rec) == c['rec_md5'], 'reconstruction differs from the reference'
 
 
+@pytest.mark.parametrize('name', ['192x128_n6_q32', '128x96_n9_q32_ra', '208x120_n4_q30_ldb_medium'])
+def test_engine_eight_wave_host_simulation_matches_golden(name):
+    """Workgroups of EIGHT wavefronts - the width of the third build of the 8-bit kernel (thor_hip_wide.cpp, what the library launches for runs of very few
+    streams): the work queue drained by eight waves, the bi-prediction phase's rows split eight ways, eight per-wave minima at the join."""
+    c = G[name]
+    bits, rec = run_encoder(build_hostsim(waves=8), golden_clip(c['clip']), c['w'], c['h'], c['n'], c['qp'], c['extra'], cfg=c.get('cfg'))
+    assert md5(bits) == c['bit_md5'], 'stream differs from the reference'
+    assert md5(rec) == c['rec_md5'], 'reconstruction differs from the reference'
+
+
 @needs_ref
 def test_sixteen_lane_teams_search_window_and_row_segments_vs_live_reference():
     """16-lane teams on a 64x64 clip (I + 2 P): with 16 lanes the PUs up to 16x16 take the side-by-side row-segment path of the
