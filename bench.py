@@ -798,12 +798,17 @@ def main():
         traffic, traffic_src, valu_util = None, None, None
         try:
             pm = json.load(open(os.path.join(ROOT, 'profiles', PMC_JSON)))
-            if pm.get('csrc_digest') != csrc_digest():
+            # `same_device_code`: digests of later source states whose DEVICE code of the profiled translation unit is identical to the profiled one (host-side or
+            # comment-only changes), each with the check that established it (scripts/device_code_same.sh: hipcc --cuda-device-only -S of both states, diffed)
+            same = {e.get('csrc_digest'): e.get('check', '') for e in pm.get('same_device_code', [])}
+            if pm.get('csrc_digest') != csrc_digest() and csrc_digest() not in same:
                 traffic_src = f'profiles/{PMC_JSON} describes other engine sources (digest {pm.get("csrc_digest")} != {csrc_digest()}): not attached'
             elif (pm.get('width') == w and pm.get('height') == h and pm.get('streams') == S and pm.get('config', 'ldb') == a.config and
                   pm.get('sigma', 2.0) == a.sigma and not hbd):   # same geometry, operating point and content as the profiled workload
                 traffic = round((pm['fetch_bytes_per_px'] + pm['write_bytes_per_px']) * w * h * S * a.steps / max(launches, 1))
                 traffic_src = f'profiles/{PMC_JSON[:-5]}.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this geometry and of these sources (%s)' % pm['workload']
+                if pm.get('csrc_digest') != csrc_digest():
+                    traffic_src += f'; profiled at source digest {pm.get("csrc_digest")}, these sources ({csrc_digest()}) have the same device code: ' + same[csrc_digest()]
                 valu_util = pm.get('valu_util_chip')
         except (OSError, KeyError, ValueError):
             pass

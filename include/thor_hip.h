@@ -214,8 +214,8 @@ int thor_hip_kat_interpolate(const void* yuv0, const void* yuv1, int width, int 
  * static LDS and private (scratch) bytes, and how many workgroups of it fit one CU - what the resident-workgroup count of every launch derives from. */
 int thor_hip_superblock_kernel_info(int sample_bytes, int* num_regs, int* lds_bytes, int* private_bytes, int* workgroups_per_cu);
 /* The build of the 8-bit superblock kernel the most recently configured engine launches: 0 = throughput build (168 registers, three four-wavefront
- * workgroups per CU), 1 = latency build (sample_bytes 0 above), 2 = eight wavefronts per workgroup, one workgroup per CU (sample_bytes 3 above: chosen when
- * all streams of a run together never offer more superblocks than the chip has CUs).  Valid after the engine's first encode call. */
+ * workgroups per CU), 1 = latency build (sample_bytes 0 above), 2 = eight wavefronts per workgroup, one workgroup per CU (sample_bytes 3 above: chosen while
+ * all streams of a run together offer at most 2.5 superblocks per CU; the latency build runs only when THOR_HIP_KERNEL=lat forces it).  Valid after the engine's first encode call. */
 int thor_hip_superblock_kernel_in_use(void);
 
 #ifdef __cplusplus

@@ -220,10 +220,15 @@ def test_pmc_figures_are_attached_only_to_the_sources_they_describe(monkeypatch)
         json.dump(pm, open(path, 'w'))
         r = run()
         assert r['traffic'] is None and 'other engine sources' in r['traffic_source']
+        pm['same_device_code'] = [{'csrc_digest': bench.csrc_digest(), 'check': 'device assembly diffed'}]   # a later source state with identical device code
+        json.dump(pm, open(path, 'w'))
+        r = run()
+        assert r['traffic'] == round(15.0 * 64 * 64 * 3 * 2 / 2) and 'same device code: device assembly diffed' in r['traffic_source']
+        del pm['same_device_code']
         pm['csrc_digest'] = bench.csrc_digest()
         json.dump(pm, open(path, 'w'))
         r = run()
-        assert r['traffic'] == round(15.0 * 64 * 64 * 3 * 2 / 2) and r['ops']['valu_util_chip'] == 0.5
+        assert r['traffic'] == round(15.0 * 64 * 64 * 3 * 2 / 2) and r['ops']['valu_util_chip'] == 0.5 and 'same device code' not in r['traffic_source']
         assert run(['--sigma', '6'])['traffic'] is None       # other content than the profiled workload
         assert run(['--streams', '4'])['traffic'] is None     # other geometry
     finally:

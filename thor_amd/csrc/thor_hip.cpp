@@ -326,16 +326,19 @@ template <typename PIX> void run_superblocks(const FrameJob<PIX>* jobs, const Fr
     HIPCHECK(hipGetDevice(&dev));
     HIPCHECK(hipGetDeviceProperties(&prop, dev));
     long cap = (long)(per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
-    // Which build of the kernel: a stream offers at most min(rows, (cols + 1) / 2) superblocks at a time (the dependency wavefront).  When all streams
-    // together can never offer more superblocks than there are CUs, eight-wave workgroups (one per CU) run them; when they cannot occupy more workgroups
-    // than the latency kernel (256 VGPRs, two per CU) has room for, that kernel does - no spills, larger search windows, nothing lost.  8-bit samples only
-    // (the 16-bit kernel has that budget anyway).  THOR_HIP_KERNEL=std|lat|wide forces one (tests, A/B).
+    // Which build of the kernel: a stream offers at most min(rows, (cols + 1) / 2) superblocks at a time (the dependency wavefront).  Eight-wave workgroups
+    // (one per CU) finish a superblock ~25 % sooner than four-wave ones and saturate at ~3/4 of the throughput build's peak, which that build only reaches
+    // with well over a hundred streams: measured (round 6, call 13) the wide build wins by 24-26 % up to S x wavefront = 2 x CUs (3840x2160: 24 / 32 streams
+    // 61.3 / 80.2 against 49.2 / 64.1 Mpx/s with four-wave workgroups, 1920x1080: 32 / 64 streams 40.8 / 76.9 against 32.9 / 61.6) and still by 5 % at 2.8 x CUs
+    // (48 streams at 3840x2160: 96.3 against 91.5).  Rule: wide up to 2.5 x CUs, the throughput build above.  The latency build (256 VGPRs, two four-wave
+    // workgroups per CU) lost its range to the wide build and runs only when forced.  8-bit samples only (the 16-bit kernel has one build).
+    // THOR_HIP_KERNEL=std|lat|wide forces one (tests, A/B).
     int pool_waves = kWaves;
     if constexpr (sizeof(PIX) == 1) {
       const long lat_cap = (long)thor_lat_workgroups_per_cu() * prop.multiProcessorCount;
       const long wide_cap = (long)thor_wide_workgroups_per_cu() * prop.multiProcessorCount;
       const long wave_front = (long)S * (rows < (cols + 1) / 2 ? rows : (cols + 1) / 2);
-      D.kern = wide_cap > 0 && wave_front <= wide_cap ? 2 : lat_cap > 0 && wave_front <= lat_cap ? 1 : 0;
+      D.kern = wide_cap > 0 && 2 * wave_front <= 5 * wide_cap ? 2 : 0;
       if (const char* e = getenv("THOR_HIP_KERNEL")) {
         if (!strcmp(e, "lat")) D.kern = lat_cap > 0 ? 1 : 0;
         else if (!strcmp(e, "wide")) D.kern = wide_cap > 0 ? 2 : 0;
