@@ -13,6 +13,9 @@ int ref_quantize(int16_t* coeff, int16_t* coeffq, int qp, int size, int coeff_bl
   return quantize(coeff, coeffq, qp, size, coeff_block_type, NULL);
 }
 int ref_quote_mv_bits(int dy, int dx) { return quote_mv_bits(dy, dx); }
+/* widesad_calc (enc/encode_block.c:430-453, file-static): SAD at the five horizontal offsets -3 -1 0 1 3, the best one and its offset; 16x16 with use_simd
+ * takes widesad_calc_simd (enc/enc_kernels.c:84-113), which needs `a` 16-byte aligned */
+unsigned ref_widesad_calc(uint8_t* a, uint8_t* b, int astride, int bstride, int w, int h, int* x) { return widesad_calc(a, b, astride, bstride, w, h, x); }
 /* bit length of write_coeff (enc/write_bits.c:145) for one coefficient block */
 int ref_coeff_bits(int16_t* coeff, int size, int type) {
   static uint8_t buf[1 << 16];

@@ -26,6 +26,20 @@ unsigned orc_sad(const uint8_t* a, int astride, const uint8_t* b, int bstride, i
   return s;
 }
 
+/* ---- widesad_calc, enc/encode_block.c:430-453 (scalar: first strictly smaller SAD over the offsets -3 -1 0 1 3) and widesad_calc_simd,
+ * enc/enc_kernels.c:84-113 (16x16: min over (sad << 3 | code), code rising with the offset) - both keep the LEFTMOST offset among equal SADs */
+unsigned orc_widesad(const uint8_t* a, int astride, const uint8_t* b, int bstride, int w, int h, int* x) {
+  static const int off[5] = {-3, -1, 0, 1, 3};
+  unsigned best = 1u << 31;
+  int bx = 0;
+  for (int k = 0; k < 5; k++) {
+    const unsigned s = orc_sad(a, astride, b + off[k], bstride, w, h);
+    if (s < best) { best = s; bx = off[k]; }
+  }
+  *x = bx;
+  return best;
+}
+
 /* ---- ME bit estimate: quote_mv_bits, enc/encode_block.c:467-515 ------------------------ */
 static int mvlen(int d) {
   d = abs(d);
@@ -227,6 +241,18 @@ unsigned orc_sad16(const uint16_t* a, int astride, const uint16_t* b, int bstrid
   for (int y = 0; y < h; y++)
     for (int x = 0; x < w; x++) s += (unsigned)abs((int)a[y * astride + x] - (int)b[y * bstride + x]);
   return s;
+}
+/* widesad_calc_simd_hbd (enc/enc_kernels.c:84-113 compiled with HBD): 16-bit samples, same rule */
+unsigned orc_widesad16(const uint16_t* a, int astride, const uint16_t* b, int bstride, int w, int h, int* x) {
+  static const int off[5] = {-3, -1, 0, 1, 3};
+  unsigned best = 1u << 31;
+  int bx = 0;
+  for (int k = 0; k < 5; k++) {
+    const unsigned s = orc_sad16(a, astride, b + off[k], bstride, w, h);
+    if (s < best) { best = s; bx = off[k]; }
+  }
+  *x = bx;
+  return best;
 }
 void orc_interp_luma16(uint16_t* dst, int dstride, const uint16_t* ref, int rstride, int w, int h, int mvx, int mvy, int sign,
                        int bipred, int pic_w, int pic_h, int xpos, int ypos, int bitdepth) {

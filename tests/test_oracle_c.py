@@ -145,3 +145,29 @@ def test_tu_pipeline_16bit(bd):
             assert (rec == K4[f'tu_rec{k}'][i]).all(), ('rec', k, i)
         k += 1
     assert k == 24
+
+
+def test_widesad():
+    """widesad_calc / widesad_calc_simd (enc/encode_block.c:430-453, enc/enc_kernels.c:84-113): SAD at the offsets -3 -1 0 1 3, the smallest and its offset, the
+    leftmost among equal ones - 8-bit vectors recorded through the file-static dispatcher with the scalar AND the SIMD path (they agree), 16-bit vectors from
+    widesad_calc_simd_hbd at bitdepth 10 and 12 (tests/golden/gen_kat6.py -> kat6.npz; content with exact ties: flat, period-2 / period-4 columns)."""
+    K6 = np.load(os.path.join(GOLD, 'kat6.npz'))
+    x = C.c_int()
+    planes = np.ascontiguousarray(K6['ws8_planes'])
+    ties = 0
+    for k in range(int(K6['ws8_n'])):
+        org = np.ascontiguousarray(K6[f'ws8_org{k}'])
+        pi, by, bx, w, h = (int(v) for v in K6[f'ws8_arg{k}'])
+        want_s, want_x = (int(v) for v in K6[f'ws8_out{k}'])
+        got = O.orc_widesad(vp(org), w, C.c_void_p(planes[pi].ctypes.data + by * 96 + bx), 96, w, h, C.byref(x))
+        assert (got, x.value) == (want_s, want_x), (k, got, x.value, want_s, want_x)
+        sads = [O.orc_sad(vp(org), w, C.c_void_p(planes[pi].ctypes.data + by * 96 + bx + o), 96, w, h) for o in (-3, -1, 0, 1, 3)]
+        ties += sads.count(min(sads)) > 1
+    assert ties >= 20, 'the vectors are meant to hold exact ties between offsets'
+    for k in range(int(K6['ws16_n'])):
+        org = np.ascontiguousarray(K6[f'ws16_org{k}'])
+        bd, pi, by, bx = (int(v) for v in K6[f'ws16_arg{k}'])
+        plane = np.ascontiguousarray(K6[f'ws16_planes_bd{bd}'][pi])
+        want_s, want_x = (int(v) for v in K6[f'ws16_out{k}'])
+        got = O.orc_widesad16(vp(org), 16, C.c_void_p(plane.ctypes.data + 2 * (by * 96 + bx)), 96, 16, 16, C.byref(x))
+        assert (got, x.value) == (want_s, want_x), (k, bd, got, x.value, want_s, want_x)
