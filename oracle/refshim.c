@@ -25,6 +25,20 @@ int ref_coeff_bits(int16_t* coeff, int size, int type) {
   return get_bit_pos(&s);
 }
 
+/* The two sub-block tests of the early-skip check (enc/encode_block.c:2146-2229, file-static): luma = 2x2 average + (N/2)-point transform against half the
+ * threshold, chroma = calc_cbp on the residual's column sums - with use_simd (what the encoder runs) calc_cbp_simd (enc/enc_kernels.c:828-907).  They read
+ * params->bitdepth only.  pblock is a compact size x size block. */
+int ref_early_skip_sub(int chroma, uint8_t* orig, int ostride, int size, int qp, uint8_t* pblock, float thr, int bitdepth, int simd) {
+  static enc_params p;
+  static encoder_info_t ei;
+  memset(&p, 0, sizeof p);
+  memset(&ei, 0, sizeof ei);
+  p.bitdepth = bitdepth;
+  ei.params = &p;
+  use_simd = simd;
+  return chroma ? check_early_skip_sub_blockC(&ei, orig, ostride, size, qp, pblock, thr) : check_early_skip_sub_block(&ei, orig, ostride, size, qp, pblock, thr);
+}
+
 /* encoder_speed > 0 sub-pel approximations (file-static in encode_block.c) and their SIMD twins */
 unsigned ref_fasthalf(uint8_t* a, uint8_t* b, int as, int bs, int w, int h, int* x, int* y, int simd) {
   if (simd) return sad_calc_fasthalf_simd_lbd(a, b, as, bs, w, h, x, y);

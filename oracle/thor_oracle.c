@@ -152,6 +152,57 @@ static void zigzag(int n, int* zz) {
 static const int QSCALE[6] = {26214, 23302, 20560, 18396, 16384, 14564};
 static const int DQSCALE[6] = {40, 45, 51, 57, 64, 72};
 
+/* ---- the sub-block tests of the early-skip check, enc/encode_block.c:2123-2229 ----------------------------------------------------------------
+ * luma (check_early_skip_sub_block): residual, 2x2 average (size > 4), forward transform of size / 2, any |coefficient| > (int)(0.5 * thr * first quantiser
+ * level) - thr is a float, the product is formed in double as the reference's C does. */
+int orc_early_skip_sub(const uint8_t* org, int ostride, const uint8_t* pred, int pstride, int size, int qp, float thr, int bitdepth) {
+  int16_t res[32 * 32], tmp[16 * 16], coef[16 * 16];
+  for (int i = 0; i < size; i++)
+    for (int j = 0; j < size; j++) res[i * size + j] = (int16_t)((int)org[i * ostride + j] - (int)pred[i * pstride + j]);
+  int n = size;
+  double rel = thr;
+  const int16_t* in = res;
+  if (size > 4) {
+    n = size / 2;
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++)
+        tmp[i * n + j] = (int16_t)((res[2 * i * size + 2 * j] + res[2 * i * size + 2 * j + 1] + res[(2 * i + 1) * size + 2 * j] + res[(2 * i + 1) * size + 2 * j + 1] + 2) >> 2);
+    in = tmp;
+    rel = 0.5 * thr;
+  }
+  orc_fwd_transform(in, coef, n, 0, bitdepth);
+  const int shift2 = 21 - ilog2((unsigned)n) + qp / 6;
+  const int threshold = (int)(rel * ((double)(1 << shift2) / (double)QSCALE[qp % 6]));
+  int flag = 0;
+  for (int k = 0; k < n * n; k++) flag |= abs((int)coef[k]) > threshold;
+  return flag;
+}
+/* chroma (check_early_skip_sub_blockC -> calc_cbp_simd, enc/enc_kernels.c:828-907: the form the encoder EXECUTES, use_simd = 1): int16 column sums of the
+ * residual with 16-bit wrap-around; 16 / 8 wide: any |sum| > threshold as int16; 4 wide: per column PAIR (2k, 2k+1) the test is sum[2k+1] + |sum[2k]| >
+ * threshold (arithmetic on sign-extended halves) - NOT the scalar calc_cbp's |sum[2k] + sum[2k+1]|. */
+int orc_early_skip_subC(const uint8_t* org, int ostride, const uint8_t* pred, int pstride, int size, int qp, float thr, int bitdepth) {
+  const int shift2 = 21 - 5 + qp / 6;
+  const int threshold = ((int)(thr * ((double)(1 << shift2) / (double)QSCALE[qp % 6]))) << (bitdepth - 8);
+  int16_t col[16];
+  for (int j = 0; j < size; j++) {
+    int16_t s = 0;
+    for (int i = 0; i < size; i++) s = (int16_t)(s + (int16_t)((int)org[i * ostride + j] - (int)pred[i * pstride + j]));
+    col[j] = s;
+  }
+  if (size == 4) {
+    for (int k = 0; k < 2; k++) {
+      const int lo = col[2 * k], hi = col[2 * k + 1];
+      if (hi + (int)(int16_t)(lo < 0 ? -lo : lo) > threshold) return 1;
+    }
+    return 0;
+  }
+  for (int j = 0; j < size; j++) {
+    const int16_t a = (int16_t)(col[j] < 0 ? -col[j] : col[j]);
+    if (a > (int16_t)threshold) return 1;
+  }
+  return 0;
+}
+
 /* quantize(), enc/encode_block.c:84-160 (no weight matrix).  coeff/coeffq compact q x q. */
 int orc_quantize(const int16_t* coeff, int16_t* coeffq, int qp, int size, int intra_block) {
   int q = size < 16 ? size : 16, N = q * q, zz[256], sc[256], sq[256];

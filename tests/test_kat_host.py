@@ -60,3 +60,20 @@ def test_clpf_and_cdef_host_build_match_reference_kat(L, bd):
         got = np.zeros_like(want)
         L.h_cdef_filter(P(plane), plane.shape[1], plane.shape[0], plane.shape[1], bd, bsize, len(par), P(par), P(got))
         assert (got == want).all(), bsize
+
+
+def test_early_skip_sub_block_tests_host_build_match_reference_kat(tmp_path):
+    """early_skip_sub / early_skip_subC (tk_block.h; the luma and the chroma sub-block test of check_early_skip) in the 1-lane host build against the 288 known
+    answers recorded from the reference's check_early_skip_sub_block / _sub_blockC with use_simd = 1 (tests/golden/gen_kat7.py) - luma 8 / 16 / 32, chroma 4 / 8 / 16
+    (incl. the 4-wide column-pair form of calc_cbp_simd), three qp, two thresholds, residuals around the decision boundary."""
+    so = str(tmp_path / 'kat_host_es.so')
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-fno-strict-aliasing', '-DTHOR_HOSTSIM', '-ffp-contract=off', '-shared', '-fPIC', '-o', so,
+                           os.path.join(ROOT, 'tests', 'hostsim', 'kat_host_es.cpp')])
+    H = C.CDLL(so)
+    H.h_early_skip_sub.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+    K7 = np.load(os.path.join(ROOT, 'tests', 'golden', 'kat7.npz'))
+    org, pred, arg, want = (np.ascontiguousarray(K7[k]) for k in ('es_org', 'es_pred', 'es_arg', 'es_out'))
+    for k in range(len(want)):
+        chroma, size, qp, thr10 = (int(v) for v in arg[k])
+        got = H.h_early_skip_sub(chroma, P(org[k]), 32, P(pred[k]), 32, size, qp, thr10 / 10.0, 8)
+        assert got == int(want[k]), (k, chroma, size, qp, thr10, got, int(want[k]))

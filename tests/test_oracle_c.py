@@ -171,3 +171,17 @@ def test_widesad():
         want_s, want_x = (int(v) for v in K6[f'ws16_out{k}'])
         got = O.orc_widesad16(vp(org), 16, C.c_void_p(plane.ctypes.data + 2 * (by * 96 + bx)), 96, 16, 16, C.byref(x))
         assert (got, x.value) == (want_s, want_x), (k, bd, got, x.value, want_s, want_x)
+
+
+def test_early_skip_sub_block_tests():
+    """The two sub-block tests of the early-skip check (enc/encode_block.c:2146-2229; chroma in the form the encoder executes: calc_cbp_simd,
+    enc/enc_kernels.c:828-907) - 288 vectors recorded from the reference's file-static functions around the decision boundary (tests/golden/gen_kat7.py)."""
+    K7 = np.load(os.path.join(GOLD, 'kat7.npz'))
+    O.orc_early_skip_sub.argtypes = O.orc_early_skip_subC.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+    org, pred, arg, want = (np.ascontiguousarray(K7[k]) for k in ('es_org', 'es_pred', 'es_arg', 'es_out'))
+    for k in range(len(want)):
+        chroma, size, qp, thr10 = (int(v) for v in arg[k])
+        f = O.orc_early_skip_subC if chroma else O.orc_early_skip_sub
+        got = f(vp(org[k]), 32, vp(pred[k]), 32, size, qp, thr10 / 10.0, 8)
+        assert got == int(want[k]), (k, chroma, size, qp, thr10, got, int(want[k]))
+    assert 0 < want.sum() < len(want)
